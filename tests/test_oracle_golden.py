@@ -1,0 +1,228 @@
+"""Pins the CPU oracle (oracle/) against the reference's own golden vectors
+and known-answer tests.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import IDX_COMBOS, as_csr
+from oracle import oracle
+
+
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_mul_csr_vec(golden, idx, ptr):
+    # sprs/src/sparse/prod.rs:375-398 (includes an empty row)
+    fx = golden["mul_csr_vec"]
+    shape, ip, ix, dt = as_csr(fx, idx, ptr)
+    y = np.zeros(5)
+    oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, np.array(fx["x"]), y)
+    assert np.all(np.abs(y - np.array(fx["expected"])) < fx["epsilon"])
+    assert y[1] == 0.0
+    # accumulate semantics (prod.rs:121: starts from the existing y)
+    y2 = np.arange(5, dtype=np.float64)
+    oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, np.array(fx["x"]), y2)
+    assert np.all(np.abs(y2 - (np.arange(5) + np.array(fx["expected"]))) < fx["epsilon"])
+    assert y2[1] == 1.0
+
+
+def test_mul_csc_vec_via_transpose(golden):
+    # prod.rs:325-348: a CSC matrix is the CSR form of its transpose; convert
+    # (csmat.rs:1782-1829) and use the CSR kernel.
+    fx = golden["mul_csc_vec"]
+    shape, ip, ix, dt = as_csr(fx)
+    ip2, ix2, dt2 = oracle.convert_storage(5, 5, ip, ix, dt)
+    y = np.zeros(5)
+    oracle.mul_acc_mat_vec_csr(shape, ip2, ix2, dt2, np.array(fx["x"]), y)
+    assert np.all(np.abs(y - np.array(fx["expected"])) < fx["epsilon"])
+
+
+def test_spmv_dim_mismatch(golden):
+    shape, ip, ix, dt = as_csr(golden["mat3"])  # 5x4
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, np.zeros(5), np.zeros(5))
+    assert e.value.code == oracle.DIM_MISMATCH and "Dimension mismatch" in str(e.value)
+
+
+def test_spmv_omp_equals_serial():
+    rng = np.random.default_rng(0)
+    n, m = 3000, 2500
+    import scipy.sparse as sp
+    a = sp.random(n, m, density=0.01, random_state=1, format="csr")
+    a.sort_indices()
+    x = rng.random(m)
+    y1, y2 = rng.random(n), None
+    y2 = y1.copy()
+    args = ((n, m), a.indptr.astype(np.uint64), a.indices.astype(np.uint64), a.data)
+    oracle.mul_acc_mat_vec_csr(*args, x, y1)
+    oracle.mul_acc_mat_vec_csr(*args, x, y2, threads=4)
+    assert np.array_equal(y1, y2)
+
+
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_symbolic_and_numeric(golden, idx, ptr):
+    # smmp.rs:422-465
+    a, b, exp = (as_csr(golden[k], idx, ptr) for k in ("mat1", "mat2", "mat1_matprod_mat2"))
+    c_ip, c_ix = oracle.symbolic(a[0], a[1], a[2], b[0], b[1], b[2])
+    assert np.array_equal(c_ip, exp[1]) and np.array_equal(c_ix, exp[2])
+    c_dt = oracle.numeric(*a, *b, c_ip, c_ix)
+    assert np.array_equal(c_dt, exp[3])
+
+
+@pytest.mark.parametrize("threads", [0, 1, 2, 4, 8])
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_mul_csr_csr(golden, idx, ptr, threads):
+    # prod.rs:425-436, smmp.rs:467-473, 491-501 (thread-count invariance)
+    a, b = as_csr(golden["mat1"], idx, ptr), as_csr(golden["mat2"], idx, ptr)
+    for rhs, key in ((a, "mat1_self_matprod"), (b, "mat1_matprod_mat2")):
+        exp = as_csr(golden[key], idx, ptr)
+        shape, ip, ix, dt = oracle.mul_csr_csr(*a, *rhs, threads=threads)
+        assert shape == exp[0]
+        assert ip.dtype == ptr and ix.dtype == idx
+        assert np.array_equal(ip, exp[1]) and np.array_equal(ix, exp[2]) and np.array_equal(dt, exp[3])
+
+
+def test_mul_storage_dispatch(golden):
+    # prod.rs:438-458 (mul_csc_csc, mul_csc_csr); dispatch csmat.rs:1933-1948
+    def m(k):
+        shape, ip, ix, dt = as_csr(golden[k])
+        return dict(storage=golden[k]["storage"], shape=shape, indptr=ip, indices=ix, data=dt)
+
+    def same(res, k):
+        e = m(k)
+        return (res["storage"] == e["storage"] and tuple(res["shape"]) == tuple(e["shape"])
+                and np.array_equal(res["indptr"], e["indptr"])
+                and np.array_equal(res["indices"], e["indices"])
+                and np.array_equal(res["data"], e["data"]))
+
+    assert same(oracle.csmat_mul_csmat(m("mat1_csc"), m("mat4")), "mat1_csc_matprod_mat4")
+    assert same(oracle.csmat_mul_csmat(m("mat1"), m("mat1_csc")), "mat1_self_matprod")
+    r = oracle.csmat_mul_csmat(m("mat1_csc"), m("mat1"))      # CSC result ...
+    assert r["storage"] == "CSC"
+    ip, ix, dt = oracle.convert_storage(5, 5, r["indptr"], r["indices"], r["data"])  # ... .to_other_storage()
+    e = m("mat1_self_matprod")
+    assert np.array_equal(ip, e["indptr"]) and np.array_equal(ix, e["indices"]) and np.array_equal(dt, e["data"])
+
+
+def test_mul_zero_rows(golden):
+    # smmp.rs:475-489 (issue 239)
+    fx = golden["mul_zero_rows"]
+    z = np.zeros(0, dtype=np.uint64)
+    shape, ip, ix, dt = oracle.mul_csr_csr(
+        tuple(fx["a_shape"]), np.array(fx["a_indptr"], dtype=np.uint64), z, np.zeros(0),
+        tuple(fx["b_shape"]), np.array(fx["b_indptr"], dtype=np.uint64), z, np.zeros(0))
+    assert shape == tuple(fx["c_shape"]) and ix.size == fx["c_nnz"] and list(ip) == [0]
+
+
+def test_one_long_row_multithreaded():
+    # smmp.rs:503-513: 1 x 100 empty row times 100 x 10 zero matrix, Fixed(4)
+    z = np.zeros(0, dtype=np.uint64)
+    shape, ip, ix, dt, used = oracle.mul_csr_csr(
+        (1, 100), np.zeros(2, dtype=np.uint64), z, np.zeros(0),
+        (100, 10), np.zeros(101, dtype=np.uint64), z, np.zeros(0), threads=4, return_threads=True)
+    assert shape == (1, 10) and ix.size == 0 and used == 1     # min(rows.max(1), 4)
+
+
+def test_structure_only_fixtures(golden):
+    # smmp.rs:515-555 (complex values; structure part) and block_matrix.rs:71-108
+    fx = golden["mul_complex_structure"]
+    ip, ix = np.array(fx["indptr"], dtype=np.uint64), np.array(fx["indices"], dtype=np.uint64)
+    c_ip, c_ix = oracle.symbolic((4, 4), ip, ix, (4, 4), ip, ix)
+    assert list(c_ip) == fx["c_indptr"] and list(c_ix) == fx["c_indices"]
+    fx = golden["block_matrix_structure"]
+    u = lambda k: np.array(fx[k], dtype=np.uint64)
+    c_ip, c_ix = oracle.symbolic(tuple(fx["a_shape"]), u("a_indptr"), u("a_indices"),
+                                 tuple(fx["b_shape"]), u("b_indptr"), u("b_indices"))
+    assert list(c_ip) == fx["c_indptr"] and list(c_ix) == fx["c_indices"]
+
+
+def test_structural_zeros_kept():
+    # [1,-1] . [1;1] keeps one stored 0.0 (no numeric pruning, smmp.rs:109-119)
+    u = lambda *v: np.array(v, dtype=np.uint64)
+    shape, ip, ix, dt = oracle.mul_csr_csr((1, 2), u(0, 2), u(0, 1), np.array([1.0, -1.0]),
+                                           (2, 1), u(0, 1, 2), u(0, 0), np.array([1.0, 1.0]))
+    assert shape == (1, 1) and list(ip) == [0, 1] and list(ix) == [0] and dt[0] == 0.0
+
+
+def test_dense_products_via_spmv(golden):
+    # prod.rs:502-542, 580-595: csr_mulacc_dense_{row,col}maj == SpMV per rhs column
+    for mk, dk, ek in (("mat1", "mat_dense1", "mat1_times_mat_dense1"),
+                       ("mat5", "mat_dense2", "mat5_times_mat_dense2")):
+        shape, ip, ix, dt = as_csr(golden[mk])
+        rhs = np.array(golden[dk])
+        exp = np.array(golden[ek]["rows"])
+        out = np.zeros((shape[0], rhs.shape[1]))
+        for j in range(rhs.shape[1]):
+            col = np.zeros(shape[0])
+            oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, rhs[:, j].copy(), col)
+            out[:, j] = col
+        assert np.all(np.abs(out - exp) <= golden[ek]["epsilon"])
+
+
+def test_dot_product_row_primitive(golden):
+    # vec.rs:1648-1673: sparse row . dense == 16 exactly (a 1-row SpMV)
+    fx = golden["dot_product"]
+    y = np.zeros(1)
+    oracle.mul_acc_mat_vec_csr((1, fx["dim"]), np.array([0, 4], dtype=np.uint64),
+                               np.array(fx["indices"], dtype=np.uint64), np.array(fx["data"]),
+                               np.array(fx["dense"]), y)
+    assert y[0] == fx["expected"]
+
+
+def test_eye_identity():
+    # csmat.rs:406-426 / lib.rs:52-73 doc tests: eye * x == x, eye * A == A  (config 1)
+    shape, ip, ix, dt = oracle.eye(1000)
+    x = 0.5 + np.arange(1000) / 1000.0
+    y = np.zeros(1000)
+    oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, x, y)
+    assert np.array_equal(x, y)
+    r = oracle.mul_csr_csr(shape, ip, ix, dt, shape, ip, ix, dt)
+    assert np.array_equal(r[1], ip) and np.array_equal(r[2], ix) and np.array_equal(r[3], dt)
+
+
+def test_gh374_index_overflow():
+    # sprs/tests/gh374.rs:10-33: transposing needs row indices wider than I.
+    # u32 twin of the u16 case: 2^32+... rows cannot be allocated here, so pin
+    # the check itself: mat.rows() = 2^32 does not fit I = u32.
+    ip = np.zeros(2, dtype=np.uint64)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.convert_storage(1, 1, ip, np.zeros(0, dtype=np.uint32), np.zeros(0), mat_rows=1 << 32)
+    assert e.value.code == oracle.INDEX_OVERFLOW and "Index type is not large enough to hold" in str(e.value)
+
+
+def test_grid_laplacian_layout():
+    # examples/heat.rs:45-80
+    shape, ip, ix, dt = oracle.grid_laplacian(4, 4)
+    assert shape == (16, 16) and ix.size == 12 + 5 * 4
+    r = 5                                   # interior vertex (1,1)
+    s, e = int(ip[r]), int(ip[r + 1])
+    assert list(ix[s:e]) == [1, 4, 5, 6, 9] and list(dt[s:e]) == [1, 1, -4, 1, 1]
+    assert int(ip[1] - ip[0]) == 1 and ix[0] == 0 and dt[0] == 1.0
+    oracle.check_structure(16, 16, ip, ix)
+
+
+def test_sliced_non_proper_indptr(golden):
+    # slice_outer (slicing.rs:65-89): indptr not rebased, indices/data offset
+    shape, ip, ix, dt = as_csr(golden["mat1"])
+    x = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    full = np.zeros(5)
+    oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, x, full)
+    part = np.zeros(3)
+    s = int(ip[1])
+    oracle.mul_acc_mat_vec_csr((3, 5), ip[1:5], ix[s:], dt[s:], x, part)
+    assert np.array_equal(part, full[1:4])
+
+
+def test_random_vs_scipy_cancellation_free():
+    # independent cross-check: on positive data scipy's structure
+    # equals sprs' after sort_indices()
+    import scipy.sparse as sp
+    a = sp.random(300, 200, density=0.05, random_state=3, format="csr")
+    b = sp.random(200, 250, density=0.05, random_state=4, format="csr")
+    a.data[:] = np.abs(a.data) + 0.5
+    b.data[:] = np.abs(b.data) + 0.5
+    a.sort_indices(); b.sort_indices()
+    c = (a @ b).tocsr(); c.sort_indices()
+    u = lambda v: v.astype(np.uint64)
+    for t in (1, 3):
+        shape, ip, ix, dt = oracle.mul_csr_csr((300, 200), u(a.indptr), u(a.indices), a.data,
+                                               (200, 250), u(b.indptr), u(b.indices), b.data, threads=t)
+        assert np.array_equal(ip, c.indptr) and np.array_equal(ix, c.indices)
+        assert np.allclose(dt, c.data, rtol=1e-13, atol=0)
