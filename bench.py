@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py — CSR SpMV throughput of the HIP path on BASELINE.json's headline
+configuration: R-MAT 10M x 10M, ~32 nnz/row, f64, sprs-default usize (64-bit)
+indices and indptr.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one y = A*x over the whole matrix (for N > 1: the local row-block
+multiply plus the all-gather-v of y over xGMI/RCCL).  The matrix, x and y are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Workload selection (for parity-sized runs, never for the headline):
+  --workload rmat10m (default) | rmat1m | laplace4096 | rmat:<n>:<nnz_per_row>
+  --idx-bytes 8 (default, sprs usize) | 4
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(rows, cols, nnz, idx_bytes, iptr_bytes, accumulate=False):
+    """nnz*(8+S_I) + (rows+1)*S_P + cols*8 [x once] + rows*8 [y] (+rows*8 if accumulating)."""
+    return nnz * (8 + idx_bytes) + (rows + 1) * iptr_bytes + cols * 8 + rows * 8 * (2 if accumulate else 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="rmat10m")
+    ap.add_argument("--idx-bytes", type=int, default=8, choices=(4, 8))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", type=int, default=None, help="spmv_kernel option for A/B (1 tiled, 2 wave-per-row)")
+    ap.add_argument("--tile", type=int, default=None)
+    ap.add_argument("--nt", type=int, default=None)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import sprs_amd
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    from sprs_amd.dist import RowShardedSpMV
+    from sprs_amd import _ffi
+    import ctypes as C
+    _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
+    for opt, val in (("spmv_kernel", args.kernel), ("spmv_tile", args.tile), ("spmv_nt", args.nt)):
+        if val is not None:
+            sprs_amd.set_option(opt, val)
+
+    # ---- workload -----------------------------------------------------------
+    idt = torch.int64 if args.idx_bytes == 8 else torch.int32
+    t0 = time.time()
+    wl = args.workload
+    if wl == "rmat10m":
+        n, k = 10_000_000, 32
+        indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=idt)
+        name = "R-MAT 10M x 10M, ~32 nnz/row (Graph500 a,b,c,d=.57,.19,.19,.05; seed 1)"
+    elif wl == "rmat1m":
+        n, k = 1_000_000, 16
+        indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=idt)
+        name = "R-MAT 1M x 1M, ~16 nnz/row"
+    elif wl == "laplace4096":
+        n = 4096 * 4096
+        indptr, indices, data = gen.grid_laplacian(4096, 4096, device=dev, idx_dtype=idt, ptr_dtype=idt)
+        name = "5-pt Laplacian 4096^2 grid"
+    elif wl.startswith("rmat:"):
+        _, n, k = wl.split(":")
+        n, k = int(n), float(k)
+        indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=idt)
+        name = "R-MAT %d x %d, ~%g nnz/row" % (n, n, k)
+    else:
+        sys.exit("unknown workload " + wl)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    nnz_total = indices.numel()
+    x = gen.dense_vector(n, seed=3, device=dev)
+    stream = torch.cuda.current_stream()
+
+    handles = {}
+
+    def local_spmv(block, xv, y_block):
+        key = id(block)
+        if key not in handles:
+            rows_b, cols_b, ip, ix, dt = block
+            handles[key] = DeviceCsMat.wrap_torch((rows_b, cols_b), ip, ix, dt)
+        out = DeviceVec.borrow(y_block)
+        prod.csmat_mul_vec(handles[key], DeviceVec.borrow(xv), out=out, stream=stream)
+
+    sh = RowShardedSpMV((n, n), indptr, indices, data, local_spmv)
+    del indptr, indices, data   # only the rank's block stays resident
+    torch.cuda.empty_cache()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        sh.step(x)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps ----------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t_start = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record(stream)
+        sh.local_spmv(sh.block, x, sh.y[sh.r0:sh.r1])   # kernel(s) on `stream`, bracketed by HIP events
+        ev[s][1].record(stream)
+        sh.exchange()
+    torch.cuda.synchronize()
+    barrier()
+    t_total = time.perf_counter() - t_start
+
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([t_total], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_total = float(tt.item())
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg_ms = float(np.mean(kern_ms))
+
+    ms_per_step = t_total * 1e3 / args.steps
+    gflops = 2.0 * nnz_total * args.steps / t_total / 1e9
+    blk_rows, blk_cols = sh.block[0], sh.block[1]
+    alg_bytes = algorithmic_bytes(blk_rows, blk_cols, sh.block_nnz, args.idx_bytes, args.idx_bytes)
+    achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "CSR SpMV GFLOP/s",
+        "value": round(gflops, 3),
+        "unit": "GFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": name,
+            "rows": n, "cols": n, "nnz": nnz_total,
+            "index_bytes": args.idx_bytes, "indptr_bytes": args.idx_bytes,
+            "partition": "nnz-balanced row blocks x%d, direct all-gather-v of y" % world if world > 1 else "single GPU",
+            "generate_s": round(gen_s, 2),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "sprs_hip::spmv_tile_kernel" if sprs_amd.get_option("spmv_kernel") != 2 else "sprs_hip::spmv_rowwave_kernel",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms_avg": round(kern_avg_ms, 5),
+            "kernel_ms_min": round(float(np.min(kern_ms)), 5),
+            "traffic": None,   # rocprofv3 --pmc passes: see profiles/ and DESIGN.md
+        },
+    }
+
+    # ---- CPU baseline (rank 0, N = 1): the oracle on the host cores -------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle   # test infrastructure: the checker + the timed CPU port, never the product
+        npdt = np.uint64 if args.idx_bytes == 8 else np.uint32
+        ip_h = sh.block[2].cpu().numpy().view(npdt)
+        ix_h = sh.block[3].cpu().numpy().view(npdt)
+        dt_h = sh.block[4].cpu().numpy()
+        x_h = x.cpu().numpy()
+        y_gpu = sh.y.cpu().numpy()
+        reps = 3
+        ts = []
+        for _ in range(reps):
+            y_h = np.zeros(n)
+            t = time.perf_counter()
+            oracle.mul_acc_mat_vec_csr((n, n), ip_h, ix_h, dt_h, x_h, y_h)
+            ts.append(time.perf_counter() - t)
+        serial_s = min(ts)
+        ncores = oracle.num_procs()
+        tp = []
+        for _ in range(reps):
+            y_p = np.zeros(n)
+            t = time.perf_counter()
+            oracle.mul_acc_mat_vec_csr((n, n), ip_h, ix_h, dt_h, x_h, y_p, threads=ncores)
+            tp.append(time.perf_counter() - t)
+        par_s = min(tp)
+        denom = np.maximum(np.abs(y_h), np.abs(y_gpu))
+        rel = np.where(denom > 0, np.abs(y_gpu - y_h) / np.where(denom > 0, denom, 1.0), 0.0)
+        out["cpu_baseline"] = {
+            "value": round(2.0 * nnz_total / serial_s / 1e9, 4),
+            "unit": "GFLOP/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": "whole %s matrix, best of %d SpMVs; C restatement of sprs' serial prod::mul_acc_mat_vec_csr "
+                      "(sprs SpMV is single-threaded; rustc is not available here)" % (wl, reps),
+            "seconds": round(serial_s, 4),
+            "all_cores_value": round(2.0 * nnz_total / par_s / 1e9, 4),
+            "all_cores": ncores,
+            "all_cores_note": "OpenMP row split, NOT in the reference",
+        }
+        out["parity"] = {"max_rel_err_vs_oracle": float(rel.max()), "tolerance": 1e-10,
+                         "ok": bool(rel.max() <= 1e-10)}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,167 @@
+/*
+ * sprs_hip.h — C ABI of libsprs_hip.so, the MI355X (gfx950) backend for the
+ * sprs CSR SpMV / SpGEMM hot path.
+ *
+ * This is the boundary a `sprs-hip-sys` Rust crate binds (rust/sprs-hip-sys,
+ * following the reference's own *_sys + safe-wrapper split,
+ * suitesparse_bindings/suitesparse_ldl_sys/src/lib.rs:10-80 and
+ * sprs_suitesparse_ldl/src/lib.rs:53-129).  Conventions, all taken from how
+ * the reference already crosses a C ABI:
+ *   - CSR is passed as (rows, cols, indptr*, indices*, data*) raw pointers
+ *     (sprs-benches/src/main.rs:28-41  <->  sprs-benches/src/eigen.cpp:6-29);
+ *   - index widths are given in bytes: 8 = usize/u64/i64/isize (sprs default,
+ *     sprs/src/sparse.rs:111-122), 4 = u32/i32 (sprs/src/indexing.rs:124-130);
+ *   - matrices are opaque handles freed by an explicit call, owned on the
+ *     Rust side by a struct with Drop (sprs_suitesparse_umfpack/src/lib.rs:30-46);
+ *   - every entry point returns a status; nothing unwinds across the boundary.
+ *     Status codes map 1:1 onto the reference's panics / errors so the wrapper
+ *     can re-raise them with the same text (see each code).
+ *
+ * All citations are relative to the sprs repository root.
+ * No torch / C++ types appear here: plain pointers and sizes only.
+ */
+#ifndef SPRS_HIP_H
+#define SPRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status ----------------------------------------------------------- */
+
+#define SPRS_HIP_OK 0
+/* assert "Dimension mismatch": prod.rs:114-117, prod.rs:283-285; assert_eq!(lhs.cols(), rhs.rows()) smmp.rs:207 */
+#define SPRS_HIP_DIM_MISMATCH 1
+/* assert "Storage mismatch": prod.rs:118, prod.rs:286 */
+#define SPRS_HIP_STORAGE_MISMATCH 2
+/* panic "Index type is not large enough to hold ...": csmat.rs:1794-1797; I::from_usize / Iptr::from_usize smmp.rs:116,121 */
+#define SPRS_HIP_INDEX_OVERFLOW 3
+/* StructureError::{Unsorted,SizeMismatch,OutOfRange}: errors.rs:4-8, sparse.rs:300-358 */
+#define SPRS_HIP_BAD_STRUCTURE 4
+/* null pointer / unsupported width / misaligned device buffer */
+#define SPRS_HIP_INVALID_ARG 5
+/* hipMalloc failed */
+#define SPRS_HIP_OUT_OF_MEMORY 6
+/* any other HIP runtime error -> LinalgError::ThirdPartyError(code, msg), errors.rs:70,94-96 */
+#define SPRS_HIP_HIP_ERROR 7
+/* no usable gfx950 device: the product path never falls back to the CPU */
+#define SPRS_HIP_NO_DEVICE 8
+
+/* CompressedStorage, sprs/src/sparse.rs:30-40 */
+#define SPRS_HIP_CSR 0
+#define SPRS_HIP_CSC 1
+
+/* Thread-local text of the last failure on the calling thread ("" if none),
+ * and the raw hipError_t behind a SPRS_HIP_HIP_ERROR (0 otherwise). */
+const char *sprs_hip_last_error(void);
+int32_t sprs_hip_last_hip_code(void);
+/* "sprs_hip <version> gfx950 ..." */
+const char *sprs_hip_version(void);
+
+/* ---- device / raw buffers (DeviceVec plumbing) ------------------------- */
+
+int32_t sprs_hip_device_count(int32_t *count);
+int32_t sprs_hip_set_device(int32_t device);
+int32_t sprs_hip_malloc(void **dev_ptr, uint64_t bytes);
+int32_t sprs_hip_free(void *dev_ptr);
+int32_t sprs_hip_memcpy_h2d(void *dev_dst, const void *host_src, uint64_t bytes);
+int32_t sprs_hip_memcpy_d2h(void *host_dst, const void *dev_src, uint64_t bytes);
+int32_t sprs_hip_memcpy_d2d(void *dev_dst, const void *dev_src, uint64_t bytes, void *stream);
+int32_t sprs_hip_memset(void *dev_dst, int32_t byte_value, uint64_t bytes, void *stream);
+int32_t sprs_hip_synchronize(void *stream); /* NULL = whole device */
+
+/* ---- device CSR/CSC container: twin of CsMatBase (sparse.rs:94-122) ---- */
+
+typedef struct sprs_hip_csmat sprs_hip_csmat;
+
+/* Copies a host matrix into device buffers OWNED by the handle (the host
+ * arrays stay the caller's).  `indptr` has outer+1 entries and may be
+ * non-zero-based, as slice_outer views are (indptr.rs:118-124, 216-219):
+ * `indices`/`data` then point at the element addressed by indptr[0], and the
+ * device copy is rebased (to_proper, indptr.rs:206-214).
+ * validate != 0 runs check_compressed_structure (sparse.rs:300-358) first and
+ * returns SPRS_HIP_BAD_STRUCTURE where CsMat::new would panic; validate == 0
+ * is new_trusted / new_unchecked (csmat.rs:265-301). */
+int32_t sprs_hip_csmat_upload(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols,
+                              const void *indptr, int32_t iptr_bytes, const void *indices,
+                              int32_t idx_bytes, const double *data, int32_t validate);
+
+/* Wraps buffers that already live on the current device (NOT owned, must
+ * outlive the handle; zero-based indptr; 16-byte aligned). */
+int32_t sprs_hip_csmat_wrap_device(sprs_hip_csmat **out, int32_t storage, uint64_t rows,
+                                   uint64_t cols, uint64_t nnz, const void *dev_indptr,
+                                   int32_t iptr_bytes, const void *dev_indices, int32_t idx_bytes,
+                                   const double *dev_data);
+
+/* shape / nnz / widths / storage; any out pointer may be NULL */
+int32_t sprs_hip_csmat_info(const sprs_hip_csmat *m, uint64_t *rows, uint64_t *cols, uint64_t *nnz,
+                            int32_t *iptr_bytes, int32_t *idx_bytes, int32_t *storage);
+/* raw device pointers (into_raw_storage, csmat.rs:946-954), still owned by the handle */
+int32_t sprs_hip_csmat_device_ptrs(const sprs_hip_csmat *m, const void **indptr,
+                                   const void **indices, const double **data);
+/* whole matrix to host buffers of outer+1 / nnz / nnz entries */
+int32_t sprs_hip_csmat_download(const sprs_hip_csmat *m, void *indptr, void *indices, double *data);
+/* outer slices [start, end) only — slice_outer (slicing.rs:65-89).  indptr_out
+ * gets end-start+1 NON-rebased entries (as the reference's view does);
+ * indices_out/data_out get indptr[end]-indptr[start] entries.  Either may be
+ * NULL to query sizes through *nnz_out. */
+int32_t sprs_hip_csmat_download_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end,
+                                      void *indptr_out, void *indices_out, double *data_out,
+                                      uint64_t *nnz_out);
+/* transpose_view (csmat.rs:982-991): free, shares the buffers, flips storage + shape */
+int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **out);
+int32_t sprs_hip_csmat_free(sprs_hip_csmat *m);
+
+/* ---- SpMV --------------------------------------------------------------- */
+
+/* Twin of prod::mul_acc_mat_vec_csr (prod.rs:103-127) when accumulate != 0:
+ *     y[i] += sum_k A[i,k] * x[k]      (y keeps its previous content),
+ * and of `&A * &x` (csmat.rs:2119-2160 -> prod::csr_mulacc_dense_colmaj,
+ * prod.rs:274-298) when accumulate == 0:  y[i] = sum_k A[i,k] * x[k].
+ * x_dev / y_dev are device pointers of x_len / y_len doubles.
+ * SPRS_HIP_DIM_MISMATCH unless A.cols == x_len && A.rows == y_len;
+ * SPRS_HIP_STORAGE_MISMATCH unless A is CSR.  Asynchronous on `stream`
+ * (hipStream_t; NULL = default stream).  Products are formed with a separately
+ * rounded multiply and add like MulAcc (mul_acc.rs:28-30); only the summation
+ * ORDER inside a row differs from the reference (tree instead of left-to-right),
+ * and it is run-to-run deterministic. */
+int32_t sprs_hip_spmv_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t x_len,
+                          double *y_dev, uint64_t y_len, int32_t accumulate, void *stream);
+
+/* One-shot host form (upload, multiply, download, synchronous): what a plain
+ * `prod::mul_acc_mat_vec_csr(mat.view(), &x[..], &mut y[..])` call maps to. */
+int32_t sprs_hip_spmv_f64_host(uint64_t rows, uint64_t cols, const void *indptr,
+                               int32_t iptr_bytes, const void *indices, int32_t idx_bytes,
+                               const double *data, const double *x, uint64_t x_len, double *y,
+                               uint64_t y_len, int32_t accumulate);
+
+/* ---- SpGEMM ------------------------------------------------------------- */
+
+/* Twin of smmp::mul_csr_csr (smmp.rs:196-416): C = A * B, all CSR, same index
+ * types as the operands (smmp.rs:196-199).  Returns a NEW owning handle:
+ * shape (A.rows, B.cols), zero-based indptr, every row strictly increasing
+ * (sort_unstable, smmp.rs:126), structural zeros kept (no value test,
+ * smmp.rs:109-119).  SPRS_HIP_DIM_MISMATCH unless A.cols == B.rows;
+ * SPRS_HIP_STORAGE_MISMATCH unless both are CSR and share index widths;
+ * SPRS_HIP_INDEX_OVERFLOW if nnz(C) does not fit Iptr.  Synchronous. */
+int32_t sprs_hip_spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c);
+
+/* Storage conversion raw::convert_mat_storage / to_other_storage
+ * (csmat.rs:1405-1426, 1782-1829): new owning handle with the other storage
+ * order.  SPRS_HIP_INDEX_OVERFLOW where the reference panics (csmat.rs:1794). */
+int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out);
+
+/* ---- tuning knobs (A/B runs; never needed for correctness) -------------- */
+
+/* name = "spmv_kernel": 0 auto, 1 nnz-tiled streaming kernel, 2 wave-per-row;
+ * name = "spmv_nt": 0/1 non-temporal loads on the matrix streams.
+ * Process-wide.  Unknown names return SPRS_HIP_INVALID_ARG. */
+int32_t sprs_hip_set_option(const char *name, int64_t value);
+int32_t sprs_hip_get_option(const char *name, int64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPRS_HIP_H */

@@ -1,0 +1,439 @@
+// C ABI of libsprs_hip.so (include/sprs_hip.h): handle lifecycle, raw device
+// buffers, status / error plumbing.  Kernels live in spmv.hip and spgemm.hip.
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+namespace sprs_hip {
+
+static thread_local std::string tl_msg;
+static thread_local int32_t tl_hip_code = 0;
+
+void clear_error() {
+    tl_msg.clear();
+    tl_hip_code = 0;
+}
+
+void set_error(int32_t status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tl_msg = buf;
+    if (status != SPRS_HIP_HIP_ERROR) tl_hip_code = 0;
+}
+
+int32_t fail_hip(hipError_t e, const char *what) {
+    tl_hip_code = (int32_t)e;
+    (void)hipGetLastError();   // clear the sticky error
+    if (e == hipErrorOutOfMemory) {
+        set_error(SPRS_HIP_OUT_OF_MEMORY, "out of device memory in %s", what);
+        return SPRS_HIP_OUT_OF_MEMORY;
+    }
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) {
+        set_error(SPRS_HIP_NO_DEVICE, "no usable HIP device (%s) in %s", hipGetErrorString(e), what);
+        tl_hip_code = (int32_t)e;
+        return SPRS_HIP_NO_DEVICE;
+    }
+    char buf[400];
+    snprintf(buf, sizeof buf, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    tl_msg = buf;
+    return SPRS_HIP_HIP_ERROR;
+}
+
+Options &options() {
+    static Options o;
+    return o;
+}
+
+void SpmvPlan::release() {
+    if (tile_row) (void)hipFree(tile_row);
+    for (auto &kv : carry)
+        if (kv.second) (void)hipFree(kv.second);
+    carry.clear();
+    tile_row = nullptr;
+    ntiles = 0;
+    tile = 0;
+}
+
+int32_t alloc_csmat(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols, uint64_t nnz,
+                    int32_t iptr_bytes, int32_t idx_bytes) {
+    auto *m = new sprs_hip_csmat();
+    m->storage = storage;
+    m->rows = rows;
+    m->cols = cols;
+    m->nnz = nnz;
+    m->iptr_bytes = iptr_bytes;
+    m->idx_bytes = idx_bytes;
+    m->owns = true;
+    hipError_t e = hipGetDevice(&m->device);
+    if (e == hipSuccess) e = hipMalloc(&m->indptr, (m->outer() + 1) * (uint64_t)iptr_bytes);
+    // hipMalloc(0) is legal but returns nullptr; keep one element so kernels never see NULL
+    if (e == hipSuccess) e = hipMalloc(&m->indices, (nnz ? nnz : 1) * (uint64_t)idx_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->data, (nnz ? nnz : 1) * sizeof(double));
+    if (e != hipSuccess) {
+        if (m->indptr) (void)hipFree(m->indptr);
+        if (m->indices) (void)hipFree(m->indices);
+        if (m->data) (void)hipFree(m->data);
+        delete m;
+        return fail_hip(e, "alloc_csmat");
+    }
+    *out = m;
+    return SPRS_HIP_OK;
+}
+
+// utils::check_compressed_structure (sprs/src/sparse.rs:300-358) on host arrays.
+template <typename I, typename P>
+static int32_t check_structure(uint64_t inner, uint64_t outer, const P *indptr, const I *indices) {
+    // Iptr / I must be able to represent the dimensions (sparse.rs:314-324)
+    if ((uint64_t)(I)inner != inner) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Index type not large enough for this matrix");
+    if ((uint64_t)(P)(outer + 1) != outer + 1) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Iptr type not large enough for this matrix");
+    const uint64_t off = (uint64_t)indptr[0];
+    for (uint64_t i = 0; i < outer; ++i)
+        if (indptr[i + 1] < indptr[i]) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Unsorted indptr");
+    if ((uint64_t)indptr[outer] > (UINT64_MAX >> 1)) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "An indptr value is larger than allowed");
+    for (uint64_t r = 0; r < outer; ++r) {
+        const uint64_t s = (uint64_t)indptr[r] - off, e = (uint64_t)indptr[r + 1] - off;
+        for (uint64_t p = s + 1; p < e; ++p)
+            if (indices[p] <= indices[p - 1]) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Indices are not sorted");
+        if (e > s && (uint64_t)indices[e - 1] >= inner)
+            SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Indice is larger than inner dimension");
+    }
+    return SPRS_HIP_OK;
+}
+
+static bool widths_ok(int32_t iptr_bytes, int32_t idx_bytes) {
+    return (iptr_bytes == 4 || iptr_bytes == 8) && (idx_bytes == 4 || idx_bytes == 8);
+}
+
+}  // namespace sprs_hip
+
+using namespace sprs_hip;
+
+extern "C" {
+
+const char *sprs_hip_last_error(void) { return tl_msg.c_str(); }
+int32_t sprs_hip_last_hip_code(void) { return tl_hip_code; }
+const char *sprs_hip_version(void) { return "sprs_hip 0.1.0 gfx950 (twin of sprs 0.11.5 prod/smmp)"; }
+
+int32_t sprs_hip_device_count(int32_t *count) {
+    clear_error();
+    if (!count) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail_hip(e, "hipGetDeviceCount");
+    }
+    *count = n;
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_set_device(int32_t device) {
+    clear_error();
+    SPRS_TRY_HIP(hipSetDevice(device));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_malloc(void **dev_ptr, uint64_t bytes) {
+    clear_error();
+    if (!dev_ptr) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "dev_ptr is NULL");
+    *dev_ptr = nullptr;
+    SPRS_TRY_HIP(hipMalloc(dev_ptr, bytes ? bytes : 8));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_free(void *dev_ptr) {
+    clear_error();
+    if (dev_ptr) SPRS_TRY_HIP(hipFree(dev_ptr));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_memcpy_h2d(void *dev_dst, const void *host_src, uint64_t bytes) {
+    clear_error();
+    if (bytes) SPRS_TRY_HIP(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_memcpy_d2h(void *host_dst, const void *dev_src, uint64_t bytes) {
+    clear_error();
+    if (bytes) SPRS_TRY_HIP(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_memcpy_d2d(void *dev_dst, const void *dev_src, uint64_t bytes, void *stream) {
+    clear_error();
+    if (bytes) SPRS_TRY_HIP(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_memset(void *dev_dst, int32_t byte_value, uint64_t bytes, void *stream) {
+    clear_error();
+    if (bytes) SPRS_TRY_HIP(hipMemsetAsync(dev_dst, byte_value, bytes, (hipStream_t)stream));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_synchronize(void *stream) {
+    clear_error();
+    if (stream) SPRS_TRY_HIP(hipStreamSynchronize((hipStream_t)stream));
+    else SPRS_TRY_HIP(hipDeviceSynchronize());
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_csmat_upload(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols,
+                              const void *indptr, int32_t iptr_bytes, const void *indices,
+                              int32_t idx_bytes, const double *data, int32_t validate) {
+    clear_error();
+    if (!out || !indptr) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    if (storage != SPRS_HIP_CSR && storage != SPRS_HIP_CSC) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "bad storage tag %d", storage);
+    if (!widths_ok(iptr_bytes, idx_bytes)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "index widths must be 4 or 8 bytes");
+    const uint64_t outer = storage == SPRS_HIP_CSR ? rows : cols;
+    const uint64_t inner = storage == SPRS_HIP_CSR ? cols : rows;
+    auto ip_at = [&](uint64_t i) -> uint64_t {
+        return iptr_bytes == 8 ? ((const uint64_t *)indptr)[i] : ((const uint32_t *)indptr)[i];
+    };
+    const uint64_t first = ip_at(0), last = ip_at(outer);
+    if (last < first) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Unsorted indptr");
+    const uint64_t nnz = last - first;
+    if (nnz && (!indices || !data)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL indices/data with nnz > 0");
+    if (validate) {
+        int32_t st;
+        if (iptr_bytes == 8 && idx_bytes == 8) st = check_structure(inner, outer, (const uint64_t *)indptr, (const uint64_t *)indices);
+        else if (iptr_bytes == 8) st = check_structure(inner, outer, (const uint64_t *)indptr, (const uint32_t *)indices);
+        else if (idx_bytes == 8) st = check_structure(inner, outer, (const uint32_t *)indptr, (const uint64_t *)indices);
+        else st = check_structure(inner, outer, (const uint32_t *)indptr, (const uint32_t *)indices);
+        SPRS_TRY(st);
+    }
+    sprs_hip_csmat *m = nullptr;
+    SPRS_TRY(alloc_csmat(&m, storage, rows, cols, nnz, iptr_bytes, idx_bytes));
+    hipError_t e = hipSuccess;
+    if (first == 0) {
+        e = hipMemcpy(m->indptr, indptr, (outer + 1) * (uint64_t)iptr_bytes, hipMemcpyHostToDevice);
+    } else {
+        // to_proper (sprs/src/sparse/indptr.rs:206-214): rebase on the way in
+        std::vector<uint8_t> tmp((outer + 1) * (size_t)iptr_bytes);
+        for (uint64_t i = 0; i <= outer; ++i) {
+            if (iptr_bytes == 8) ((uint64_t *)tmp.data())[i] = ip_at(i) - first;
+            else ((uint32_t *)tmp.data())[i] = (uint32_t)(ip_at(i) - first);
+        }
+        e = hipMemcpy(m->indptr, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && nnz) e = hipMemcpy(m->indices, indices, nnz * (uint64_t)idx_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz) e = hipMemcpy(m->data, data, nnz * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        sprs_hip_csmat_free(m);
+        return fail_hip(e, "csmat_upload");
+    }
+    *out = m;
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_csmat_wrap_device(sprs_hip_csmat **out, int32_t storage, uint64_t rows,
+                                   uint64_t cols, uint64_t nnz, const void *dev_indptr,
+                                   int32_t iptr_bytes, const void *dev_indices, int32_t idx_bytes,
+                                   const double *dev_data) {
+    clear_error();
+    if (!out || !dev_indptr) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    if (storage != SPRS_HIP_CSR && storage != SPRS_HIP_CSC) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "bad storage tag %d", storage);
+    if (!widths_ok(iptr_bytes, idx_bytes)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "index widths must be 4 or 8 bytes");
+    if (nnz && (!dev_indices || !dev_data)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL indices/data with nnz > 0");
+    if (((uintptr_t)dev_indptr | (uintptr_t)dev_indices | (uintptr_t)dev_data) & 15)
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "device buffers must be 16-byte aligned");
+    auto *m = new sprs_hip_csmat();
+    m->storage = storage;
+    m->rows = rows;
+    m->cols = cols;
+    m->nnz = nnz;
+    m->iptr_bytes = iptr_bytes;
+    m->idx_bytes = idx_bytes;
+    m->indptr = const_cast<void *>(dev_indptr);
+    m->indices = const_cast<void *>(dev_indices);
+    m->data = const_cast<double *>(dev_data);
+    m->owns = false;
+    hipError_t e = hipGetDevice(&m->device);
+    if (e != hipSuccess) {
+        delete m;
+        return fail_hip(e, "hipGetDevice");
+    }
+    *out = m;
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_csmat_info(const sprs_hip_csmat *m, uint64_t *rows, uint64_t *cols, uint64_t *nnz,
+                            int32_t *iptr_bytes, int32_t *idx_bytes, int32_t *storage) {
+    clear_error();
+    if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    if (rows) *rows = m->rows;
+    if (cols) *cols = m->cols;
+    if (nnz) *nnz = m->nnz;
+    if (iptr_bytes) *iptr_bytes = m->iptr_bytes;
+    if (idx_bytes) *idx_bytes = m->idx_bytes;
+    if (storage) *storage = m->storage;
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_csmat_device_ptrs(const sprs_hip_csmat *m, const void **indptr,
+                                   const void **indices, const double **data) {
+    clear_error();
+    if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    if (indptr) *indptr = m->indptr;
+    if (indices) *indices = m->indices;
+    if (data) *data = m->data;
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_csmat_download(const sprs_hip_csmat *m, void *indptr, void *indices, double *data) {
+    clear_error();
+    if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    if (indptr) SPRS_TRY_HIP(hipMemcpy(indptr, m->indptr, (m->outer() + 1) * (uint64_t)m->iptr_bytes, hipMemcpyDeviceToHost));
+    if (indices && m->nnz) SPRS_TRY_HIP(hipMemcpy(indices, m->indices, m->nnz * (uint64_t)m->idx_bytes, hipMemcpyDeviceToHost));
+    if (data && m->nnz) SPRS_TRY_HIP(hipMemcpy(data, m->data, m->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_csmat_download_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end,
+                                      void *indptr_out, void *indices_out, double *data_out,
+                                      uint64_t *nnz_out) {
+    clear_error();
+    if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    // Range checks of slice_outer (sprs/src/sparse/slicing.rs:65-89 -> range.rs)
+    if (start > end || end > m->outer()) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "slice_outer range out of bounds");
+    uint64_t lo = 0, hi = 0;
+    const uint64_t pb = (uint64_t)m->iptr_bytes;
+    if (pb == 8) {
+        SPRS_TRY_HIP(hipMemcpy(&lo, (const uint8_t *)m->indptr + start * pb, 8, hipMemcpyDeviceToHost));
+        SPRS_TRY_HIP(hipMemcpy(&hi, (const uint8_t *)m->indptr + end * pb, 8, hipMemcpyDeviceToHost));
+    } else {
+        uint32_t a = 0, b = 0;
+        SPRS_TRY_HIP(hipMemcpy(&a, (const uint8_t *)m->indptr + start * pb, 4, hipMemcpyDeviceToHost));
+        SPRS_TRY_HIP(hipMemcpy(&b, (const uint8_t *)m->indptr + end * pb, 4, hipMemcpyDeviceToHost));
+        lo = a;
+        hi = b;
+    }
+    if (nnz_out) *nnz_out = hi - lo;
+    if (indptr_out) SPRS_TRY_HIP(hipMemcpy(indptr_out, (const uint8_t *)m->indptr + start * pb, (end - start + 1) * pb, hipMemcpyDeviceToHost));
+    if (indices_out && hi > lo)
+        SPRS_TRY_HIP(hipMemcpy(indices_out, (const uint8_t *)m->indices + lo * (uint64_t)m->idx_bytes, (hi - lo) * (uint64_t)m->idx_bytes, hipMemcpyDeviceToHost));
+    if (data_out && hi > lo) SPRS_TRY_HIP(hipMemcpy(data_out, m->data + lo, (hi - lo) * sizeof(double), hipMemcpyDeviceToHost));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
+    clear_error();
+    if (!m || !out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    auto *t = new sprs_hip_csmat();
+    t->storage = m->storage == SPRS_HIP_CSR ? SPRS_HIP_CSC : SPRS_HIP_CSR;
+    t->rows = m->cols;
+    t->cols = m->rows;
+    t->nnz = m->nnz;
+    t->iptr_bytes = m->iptr_bytes;
+    t->idx_bytes = m->idx_bytes;
+    t->indptr = m->indptr;
+    t->indices = m->indices;
+    t->data = m->data;
+    t->owns = false;
+    t->device = m->device;
+    *out = t;
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_csmat_free(sprs_hip_csmat *m) {
+    clear_error();
+    if (!m) return SPRS_HIP_OK;
+    m->plan.release();
+    if (m->owns) {
+        if (m->indptr) (void)hipFree(m->indptr);
+        if (m->indices) (void)hipFree(m->indices);
+        if (m->data) (void)hipFree(m->data);
+    }
+    delete m;
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_spmv_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t x_len,
+                          double *y_dev, uint64_t y_len, int32_t accumulate, void *stream) {
+    clear_error();
+    if (!a) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    // prod.rs:114-118: dimension check first, then storage
+    if (a->cols != x_len || a->rows != y_len) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if (a->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    if ((x_len && !x_dev) || (y_len && !y_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL vector");
+    return spmv_f64(const_cast<sprs_hip_csmat *>(a), x_dev, y_dev, accumulate != 0, (hipStream_t)stream);
+}
+
+int32_t sprs_hip_spmv_f64_host(uint64_t rows, uint64_t cols, const void *indptr,
+                               int32_t iptr_bytes, const void *indices, int32_t idx_bytes,
+                               const double *data, const double *x, uint64_t x_len, double *y,
+                               uint64_t y_len, int32_t accumulate) {
+    clear_error();
+    if (cols != x_len || rows != y_len) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    sprs_hip_csmat *m = nullptr;
+    SPRS_TRY(sprs_hip_csmat_upload(&m, SPRS_HIP_CSR, rows, cols, indptr, iptr_bytes, indices, idx_bytes, data, 0));
+    double *dx = nullptr, *dy = nullptr;
+    int32_t st = sprs_hip_malloc((void **)&dx, x_len * 8);
+    if (st == SPRS_HIP_OK) st = sprs_hip_malloc((void **)&dy, y_len * 8);
+    if (st == SPRS_HIP_OK) st = sprs_hip_memcpy_h2d(dx, x, x_len * 8);
+    if (st == SPRS_HIP_OK && accumulate) st = sprs_hip_memcpy_h2d(dy, y, y_len * 8);
+    if (st == SPRS_HIP_OK) st = sprs_hip_spmv_f64(m, dx, x_len, dy, y_len, accumulate, nullptr);
+    if (st == SPRS_HIP_OK) st = sprs_hip_synchronize(nullptr);
+    if (st == SPRS_HIP_OK) st = sprs_hip_memcpy_d2h(y, dy, y_len * 8);
+    std::string keep = tl_msg;
+    int32_t keep_code = tl_hip_code;
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    sprs_hip_csmat_free(m);
+    if (st != SPRS_HIP_OK) {
+        tl_msg = keep;
+        tl_hip_code = keep_code;
+    }
+    return st;
+}
+
+int32_t sprs_hip_spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
+    clear_error();
+    if (!a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *c = nullptr;
+    if (a->cols != b->rows) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");   // smmp.rs:207
+    if (a->storage != SPRS_HIP_CSR || b->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    if (a->iptr_bytes != b->iptr_bytes || a->idx_bytes != b->idx_bytes)
+        SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "operands must share index types (smmp.rs:196-199)");
+    return spgemm_f64(a, b, c);
+}
+
+int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
+    clear_error();
+    if (!m || !out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    return to_other_storage(m, out);
+}
+
+int32_t sprs_hip_set_option(const char *name, int64_t value) {
+    clear_error();
+    if (!name) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL name");
+    Options &o = options();
+    if (!strcmp(name, "spmv_kernel")) o.spmv_kernel = value;
+    else if (!strcmp(name, "spmv_nt")) o.spmv_nt = value;
+    else if (!strcmp(name, "spmv_tile")) {
+        if (value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 2048 or 4096");
+        o.spmv_tile = value;
+    } else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_get_option(const char *name, int64_t *value) {
+    clear_error();
+    if (!name || !value) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    Options &o = options();
+    if (!strcmp(name, "spmv_kernel")) *value = o.spmv_kernel;
+    else if (!strcmp(name, "spmv_nt")) *value = o.spmv_nt;
+    else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
+    else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
+    return SPRS_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+"""Row-sharded SpMV across the GPUs of one node.
+
+The reference has no distributed code; the shard is its own `slice_outer`
+(sprs/src/sparse/slicing.rs:65-89): rank g owns the contiguous row block
+[r_g, r_{g+1}) chosen so that every block holds ~nnz/G stored entries, keeps a
+full replica of x and computes y[r_g:r_{g+1}) = A[r_g:r_{g+1}, :] * x with the
+single-GPU kernel.  The one exchange step is an all-gather-v of y.
+
+MI355X-native choice for the exchange: xGMI is a full point-to-point mesh
+(7 links per GPU), so a ring all-gather is bound by ONE link while a direct
+exchange — every rank sends its block to its 7 peers at once — uses all seven.
+The exchange is therefore issued as one grouped batch of send/recv pairs
+(`batch_isend_irecv` == ncclGroupStart / ncclSend+ncclRecv / ncclGroupEnd on
+the RCCL backend).  The same code runs on gloo for the CPU tests.
+
+torch / torch.distributed are plumbing here (device memory, process group);
+the multiply itself is `local_spmv`, by default the HIP path.
+"""
+import torch
+import torch.distributed as dist
+
+from . import gen
+
+
+class RowShardedSpMV:
+    """y = A * x with A split by nnz-balanced row blocks over the process group.
+
+    indptr/indices/data: the FULL matrix as torch tensors on this rank's device
+    (every rank generates or loads the same matrix; only the own block is
+    kept).  local_spmv(block, x, y_block) multiplies the local block, where
+    block = (rows, cols, indptr, indices, data) with a zero-based indptr.
+    """
+
+    def __init__(self, shape, indptr, indices, data, local_spmv, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rows, self.cols = shape
+        self.cuts = gen.balanced_row_blocks(indptr, self.world)
+        r0, r1 = self.cuts[self.rank], self.cuts[self.rank + 1]
+        lo, hi = int(indptr[r0]), int(indptr[r1])
+        # slice_outer + to_proper (indptr.rs:206-214): rebase the block's indptr
+        # (clone: fresh, 16-byte aligned allocations the full arrays can be freed behind)
+        self.block = (r1 - r0, self.cols, (indptr[r0:r1 + 1] - indptr[r0]).contiguous(),
+                      indices[lo:hi].clone(), data[lo:hi].clone())
+        self.block_nnz = hi - lo
+        self.total_nnz = int(indptr[-1]) - int(indptr[0])
+        self.r0, self.r1 = r0, r1
+        self.local_spmv = local_spmv
+        self.y = torch.zeros(self.rows, dtype=torch.float64, device=indptr.device)
+
+    def exchange(self):
+        """all-gather-v of y: direct send/recv with every peer, one group."""
+        if self.world == 1:
+            return
+        mine = self.y[self.r0:self.r1]
+        ops = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            theirs = self.y[self.cuts[peer]:self.cuts[peer + 1]]
+            if mine.numel():
+                ops.append(dist.P2POp(dist.isend, mine, peer, self.group))
+            if theirs.numel():
+                ops.append(dist.P2POp(dist.irecv, theirs, peer, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def step(self, x):
+        """One SpMV: local block multiply, then the exchange.  Returns the full y."""
+        self.local_spmv(self.block, x, self.y[self.r0:self.r1])
+        self.exchange()
+        return self.y

@@ -1,0 +1,58 @@
+"""Twin of `sprs::prod` for device operands (sprs/src/sparse/prod.rs) plus the
+operator dispatch of csmat.rs.  Same names, argument order and failure
+behaviour: where the reference panics, SprsHipError carries the panic text."""
+import ctypes as C
+
+from . import _ffi
+from ._ffi import CSC, CSR, check, lib
+from .device import DeviceCsMat, DeviceVec
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+
+
+def mul_acc_mat_vec_csr(mat, in_vec, res_vec, stream=None):
+    """prod::mul_acc_mat_vec_csr (prod.rs:103-127): res_vec += mat * in_vec."""
+    check(lib.sprs_hip_spmv_f64(mat._h, C.c_void_p(in_vec.ptr), in_vec.n, C.c_void_p(res_vec.ptr),
+                                res_vec.n, 1, _stream_ptr(stream)))
+
+
+def csr_mulacc_dense_colmaj(lhs, rhs_cols, out_cols, stream=None):
+    """prod::csr_mulacc_dense_colmaj (prod.rs:274-298) with the rhs / out given
+    as lists of column vectors: out[:, j] += lhs * rhs[:, j]."""
+    if len(rhs_cols) != len(out_cols):
+        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
+    for r, o in zip(rhs_cols, out_cols):
+        mul_acc_mat_vec_csr(lhs, r, o, stream)
+
+
+def csmat_mul_vec(mat, vec, out=None, stream=None):
+    """`&CsMat * &Array1` (csmat.rs:2119-2160): fresh zero result, CSR goes
+    through csr_mulacc_dense_colmaj with one column."""
+    if out is None:
+        out = DeviceVec(mat.rows())
+    if mat.is_csc():
+        # csmat.rs:2149-2156 uses csc_mulacc_dense_colmaj; not on the device yet
+        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")
+    check(lib.sprs_hip_spmv_f64(mat._h, C.c_void_p(vec.ptr), vec.n, C.c_void_p(out.ptr), out.n, 0,
+                                _stream_ptr(stream)))
+    return out
+
+
+def csmat_mul_csmat(lhs, rhs):
+    """csmat_mul_csmat (csmat.rs:1895-1949): storage dispatch around
+    smmp::mul_csr_csr; the result has the lhs' storage order."""
+    from . import smmp
+    ls, rs = lhs.storage(), rhs.storage()
+    if (ls, rs) == (CSR, CSR):
+        return smmp.mul_csr_csr(lhs, rhs)
+    if (ls, rs) == (CSR, CSC):
+        return smmp.mul_csr_csr(lhs, rhs.to_other_storage())
+    if (ls, rs) == (CSC, CSR):
+        res = smmp.mul_csr_csr(rhs.to_other_storage().transpose_view(), lhs.transpose_view())
+        return res.transpose_view()            # transpose_into
+    res = smmp.mul_csr_csr(rhs.transpose_view(), lhs.transpose_view())
+    return res.transpose_view()
