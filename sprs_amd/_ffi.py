@@ -71,6 +71,27 @@ if not os.path.exists(LIB_PATH):
         "sprs_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "or `make -C sprs_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
 
+
+
+def _preload_shared_hip_runtime():
+    """One process must use ONE libamdhip64: PyTorch wheels bundle their own
+    copy (same SONAME as /opt/rocm's).  If torch is installed, load its copy
+    first so that libsprs_hip.so and torch share a single HIP runtime whatever
+    the import order (bench.py and the multi-GPU path hand torch-owned device
+    buffers to this library).  torch itself is NOT imported here."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:   # fall back to the system ROCm runtime (RUNPATH of the .so)
+        pass
+
+
+_preload_shared_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():
     _f = getattr(lib, _name)   # AttributeError here == the .so does not match the header

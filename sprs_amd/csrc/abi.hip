@@ -421,7 +421,8 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     else if (!strcmp(name, "spmv_tile")) {
         if (value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 2048 or 4096");
         o.spmv_tile = value;
-    } else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
+    } else if (!strcmp(name, "spmv_xmask")) o.spmv_xmask = value;
+    else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }
 
@@ -432,6 +433,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     if (!strcmp(name, "spmv_kernel")) *value = o.spmv_kernel;
     else if (!strcmp(name, "spmv_nt")) *value = o.spmv_nt;
     else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
+    else if (!strcmp(name, "spmv_xmask")) *value = o.spmv_xmask;
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }

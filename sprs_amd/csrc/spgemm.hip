@@ -1,10 +1,616 @@
-// placeholder until the SMMP twin lands (next commit)
+// CSR x CSR SpGEMM for gfx950 — device twin of smmp::mul_csr_csr
+// (sprs/src/sparse/smmp.rs:196-416): symbolic (smmp.rs:81-131) -> prefix sum of
+// the per-row counts (smmp.rs:320-331) -> numeric (smmp.rs:151-189).
+//
+// Output contract (what makes indptr/indices bit-exact with the reference):
+// every column reachable through A_i -> B_k is emitted, no numeric test
+// (structural zeros kept, smmp.rs:109-119), and each row is strictly increasing
+// (sort_unstable, smmp.rs:126).  Values: every C(i,j) is accumulated from +0.0
+// over k in ascending order with a separately rounded multiply and add
+// (smmp.rs:174-181, mul_acc.rs:28-30) — the same order as the reference, by a
+// single owner, so results are deterministic (no float atomics anywhere).
+//
+// Work decomposition: a TASK is (row i, column window w of 2^19 columns).
+//   * rows whose product count  ub_i = sum_{k in A_i} nnz(B_k)  is <= 512 are one
+//     task handled by ONE WAVE with an LDS hash table (keys + f64 accumulators),
+//     then a bitonic sort of the table in LDS;
+//   * larger rows get one task per column window, handled by a 512-thread
+//     workgroup with a 64 KiB LDS BITMAP of the window: setting bits is the
+//     symbolic pass, a popcount prefix over the bitmap turns a column into its
+//     rank inside the (sorted!) output row, so indices come out sorted for free
+//     and the accumulators are the output values themselves.
+// Per-task counts are scanned (hand-written two-level prefix sum) into output
+// offsets; C.indptr falls out of the same scan.  Integer/HBM-bound: no MFMA.
 #include "common.hpp"
+
 namespace sprs_hip {
-int32_t spgemm_f64(const sprs_hip_csmat *, const sprs_hip_csmat *, sprs_hip_csmat **) {
-    SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm: not built yet");
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr uint64_t SMALL_MAX = 512;       // products per row handled by the wave/hash path
+constexpr int SMALL_TAB = 1024;           // hash slots per wave (load factor <= 0.5)
+constexpr int SM_BLOCK = 256;             // 4 waves
+constexpr int SM_WAVES = SM_BLOCK / WAVE;
+constexpr int WIN_LOG2 = 19;              // columns per window
+constexpr uint64_t WIN = 1ull << WIN_LOG2;
+constexpr int WORDS = (int)(WIN / 64);    // 8192 64-bit words = 64 KiB
+constexpr int LG_BLOCK = 512;             // 8 waves
+constexpr int LG_WAVES = LG_BLOCK / WAVE;
+constexpr int WORDS_PER_THREAD = WORDS / LG_BLOCK;   // 16
+constexpr int SUPER_WORDS = 64;           // words per superblock (4096 columns)
+constexpr int NSUPER = WORDS / SUPER_WORDS;          // 128
+
+template <typename IDX, typename PTR>
+struct CsrView {
+    const PTR *indptr;
+    const IDX *indices;
+    const double *data;
+};
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
 }
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t c, int lg) { return (c * 0x9E3779B1u) >> (32 - lg); }
+
+__device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }
+
+// first position in [lo, hi) whose column is >= v
+template <typename IDX>
+__device__ __forceinline__ uint64_t lower_bound_col(const IDX *__restrict__ idx, uint64_t lo, uint64_t hi, uint64_t v) {
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)idx[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------
+// pass 0: per-row product count and number of tasks
+// ---------------------------------------------------------------------------
+template <typename IDX, typename PTR>
+__global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
+                                                       uint64_t nwin, uint64_t *__restrict__ ub,
+                                                       uint64_t *__restrict__ ntasks) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
+    for (uint64_t r = w0; r < rows; r += nw) {
+        const uint64_t s = (uint64_t)A.indptr[r], e = (uint64_t)A.indptr[r + 1];
+        uint64_t acc = 0;
+        for (uint64_t p = s + lane; p < e; p += WAVE) {
+            const uint64_t k = (uint64_t)A.indices[p];
+            acc += (uint64_t)B.indptr[k + 1] - (uint64_t)B.indptr[k];
+        }
+        acc = wave_sum_u64(acc);
+        if (lane == 0) {
+            ub[r] = acc;
+            ntasks[r] = acc == 0 ? 0 : (acc <= SMALL_MAX ? 1 : nwin);
+        }
+    }
+}
+
+__global__ void make_tasks_kernel(const uint64_t *__restrict__ ub, const uint64_t *__restrict__ ntasks,
+                                  const uint64_t *__restrict__ first_task, uint64_t rows,
+                                  uint64_t *__restrict__ task_row, uint64_t *__restrict__ small_list,
+                                  uint64_t *__restrict__ large_list, unsigned long long *__restrict__ counters) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint64_t n = ntasks[r];
+    if (!n) return;
+    const uint64_t f = first_task[r];
+    for (uint64_t j = 0; j < n; ++j) task_row[f + j] = r;
+    if (ub[r] <= SMALL_MAX) {
+        small_list[atomicAdd(&counters[0], 1ull)] = f;
+    } else {
+        const uint64_t pos = atomicAdd(&counters[1], (unsigned long long)n);
+        for (uint64_t j = 0; j < n; ++j) large_list[pos + j] = f + j;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// exclusive prefix sum over uint64 (two-level, hand written):
+//   out[i] = sum_{j<i} in[j]  for i = 0..n   (out has n+1 entries, out[n] = total)
+// ---------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *wave_tot /*LDS, >= 16*/, uint64_t *total) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const uint32_t nwaves = blockDim.x / WAVE;
+    uint64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint64_t o = __shfl_up(inc, off, WAVE);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == WAVE - 1) wave_tot[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+        const uint64_t t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_partial_kernel(const uint64_t *__restrict__ in, uint64_t n,
+                                                                  uint64_t *__restrict__ sums) {
+    __shared__ uint64_t wt[16];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) s += in[base + i];
+    uint64_t tot;
+    (void)block_excl_scan_u64(s, wt, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint64_t *__restrict__ sums, uint64_t nblocks) {
+    __shared__ uint64_t wt[16];
+    uint64_t carry = 0;
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += 1024) {
+        const uint64_t i = b0 + threadIdx.x;
+        const uint64_t v = i < nblocks ? sums[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = block_excl_scan_u64(v, wt, &tot);
+        if (i < nblocks) sums[i] = carry + ex;
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_final_kernel(const uint64_t *__restrict__ in, uint64_t n,
+                                                                const uint64_t *__restrict__ sums,
+                                                                uint64_t *__restrict__ out) {
+    __shared__ uint64_t wt[16];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    uint64_t tot;
+    uint64_t run = sums[blockIdx.x] + block_excl_scan_u64(s, wt, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+}
+
+__global__ void scan_total_kernel(const uint64_t *__restrict__ in, const uint64_t *__restrict__ out_excl, uint64_t n,
+                                  uint64_t *__restrict__ out) {
+    // out[n] = out[n-1] + in[n-1]
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[n] = n ? out_excl[n - 1] + in[n - 1] : 0;
+}
+
+static int32_t exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t stream) {
+    if (n == 0) {
+        SPRS_TRY_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), stream));
+        return SPRS_HIP_OK;
+    }
+    const uint64_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    uint64_t *sums = nullptr;
+    SPRS_TRY_HIP(hipMalloc((void **)&sums, nblocks * sizeof(uint64_t)));
+    hipLaunchKernelGGL(scan_partial_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, n, sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks);
+    hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, n, sums, out);
+    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, stream, in, out, n, out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(sums);
+    if (e != hipSuccess) return fail_hip(e, "exclusive_scan_u64");
+    return SPRS_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// small rows: one wave per task, LDS hash table
+// ---------------------------------------------------------------------------
+template <typename IDX, typename PTR, bool NUMERIC>
+__global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B,
+                                                              const uint64_t *__restrict__ small_list,
+                                                              uint64_t n_small, const uint64_t *__restrict__ task_row,
+                                                              const uint64_t *__restrict__ ub,
+                                                              uint64_t *__restrict__ count,        // symbolic: out
+                                                              const uint64_t *__restrict__ off,    // numeric: in
+                                                              IDX *__restrict__ c_indices, double *__restrict__ c_data) {
+    __shared__ uint32_t keys_s[SM_WAVES][SMALL_TAB];
+    __shared__ double vals_s[NUMERIC ? SM_WAVES : 1][NUMERIC ? SMALL_TAB : 1];
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    uint32_t *keys = keys_s[wave];
+    double *vals = vals_s[NUMERIC ? wave : 0];
+    const uint64_t w0 = (uint64_t)blockIdx.x * SM_WAVES + wave;
+    const uint64_t nw = (uint64_t)gridDim.x * SM_WAVES;
+    for (uint64_t q = w0; q < n_small; q += nw) {
+        const uint64_t t = small_list[q];
+        const uint64_t r = task_row[t];
+        // table size: symbolic sizes it by the product count, numeric by the exact row count
+        const uint32_t need = NUMERIC ? (uint32_t)count[t] : (uint32_t)ub[r];
+        int lg = ceil_log2_u32(2 * need);
+        if (lg < 6) lg = 6;
+        const uint32_t tsize = 1u << lg, mask = tsize - 1;
+        for (uint32_t i = lane; i < tsize; i += WAVE) keys[i] = EMPTY;
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
+        uint32_t fresh = 0;
+        for (uint64_t p0 = as; p0 < ae; p0 += WAVE) {
+            const uint64_t p = p0 + lane;
+            const bool valid = p < ae;
+            const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
+            const double av = valid ? A.data[p] : 0.0;
+            const uint64_t bs = valid ? (uint64_t)B.indptr[k] : 0, be = valid ? (uint64_t)B.indptr[k + 1] : 0;
+            const int nb = (ae - p0 < (uint64_t)WAVE) ? (int)(ae - p0) : WAVE;
+            for (int j = 0; j < nb; ++j) {            // k ascending: the reference's order (smmp.rs:174-181)
+                const uint64_t bsj = __shfl(bs, j, WAVE), bej = __shfl(be, j, WAVE);
+                const double avj = __shfl(av, j, WAVE);
+                for (uint64_t b = bsj + lane; b < bej; b += WAVE) {
+                    const uint32_t c = (uint32_t)B.indices[b];
+                    double pr = 0.0;
+                    if constexpr (NUMERIC) pr = avj * B.data[b];
+                    uint32_t h = hash_slot(c, lg);
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&keys[h], EMPTY, c);
+                        if (old == EMPTY) {
+                            ++fresh;
+                            if constexpr (NUMERIC) vals[h] = 0.0 + pr;     // tmp starts at N::zero()
+                            break;
+                        }
+                        if (old == c) {
+                            if constexpr (NUMERIC) vals[h] += pr;          // columns of one B row are distinct
+                            break;
+                        }
+                        h = (h + 1) & mask;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if constexpr (!NUMERIC) {
+            const uint64_t tot = wave_sum_u64(fresh);
+            if (lane == 0) count[t] = tot;
+        } else {
+            // bitonic sort of the table by key (EMPTY sorts last), values follow
+            for (uint32_t k2 = 2; k2 <= tsize; k2 <<= 1) {
+                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = lane; i < tsize; i += WAVE) {
+                        const uint32_t l = i ^ j;
+                        if (l > i) {
+                            const uint32_t ki = keys[i], kl = keys[l];
+                            const bool asc = (i & k2) == 0;
+                            if ((ki > kl) == asc) {
+                                keys[i] = kl;
+                                keys[l] = ki;
+                                const double vi = vals[i], vl = vals[l];
+                                vals[i] = vl;
+                                vals[l] = vi;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            const uint64_t o = off[t];
+            for (uint32_t i = lane; i < need; i += WAVE) {
+                c_indices[o + i] = (IDX)keys[i];
+                c_data[o + i] = vals[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// large rows: one workgroup per (row, column window) task, LDS bitmap
+// ---------------------------------------------------------------------------
+template <typename IDX, typename PTR>
+__device__ __forceinline__ void set_window_bits(const CsrView<IDX, PTR> &A, const CsrView<IDX, PTR> &B, uint64_t as,
+                                                uint64_t ae, uint64_t wlo, uint64_t whi, bool whole_row,
+                                                unsigned long long *bm, uint32_t &fresh) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    for (uint64_t p0 = as + (uint64_t)wave * WAVE; p0 < ae; p0 += (uint64_t)LG_WAVES * WAVE) {
+        const uint64_t p = p0 + lane;
+        const bool valid = p < ae;
+        const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
+        uint64_t s = valid ? (uint64_t)B.indptr[k] : 0, e = valid ? (uint64_t)B.indptr[k + 1] : 0;
+        if (!whole_row && e > s) {
+            s = lower_bound_col(B.indices, s, e, wlo);
+            e = lower_bound_col(B.indices, s, e, whi);
+        }
+        unsigned long long live = __ballot(e > s);
+        while (live) {
+            const int j = __ffsll((long long)live) - 1;
+            live &= live - 1;
+            const uint64_t sj = __shfl(s, j, WAVE), ej = __shfl(e, j, WAVE);
+            for (uint64_t b = sj + lane; b < ej; b += WAVE) {
+                const uint64_t c = (uint64_t)B.indices[b] - wlo;
+                const unsigned long long bit = 1ull << (c & 63);
+                const unsigned long long old = atomicOr(&bm[c >> 6], bit);
+                fresh += (old & bit) ? 0u : 1u;
+            }
+        }
+    }
+}
+
+template <typename IDX, typename PTR>
+__global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B,
+                                                                  uint64_t b_cols, const uint64_t *__restrict__ large_list,
+                                                                  const uint64_t *__restrict__ task_row,
+                                                                  const uint64_t *__restrict__ first_task,
+                                                                  const uint64_t *__restrict__ ntasks,
+                                                                  uint64_t *__restrict__ count) {
+    __shared__ unsigned long long bm[WORDS];
+    __shared__ uint64_t red[LG_WAVES];
+    const uint64_t t = large_list[blockIdx.x];
+    const uint64_t r = task_row[t];
+    const uint64_t w = t - first_task[r];
+    const uint64_t wlo = w * WIN, whi = (wlo + WIN < b_cols) ? wlo + WIN : b_cols;
+    for (int i = threadIdx.x; i < WORDS; i += LG_BLOCK) bm[i] = 0;
+    __syncthreads();
+    uint32_t fresh = 0;
+    set_window_bits(A, B, (uint64_t)A.indptr[r], (uint64_t)A.indptr[r + 1], wlo, whi, ntasks[r] == 1, bm, fresh);
+    const uint64_t ws = wave_sum_u64(fresh);
+    if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t tot = 0;
+        for (int i = 0; i < LG_WAVES; ++i) tot += red[i];
+        count[t] = tot;
+    }
+}
+
+template <typename IDX, typename PTR>
+__global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B,
+                                                                 uint64_t b_cols, const uint64_t *__restrict__ large_list,
+                                                                 const uint64_t *__restrict__ task_row,
+                                                                 const uint64_t *__restrict__ first_task,
+                                                                 const uint64_t *__restrict__ ntasks,
+                                                                 const uint64_t *__restrict__ count,
+                                                                 const uint64_t *__restrict__ off,
+                                                                 IDX *__restrict__ c_indices, double *__restrict__ c_data) {
+    __shared__ unsigned long long bm[WORDS];        // 64 KiB
+    __shared__ uint16_t sub[WORDS];                 // 16 KiB: rank of a word inside its superblock
+    __shared__ uint32_t super[NSUPER + 1];          // outputs before each 4096-column superblock
+    __shared__ uint64_t wt[16];
+    const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const uint64_t t = large_list[blockIdx.x];
+    const uint64_t r = task_row[t];
+    const uint64_t w = t - first_task[r];
+    const uint64_t wlo = w * WIN, whi = (wlo + WIN < b_cols) ? wlo + WIN : b_cols;
+    const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
+    const uint64_t out = off[t];
+    const uint32_t cnt = (uint32_t)count[t];
+    if (cnt == 0) return;                           // window without outputs (block-uniform)
+
+    for (int i = tid; i < WORDS; i += LG_BLOCK) bm[i] = 0;
+    __syncthreads();
+    uint32_t fresh = 0;
+    set_window_bits(A, B, as, ae, wlo, whi, ntasks[r] == 1, bm, fresh);
+    __syncthreads();
+
+    // popcount prefix: thread tid owns words [16 tid, 16 tid + 16)
+    uint32_t local[WORDS_PER_THREAD];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < WORDS_PER_THREAD; ++i) {
+        local[i] = mine;
+        mine += (uint32_t)__popcll(bm[tid * WORDS_PER_THREAD + i]);
+    }
+    uint64_t tot;
+    const uint32_t tpre = (uint32_t)block_excl_scan_u64(mine, wt, &tot);
+    constexpr int THREADS_PER_SUPER = SUPER_WORDS / WORDS_PER_THREAD;   // 4
+    if (tid % THREADS_PER_SUPER == 0) super[tid / THREADS_PER_SUPER] = tpre;
+    if (tid == 0) super[NSUPER] = (uint32_t)tot;
+    __syncthreads();
+    const uint32_t sbase = super[tid / THREADS_PER_SUPER];
+    // indices come out sorted: walk the set bits in order; zero the accumulators
+    uint32_t run = tpre;
+#pragma unroll 1
+    for (int i = 0; i < WORDS_PER_THREAD; ++i) {
+        const int word = tid * WORDS_PER_THREAD + i;
+        sub[word] = (uint16_t)(tpre + local[i] - sbase);
+        unsigned long long m = bm[word];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            c_indices[out + run] = (IDX)(wlo + (uint64_t)word * 64 + (uint64_t)b);
+            c_data[out + run] = 0.0;
+            ++run;
+        }
+    }
+    __syncthreads();   // sub/super complete; zeroed accumulators have reached L2 (release at workgroup scope)
+
+    // each wave OWNS a contiguous range of superblocks holding ~cnt/8 outputs, and walks
+    // every k in ascending order for it: one owner per accumulator, reference order.
+    auto boundary = [&](uint32_t target) -> uint32_t {   // number of superblocks with super[sb] < target
+        uint32_t n = 0;
+        for (int sb = lane; sb < NSUPER; sb += WAVE) n += (super[sb] < target) ? 1u : 0u;
+        return (uint32_t)wave_sum_u64(n);
+    };
+    uint32_t sb_lo = boundary((uint32_t)(((uint64_t)cnt * wave) / LG_WAVES));
+    uint32_t sb_hi = boundary((uint32_t)(((uint64_t)cnt * (wave + 1)) / LG_WAVES));
+    sb_lo = __shfl(sb_lo, 0, WAVE);
+    sb_hi = __shfl(sb_hi, 0, WAVE);
+    if (wave == 0) sb_lo = 0;
+    if (wave == LG_WAVES - 1) sb_hi = NSUPER;
+    if (sb_hi <= sb_lo) return;
+    const uint64_t clo = wlo + (uint64_t)sb_lo * (SUPER_WORDS * 64);
+    uint64_t chi = wlo + (uint64_t)sb_hi * (SUPER_WORDS * 64);
+    if (chi > whi) chi = whi;
+    if (clo >= chi) return;
+
+    for (uint64_t p0 = as; p0 < ae; p0 += WAVE) {
+        const uint64_t p = p0 + lane;
+        const bool valid = p < ae;
+        const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
+        const double av = valid ? A.data[p] : 0.0;
+        uint64_t s = valid ? (uint64_t)B.indptr[k] : 0, e = valid ? (uint64_t)B.indptr[k + 1] : 0;
+        if (e > s) {
+            s = lower_bound_col(B.indices, s, e, clo);
+            e = lower_bound_col(B.indices, s, e, chi);
+        }
+        unsigned long long live = __ballot(e > s);
+        while (live) {                                  // ascending j == ascending k
+            const int j = __ffsll((long long)live) - 1;
+            live &= live - 1;
+            const uint64_t sj = __shfl(s, j, WAVE), ej = __shfl(e, j, WAVE);
+            const double avj = __shfl(av, j, WAVE);
+            for (uint64_t b = sj + lane; b < ej; b += WAVE) {
+                const uint64_t c = (uint64_t)B.indices[b] - wlo;
+                const double pr = avj * B.data[b];
+                const uint32_t word = (uint32_t)(c >> 6);
+                const uint32_t rank = super[word / SUPER_WORDS] + sub[word] +
+                                      (uint32_t)__popcll(bm[word] & ((1ull << (c & 63)) - 1ull));
+                double *dst = c_data + out + rank;
+                // accumulator lives in L2: read around the (per-CU, write-through) L1
+                double v = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v += pr;
+                __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the next k may hit the same accumulators: its loads must follow these stores
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+template <typename PTR>
+__global__ void write_indptr_kernel(const uint64_t *__restrict__ first_task, const uint64_t *__restrict__ off,
+                                    uint64_t rows, PTR *__restrict__ indptr) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rows) return;
+    indptr[r] = (PTR)off[first_task[r]];
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T>
+    T *as() { return (T *)p; }
+};
+
+template <typename IDX, typename PTR>
+int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c_out) {
+    hipStream_t stream = nullptr;
+    const uint64_t rows = a->rows, b_cols = b->cols;
+    CsrView<IDX, PTR> A{(const PTR *)a->indptr, (const IDX *)a->indices, a->data};
+    CsrView<IDX, PTR> B{(const PTR *)b->indptr, (const IDX *)b->indices, b->data};
+    const uint64_t nwin = b_cols ? (b_cols + WIN - 1) / WIN : 1;
+
+    DevBuf ub, ntasks, first_task, counters;
+    SPRS_TRY_HIP(ub.alloc(rows * 8));
+    SPRS_TRY_HIP(ntasks.alloc(rows * 8));
+    SPRS_TRY_HIP(first_task.alloc((rows + 1) * 8));
+    SPRS_TRY_HIP(counters.alloc(16));
+    SPRS_TRY_HIP(hipMemsetAsync(counters.p, 0, 16, stream));
+    uint64_t ntask_total = 0;
+    if (rows) {
+        uint64_t blocks = (rows + 3) / 4;
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, nwin,
+                           ub.as<uint64_t>(), ntasks.as<uint64_t>());
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    SPRS_TRY(exclusive_scan_u64(ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows, stream));
+    SPRS_TRY_HIP(hipMemcpy(&ntask_total, first_task.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
+
+    DevBuf task_row, small_list, large_list, count, off;
+    SPRS_TRY_HIP(task_row.alloc(ntask_total * 8));
+    SPRS_TRY_HIP(small_list.alloc(ntask_total * 8));
+    SPRS_TRY_HIP(large_list.alloc(ntask_total * 8));
+    SPRS_TRY_HIP(count.alloc(ntask_total * 8));
+    SPRS_TRY_HIP(off.alloc((ntask_total + 1) * 8));
+    uint64_t n_small = 0, n_large = 0;
+    if (ntask_total) {
+        hipLaunchKernelGGL(make_tasks_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream,
+                           ub.as<uint64_t>(), ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows,
+                           task_row.as<uint64_t>(), small_list.as<uint64_t>(), large_list.as<uint64_t>(),
+                           counters.as<unsigned long long>());
+        SPRS_TRY_HIP(hipGetLastError());
+        uint64_t h[2];
+        SPRS_TRY_HIP(hipMemcpy(h, counters.p, 16, hipMemcpyDeviceToHost));
+        n_small = h[0];
+        n_large = h[1];
+    }
+    auto small_grid = [&]() {
+        uint64_t g = (n_small + SM_WAVES - 1) / SM_WAVES;
+        if (g > 256 * 32) g = 256 * 32;
+        return dim3((unsigned)g);
+    };
+    if (n_large > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many SpGEMM tasks for one launch");
+
+    // ---- symbolic ----------------------------------------------------------
+    if (n_small) {
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false>), small_grid(), dim3(SM_BLOCK), 0, stream, A, B,
+                           small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
+                           count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    if (n_large) {
+        hipLaunchKernelGGL((large_symbolic_kernel<IDX, PTR>), dim3((unsigned)n_large), dim3(LG_BLOCK), 0, stream, A, B,
+                           b_cols, large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),
+                           ntasks.as<uint64_t>(), count.as<uint64_t>());
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+
+    // ---- prefix sum of the counts -> offsets, C.indptr (smmp.rs:320-331) ----
+    SPRS_TRY(exclusive_scan_u64(count.as<uint64_t>(), off.as<uint64_t>(), ntask_total, stream));
+    uint64_t c_nnz = 0;
+    SPRS_TRY_HIP(hipMemcpy(&c_nnz, off.as<uint64_t>() + ntask_total, 8, hipMemcpyDeviceToHost));
+    if (sizeof(PTR) == 4 && c_nnz > 0xFFFFFFFFull)
+        SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Index type is not large enough to hold the nnz of the product (%llu)",
+                  (unsigned long long)c_nnz);   // Iptr::from_usize, smmp.rs:121
+
+    sprs_hip_csmat *c = nullptr;
+    SPRS_TRY(alloc_csmat(&c, SPRS_HIP_CSR, rows, b_cols, c_nnz, (int32_t)sizeof(PTR), (int32_t)sizeof(IDX)));
+    hipLaunchKernelGGL((write_indptr_kernel<PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream,
+                       first_task.as<uint64_t>(), off.as<uint64_t>(), rows, (PTR *)c->indptr);
+
+    // ---- numeric -------------------------------------------------------------
+    if (n_small)
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true>), small_grid(), dim3(SM_BLOCK), 0, stream, A, B,
+                           small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
+                           count.as<uint64_t>(), off.as<uint64_t>(), (IDX *)c->indices, c->data);
+    if (n_large)
+        hipLaunchKernelGGL((large_numeric_kernel<IDX, PTR>), dim3((unsigned)n_large), dim3(LG_BLOCK), 0, stream, A, B,
+                           b_cols, large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),
+                           ntasks.as<uint64_t>(), count.as<uint64_t>(), off.as<uint64_t>(), (IDX *)c->indices,
+                           c->data);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        sprs_hip_csmat_free(c);
+        return fail_hip(e, "spgemm numeric");
+    }
+    *c_out = c;
+    return SPRS_HIP_OK;
+}
+
+}  // namespace
+
+int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
+    if (b->cols > 0xFFFFFFFEull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "SpGEMM: more than 2^32-2 columns is not supported");
+    if (a->idx_bytes == 8 && a->iptr_bytes == 8) return spgemm_impl<uint64_t, uint64_t>(a, b, c);
+    if (a->idx_bytes == 4 && a->iptr_bytes == 8) return spgemm_impl<uint32_t, uint64_t>(a, b, c);
+    if (a->idx_bytes == 8 && a->iptr_bytes == 4) return spgemm_impl<uint64_t, uint32_t>(a, b, c);
+    return spgemm_impl<uint32_t, uint32_t>(a, b, c);
+}
+
 int32_t to_other_storage(const sprs_hip_csmat *, sprs_hip_csmat **) {
     SPRS_FAIL(SPRS_HIP_INVALID_ARG, "to_other_storage: not built yet");
 }
+
 }  // namespace sprs_hip

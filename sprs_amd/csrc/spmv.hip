@@ -87,7 +87,7 @@ template <typename IDX, typename PTR, int T, bool ACC, bool NT>
 __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
     const PTR *__restrict__ indptr, const IDX *__restrict__ indices, const double *__restrict__ data,
     const double *__restrict__ x, double *__restrict__ y, const uint64_t *__restrict__ tile_row,
-    double *__restrict__ carry, uint64_t nnz, uint64_t ntiles) {
+    double *__restrict__ carry, uint64_t nnz, uint64_t ntiles, uint64_t xmask) {
     constexpr int V = 2;                          // elements per lane per pass (16 B of data)
     constexpr int PASSES = T / (BLOCK * V);
     typedef IDX idx2 __attribute__((ext_vector_type(2)));
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
         double xv[PASSES][V];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            xv[p][0] = x[ix[p][0]];
-            xv[p][1] = x[ix[p][1]];
+            xv[p][0] = x[(uint64_t)ix[p][0] & xmask];
+            xv[p][1] = x[(uint64_t)ix[p][1] & xmask];
         }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
         for (int p = 0; p < PASSES; ++p) {
             const uint32_t i = p * (BLOCK * V) + tid * V;
             dbl2 pr = {0.0, 0.0};
-            if (i < cnt) pr[0] = dp[i] * x[ip[i]];
-            if (i + 1 < cnt) pr[1] = dp[i + 1] * x[ip[i + 1]];
+            if (i < cnt) pr[0] = dp[i] * x[(uint64_t)ip[i] & xmask];
+            if (i + 1 < cnt) pr[1] = dp[i + 1] * x[(uint64_t)ip[i + 1] & xmask];
             *(dbl2 *)&prod[i] = pr;
         }
     }
@@ -301,7 +301,7 @@ static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool 
     const PTR *ip = (const PTR *)a->indptr;
 #define SPRS_LAUNCH(ACC_, NT_)                                                                              \
     hipLaunchKernelGGL((spmv_tile_kernel<IDX, PTR, T, ACC_, NT_>), grid, block, 0, stream, ip, ix, a->data, x, y, \
-                       pl.tile_row, carry, a->nnz, pl.ntiles)
+                       pl.tile_row, carry, a->nnz, pl.ntiles, (uint64_t)options().spmv_xmask)
     if (acc) {
         if (nt) SPRS_LAUNCH(true, true);
         else SPRS_LAUNCH(true, false);

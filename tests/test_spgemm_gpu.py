@@ -1,0 +1,194 @@
+"""GPU parity tests of the HIP SpGEMM path (smmp::mul_csr_csr twin) against the
+CPU oracle and the reference's golden matrices.  Bar: indptr / indices
+bit-exact, values within 1e-10 relative (north star)."""
+import numpy as np
+import pytest
+
+from conftest import IDX_COMBOS, as_csr
+from helpers import ragged_csr, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import sprs_amd
+    if sprs_amd.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need the MI355X (no CPU fallback exists)")
+    return sprs_amd
+
+
+def gpu_mul(a, b, validate=True):
+    from sprs_amd import smmp
+    from sprs_amd.device import DeviceCsMat
+    da = DeviceCsMat.from_host(*a, validate=validate)
+    db = DeviceCsMat.from_host(*b, validate=validate)
+    c = smmp.mul_csr_csr(da, db)
+    assert c.is_csr()
+    return c.to_host()
+
+
+def check_against_oracle(a, b, exact_values=False):
+    from oracle import oracle
+    shape, ip, ix, dt = gpu_mul(a, b)
+    rshape, rip, rix, rdt = oracle.mul_csr_csr(*a, *b, threads=1)
+    assert shape == rshape
+    assert ip.dtype == rip.dtype and ix.dtype == rix.dtype          # same I / Iptr as the operands (smmp.rs:196-199)
+    assert np.array_equal(ip, rip), "indptr differs"
+    assert np.array_equal(ix, rix), "indices differ"
+    if exact_values:
+        assert np.array_equal(dt, rdt)
+    assert rel_err(dt, rdt) <= TOL
+    return shape, ip, ix, dt
+
+
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_golden_mul_csr_csr(hip, golden, idx, ptr):
+    # prod.rs:425-436, smmp.rs:467-473: exact equality with the fixtures
+    a, b = as_csr(golden["mat1"], idx, ptr), as_csr(golden["mat2"], idx, ptr)
+    for rhs, key in ((a, "mat1_self_matprod"), (b, "mat1_matprod_mat2")):
+        exp = as_csr(golden[key], idx, ptr)
+        shape, ip, ix, dt = gpu_mul(a, rhs)
+        assert shape == exp[0]
+        assert np.array_equal(ip, exp[1]) and np.array_equal(ix, exp[2]) and np.array_equal(dt, exp[3])
+
+
+def test_golden_structure_only(hip, golden):
+    # smmp.rs:515-555 (complex; structure) and tests/block_matrix.rs:71-108
+    fx = golden["mul_complex_structure"]
+    m = (tuple(fx["shape"]), np.array(fx["indptr"], dtype=np.uint64), np.array(fx["indices"], dtype=np.uint64),
+         np.ones(len(fx["indices"])))
+    shape, ip, ix, dt = gpu_mul(m, m)
+    assert list(ip) == fx["c_indptr"] and list(ix) == fx["c_indices"]
+    fx = golden["block_matrix_structure"]
+    u = lambda k: np.array(fx[k], dtype=np.uint64)
+    a = (tuple(fx["a_shape"]), u("a_indptr"), u("a_indices"), np.ones(3))
+    b = (tuple(fx["b_shape"]), u("b_indptr"), u("b_indices"), np.ones(2))
+    shape, ip, ix, dt = gpu_mul(a, b)
+    assert list(ip) == fx["c_indptr"] and list(ix) == fx["c_indices"]
+
+
+def test_zero_rows_and_empty(hip, golden):
+    # smmp.rs:475-489 (issue 239) and smmp.rs:503-513
+    fx = golden["mul_zero_rows"]
+    z = np.zeros(0, dtype=np.uint64)
+    a = (tuple(fx["a_shape"]), np.array(fx["a_indptr"], dtype=np.uint64), z, np.zeros(0))
+    b = (tuple(fx["b_shape"]), np.array(fx["b_indptr"], dtype=np.uint64), z, np.zeros(0))
+    shape, ip, ix, dt = gpu_mul(a, b)
+    assert shape == tuple(fx["c_shape"]) and ix.size == 0 and list(ip) == [0]
+    a = ((1, 100), np.zeros(2, dtype=np.uint64), z, np.zeros(0))
+    b = ((100, 10), np.zeros(101, dtype=np.uint64), z, np.zeros(0))
+    shape, ip, ix, dt = gpu_mul(a, b)
+    assert shape == (1, 10) and ix.size == 0 and list(ip) == [0, 0]
+
+
+def test_structural_zeros_kept(hip):
+    # products that cancel or are zero stay stored (smmp.rs:109-119)
+    u = lambda *v: np.array(v, dtype=np.uint64)
+    a = ((1, 2), u(0, 2), u(0, 1), np.array([1.0, -1.0]))
+    b = ((2, 1), u(0, 1, 2), u(0, 0), np.array([1.0, 1.0]))
+    shape, ip, ix, dt = gpu_mul(a, b)
+    assert shape == (1, 1) and list(ip) == [0, 1] and list(ix) == [0] and dt[0] == 0.0
+    a = ((1, 1), u(0, 1), u(0), np.array([0.0]))
+    b = ((1, 3), u(0, 2), u(0, 2), np.array([5.0, np.inf]))
+    shape, ip, ix, dt = gpu_mul(a, b)
+    assert list(ix) == [0, 2] and dt[0] == 0.0 and np.isnan(dt[1])
+
+
+def test_eye_times_matrix(hip, golden):
+    # lib.rs:52-73 doc test: eye * A == A
+    from oracle import oracle
+    a = as_csr(golden["mat5"])                       # 5 x 15
+    e = oracle.eye(5)
+    shape, ip, ix, dt = gpu_mul(e, a)
+    assert shape == (5, 15) and np.array_equal(ip, a[1]) and np.array_equal(ix, a[2]) and np.array_equal(dt, a[3])
+
+
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_rmat_square_vs_oracle(hip, idx, ptr):
+    # config 5 shape at test size: A*A, power-law rows; small + large row paths
+    from sprs_amd import gen
+    n = 20000
+    indptr, indices, data = gen.rmat_csr(n, 8, seed=5)
+    a = ((n, n), indptr.numpy().astype(ptr), indices.numpy().astype(idx), data.numpy())
+    shape, ip, ix, dt = check_against_oracle(a, a, exact_values=True)
+    lens = np.diff(ip.astype(np.int64))
+    assert lens.max() > 4096 and (lens == 0).any()
+
+
+def test_rectangular_random_mixed_sign(hip):
+    import scipy.sparse as sp
+    a = sp.random(700, 3000, density=0.01, random_state=1, format="csr")
+    b = sp.random(3000, 900, density=0.02, random_state=2, format="csr")
+    a.data[:] = np.random.default_rng(0).standard_normal(a.nnz)
+    b.data[:] = np.random.default_rng(1).standard_normal(b.nnz)
+    a.sort_indices(); b.sort_indices()
+    u = lambda v: v.astype(np.uint64)
+    A = ((700, 3000), u(a.indptr), u(a.indices), a.data)
+    B = ((3000, 900), u(b.indptr), u(b.indices), b.data)
+    check_against_oracle(A, B, exact_values=True)     # same k order, unfused: bit-identical values
+
+
+def test_multi_window_columns(hip):
+    # B wider than one 2^19-column window: rows above the small-row threshold span 3 windows
+    cols = (1 << 20) + 12345
+    rng = np.random.default_rng(3)
+    b_lens = [int(v) for v in rng.integers(200, 900, size=40)]
+    B = ragged_csr(b_lens, cols, seed=9)
+    a_lens = [40, 0, 3, 25, 1, 40]
+    A = ragged_csr(a_lens, 40, seed=4)
+    shape, ip, ix, dt = check_against_oracle(A, B, exact_values=True)
+    assert ix.max() >= (1 << 20)
+    # columns exactly at the window edges
+    u = lambda *v: np.array(v, dtype=np.uint64)
+    edge = np.array(sorted(set([0, (1 << 19) - 1, 1 << 19, (1 << 20) - 1, 1 << 20, cols - 1] +
+                               list(range(1000, 1700)))), dtype=np.uint64)
+    B2 = ((1, cols), u(0, edge.size), edge, np.full(edge.size, 2.0))
+    A2 = ((2, 1), u(0, 1, 2), u(0, 0), np.array([3.0, 0.5]))
+    check_against_oracle(A2, B2, exact_values=True)
+
+
+def test_contract_violations(hip, golden):
+    from sprs_amd import SprsHipError, _ffi, smmp
+    from sprs_amd.device import DeviceCsMat
+    a = DeviceCsMat.from_host(*as_csr(golden["mat3"]))              # 5 x 4
+    with pytest.raises(SprsHipError, match="Dimension mismatch") as e:   # smmp.rs:207
+        smmp.mul_csr_csr(a, a)
+    assert e.value.status == _ffi.DIM_MISMATCH
+    shape, ip, ix, dt = as_csr(golden["mat1_csc"])
+    csc = DeviceCsMat.from_host(shape, ip, ix, dt, storage=_ffi.CSC)
+    sq = DeviceCsMat.from_host(*as_csr(golden["mat1"]))
+    with pytest.raises(SprsHipError) as e:
+        smmp.mul_csr_csr(sq, csc)
+    assert e.value.status == _ffi.STORAGE_MISMATCH
+    b32 = DeviceCsMat.from_host(*as_csr(golden["mat1"], np.uint32, np.uint32))
+    with pytest.raises(SprsHipError) as e:                         # operands share I / Iptr (smmp.rs:196-199)
+        smmp.mul_csr_csr(sq, b32)
+    assert e.value.status == _ffi.STORAGE_MISMATCH
+
+
+def test_iptr_overflow_u32(hip):
+    # Iptr::from_usize panics when nnz(C) does not fit (smmp.rs:121; indexing.rs:104-108):
+    # 70000 x 1 times 1 x 70000 of ones has 4.9e9 > 2^32 stored entries.
+    from sprs_amd import SprsHipError, _ffi, smmp
+    from sprs_amd.device import DeviceCsMat
+    n = 70000
+    a = DeviceCsMat.from_host((n, 1), np.arange(n + 1, dtype=np.uint32), np.zeros(n, dtype=np.uint32), np.ones(n))
+    b = DeviceCsMat.from_host((1, n), np.array([0, n], dtype=np.uint32), np.arange(n, dtype=np.uint32), np.ones(n))
+    with pytest.raises(SprsHipError, match="Index type is not large enough") as e:
+        smmp.mul_csr_csr(a, b)
+    assert e.value.status == _ffi.INDEX_OVERFLOW
+
+
+def test_deterministic_and_operator(hip):
+    from sprs_amd import gen
+    from sprs_amd.device import DeviceCsMat
+    n = 30000
+    indptr, indices, data = gen.rmat_csr(n, 6, seed=21)
+    a = DeviceCsMat.from_host((n, n), indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64),
+                              data.numpy())
+    r1 = (a * a).to_host()            # `&A * &A` -> csmat_mul_csmat -> smmp::mul_csr_csr (csmat.rs:1866-1949)
+    r2 = (a * a).to_host()
+    for x, y in zip(r1[1:], r2[1:]):
+        assert np.array_equal(x, y)
