@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=None, help="spmv_kernel option for A/B (1 tiled, 2 wave-per-row)")
     ap.add_argument("--tile", type=int, default=None)
     ap.add_argument("--nt", type=int, default=None)
+    ap.add_argument("--xload", type=int, default=None, help="x gather flavour: 0 plain, 1 nt, 2 sc1")
     ap.add_argument("--xmask", type=int, default=None, help="timing experiment only: gather x[col & mask]")
     args = ap.parse_args()
 
@@ -71,7 +72,7 @@ def main():
     from sprs_amd import _ffi
     import ctypes as C
     _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
-    for opt, val in (("spmv_kernel", args.kernel), ("spmv_tile", args.tile), ("spmv_nt", args.nt), ("spmv_xmask", args.xmask)):
+    for opt, val in (("spmv_kernel", args.kernel), ("spmv_tile", args.tile), ("spmv_nt", args.nt), ("spmv_xmask", args.xmask), ("spmv_xload", args.xload)):
         if val is not None:
             sprs_amd.set_option(opt, val)
 

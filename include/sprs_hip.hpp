@@ -1,0 +1,155 @@
+// sprs_hip.hpp — header-only C++ host mirror of the reference interface for
+// the SpMV / SpGEMM path, on top of the C ABI (sprs_hip.h).
+//
+// The reference's host language is Rust; rustc is absent from this build
+// environment, so this is the compiled-language host side (the Rust crates in
+// rust/ are the same surface, source only).  Names, argument order and failure
+// behaviour follow sprs:
+//   sprs_hip::prod::mul_acc_mat_vec_csr(mat, in_vec, res_vec)   sprs/src/sparse/prod.rs:103-127
+//   sprs_hip::smmp::mul_csr_csr(lhs, rhs)                       sprs/src/sparse/smmp.rs:196-416
+//   mat * vec, mat * mat                                        sprs/src/sparse/csmat.rs:1866-1888, 2119-2160
+//   DeviceCsMat::eye(n)                                         sprs/src/sparse/csmat.rs:416-426
+// Where the reference panics ("Dimension mismatch", "Storage mismatch", "Index
+// type is not large enough to hold ..."), sprs_hip::Error is thrown with the
+// same text.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "sprs_hip.h"
+
+namespace sprs_hip {
+
+struct Error : std::runtime_error {
+    int32_t status;
+    Error(int32_t s, const std::string &m) : std::runtime_error(m), status(s) {}
+};
+
+inline void check(int32_t status) {
+    if (status != SPRS_HIP_OK) throw Error(status, sprs_hip_last_error());
+}
+
+// Dense f64 vector in HBM (what `&[f64]` / `Vec<f64>` / `Array1<f64>` are on the host,
+// sprs/src/dense_vector.rs:10-29).
+class DeviceVec {
+public:
+    explicit DeviceVec(uint64_t n) : n_(n) {
+        check(sprs_hip_malloc(&p_, n * 8));
+        check(sprs_hip_memset(p_, 0, n * 8, nullptr));
+    }
+    explicit DeviceVec(const std::vector<double> &v) : n_(v.size()) {
+        check(sprs_hip_malloc(&p_, n_ * 8));
+        check(sprs_hip_memcpy_h2d(p_, v.data(), n_ * 8));
+    }
+    DeviceVec(DeviceVec &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+    DeviceVec(const DeviceVec &) = delete;
+    DeviceVec &operator=(const DeviceVec &) = delete;
+    ~DeviceVec() {
+        if (p_) sprs_hip_free(p_);
+    }
+    uint64_t dim() const { return n_; }
+    double *ptr() { return static_cast<double *>(p_); }
+    const double *ptr() const { return static_cast<const double *>(p_); }
+    std::vector<double> to_host() const {
+        std::vector<double> out(n_);
+        check(sprs_hip_synchronize(nullptr));
+        check(sprs_hip_memcpy_d2h(out.data(), p_, n_ * 8));
+        return out;
+    }
+
+private:
+    void *p_ = nullptr;
+    uint64_t n_ = 0;
+};
+
+// Device twin of CsMatI<f64, I, Iptr> (sprs/src/sparse.rs:94-122).
+class DeviceCsMat {
+public:
+    // CsMat::new / new_csc (validate = true) or new_trusted (validate = false)
+    template <typename I, typename Iptr>
+    DeviceCsMat(int32_t storage, uint64_t rows, uint64_t cols, const std::vector<Iptr> &indptr,
+                const std::vector<I> &indices, const std::vector<double> &data, bool validate = true) {
+        static_assert(std::is_integral<I>::value && std::is_integral<Iptr>::value, "SpIndex types");
+        static_assert(sizeof(I) == 4 || sizeof(I) == 8, "I must be 4 or 8 bytes");
+        static_assert(sizeof(Iptr) == 4 || sizeof(Iptr) == 8, "Iptr must be 4 or 8 bytes");
+        check(sprs_hip_csmat_upload(&h_, storage, rows, cols, indptr.data(), (int32_t)sizeof(Iptr), indices.data(),
+                                    (int32_t)sizeof(I), data.data(), validate ? 1 : 0));
+    }
+    explicit DeviceCsMat(sprs_hip_csmat *h) : h_(h) {}
+    DeviceCsMat(DeviceCsMat &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    DeviceCsMat(const DeviceCsMat &) = delete;
+    DeviceCsMat &operator=(const DeviceCsMat &) = delete;
+    ~DeviceCsMat() {
+        if (h_) sprs_hip_csmat_free(h_);
+    }
+
+    static DeviceCsMat eye(uint64_t dim) {   // csmat.rs:416-426
+        std::vector<uint64_t> indptr(dim + 1), indices(dim);
+        for (uint64_t i = 0; i <= dim; ++i) indptr[i] = i;
+        for (uint64_t i = 0; i < dim; ++i) indices[i] = i;
+        return DeviceCsMat(SPRS_HIP_CSR, dim, dim, indptr, indices, std::vector<double>(dim, 1.0), false);
+    }
+
+    uint64_t rows() const { return info().rows; }
+    uint64_t cols() const { return info().cols; }
+    uint64_t nnz() const { return info().nnz; }
+    bool is_csr() const { return info().storage == SPRS_HIP_CSR; }
+    const sprs_hip_csmat *handle() const { return h_; }
+
+    // into_raw_storage (csmat.rs:946-954) for 8-byte handles
+    void to_host(std::vector<uint64_t> &indptr, std::vector<uint64_t> &indices, std::vector<double> &data) const {
+        const Info i = info();
+        if (i.iptr_bytes != 8 || i.idx_bytes != 8) throw Error(SPRS_HIP_INVALID_ARG, "to_host: 64-bit handles only");
+        const uint64_t outer = i.storage == SPRS_HIP_CSR ? i.rows : i.cols;
+        indptr.resize(outer + 1);
+        indices.resize(i.nnz);
+        data.resize(i.nnz);
+        check(sprs_hip_csmat_download(h_, indptr.data(), indices.data(), data.data()));
+    }
+
+private:
+    struct Info {
+        uint64_t rows, cols, nnz;
+        int32_t iptr_bytes, idx_bytes, storage;
+    };
+    Info info() const {
+        Info i{};
+        check(sprs_hip_csmat_info(h_, &i.rows, &i.cols, &i.nnz, &i.iptr_bytes, &i.idx_bytes, &i.storage));
+        return i;
+    }
+    sprs_hip_csmat *h_ = nullptr;
+};
+
+namespace prod {
+// prod::mul_acc_mat_vec_csr (prod.rs:103-127): res_vec += mat * in_vec
+inline void mul_acc_mat_vec_csr(const DeviceCsMat &mat, const DeviceVec &in_vec, DeviceVec &res_vec,
+                                void *stream = nullptr) {
+    check(sprs_hip_spmv_f64(mat.handle(), in_vec.ptr(), in_vec.dim(), res_vec.ptr(), res_vec.dim(), 1, stream));
+}
+}  // namespace prod
+
+namespace smmp {
+// smmp::mul_csr_csr (smmp.rs:196-416)
+inline DeviceCsMat mul_csr_csr(const DeviceCsMat &lhs, const DeviceCsMat &rhs) {
+    sprs_hip_csmat *c = nullptr;
+    check(sprs_hip_spgemm_f64(lhs.handle(), rhs.handle(), &c));
+    return DeviceCsMat(c);
+}
+}  // namespace smmp
+
+// `&A * &x` (csmat.rs:2119-2160): fresh result
+inline DeviceVec operator*(const DeviceCsMat &a, const DeviceVec &x) {
+    DeviceVec y(a.rows());
+    check(sprs_hip_spmv_f64(a.handle(), x.ptr(), x.dim(), y.ptr(), y.dim(), 0, nullptr));
+    return y;
+}
+
+// `&A * &B` (csmat.rs:1866-1888)
+inline DeviceCsMat operator*(const DeviceCsMat &a, const DeviceCsMat &b) { return smmp::mul_csr_csr(a, b); }
+
+}  // namespace sprs_hip

@@ -1,0 +1,74 @@
+//! Raw declarations of `include/sprs_hip.h` (NOT COMPILED in the build
+//! environment of this repository: no rustc there).  One item per C entry point.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+pub const SPRS_HIP_OK: i32 = 0;
+pub const SPRS_HIP_DIM_MISMATCH: i32 = 1;
+pub const SPRS_HIP_STORAGE_MISMATCH: i32 = 2;
+pub const SPRS_HIP_INDEX_OVERFLOW: i32 = 3;
+pub const SPRS_HIP_BAD_STRUCTURE: i32 = 4;
+pub const SPRS_HIP_INVALID_ARG: i32 = 5;
+pub const SPRS_HIP_OUT_OF_MEMORY: i32 = 6;
+pub const SPRS_HIP_HIP_ERROR: i32 = 7;
+pub const SPRS_HIP_NO_DEVICE: i32 = 8;
+pub const SPRS_HIP_CSR: i32 = 0;
+pub const SPRS_HIP_CSC: i32 = 1;
+
+#[repr(C)]
+pub struct sprs_hip_csmat {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn sprs_hip_last_error() -> *const c_char;
+    pub fn sprs_hip_last_hip_code() -> i32;
+    pub fn sprs_hip_version() -> *const c_char;
+    pub fn sprs_hip_device_count(count: *mut i32) -> i32;
+    pub fn sprs_hip_set_device(device: i32) -> i32;
+    pub fn sprs_hip_malloc(dev_ptr: *mut *mut c_void, bytes: u64) -> i32;
+    pub fn sprs_hip_free(dev_ptr: *mut c_void) -> i32;
+    pub fn sprs_hip_memcpy_h2d(dev_dst: *mut c_void, host_src: *const c_void, bytes: u64) -> i32;
+    pub fn sprs_hip_memcpy_d2h(host_dst: *mut c_void, dev_src: *const c_void, bytes: u64) -> i32;
+    pub fn sprs_hip_memcpy_d2d(dev_dst: *mut c_void, dev_src: *const c_void, bytes: u64, stream: *mut c_void) -> i32;
+    pub fn sprs_hip_memset(dev_dst: *mut c_void, byte_value: i32, bytes: u64, stream: *mut c_void) -> i32;
+    pub fn sprs_hip_synchronize(stream: *mut c_void) -> i32;
+    pub fn sprs_hip_csmat_upload(
+        out: *mut *mut sprs_hip_csmat, storage: i32, rows: u64, cols: u64,
+        indptr: *const c_void, iptr_bytes: i32, indices: *const c_void, idx_bytes: i32,
+        data: *const f64, validate: i32,
+    ) -> i32;
+    pub fn sprs_hip_csmat_wrap_device(
+        out: *mut *mut sprs_hip_csmat, storage: i32, rows: u64, cols: u64, nnz: u64,
+        dev_indptr: *const c_void, iptr_bytes: i32, dev_indices: *const c_void, idx_bytes: i32,
+        dev_data: *const f64,
+    ) -> i32;
+    pub fn sprs_hip_csmat_info(
+        m: *const sprs_hip_csmat, rows: *mut u64, cols: *mut u64, nnz: *mut u64,
+        iptr_bytes: *mut i32, idx_bytes: *mut i32, storage: *mut i32,
+    ) -> i32;
+    pub fn sprs_hip_csmat_device_ptrs(
+        m: *const sprs_hip_csmat, indptr: *mut *const c_void, indices: *mut *const c_void,
+        data: *mut *const f64,
+    ) -> i32;
+    pub fn sprs_hip_csmat_download(m: *const sprs_hip_csmat, indptr: *mut c_void, indices: *mut c_void, data: *mut f64) -> i32;
+    pub fn sprs_hip_csmat_download_outer(
+        m: *const sprs_hip_csmat, start: u64, end: u64, indptr_out: *mut c_void,
+        indices_out: *mut c_void, data_out: *mut f64, nnz_out: *mut u64,
+    ) -> i32;
+    pub fn sprs_hip_csmat_transpose_view(m: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_csmat_free(m: *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_spmv_f64(
+        a: *const sprs_hip_csmat, x_dev: *const f64, x_len: u64, y_dev: *mut f64, y_len: u64,
+        accumulate: i32, stream: *mut c_void,
+    ) -> i32;
+    pub fn sprs_hip_spmv_f64_host(
+        rows: u64, cols: u64, indptr: *const c_void, iptr_bytes: i32, indices: *const c_void,
+        idx_bytes: i32, data: *const f64, x: *const f64, x_len: u64, y: *mut f64, y_len: u64,
+        accumulate: i32,
+    ) -> i32;
+    pub fn sprs_hip_spgemm_f64(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_csmat_to_other_storage(m: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_set_option(name: *const c_char, value: i64) -> i32;
+    pub fn sprs_hip_get_option(name: *const c_char, value: *mut i64) -> i32;
+}

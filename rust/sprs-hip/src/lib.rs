@@ -1,0 +1,167 @@
+//! Safe wrapper over `sprs-hip-sys` (NOT COMPILED in this repository's build
+//! environment: no rustc there).  Shape of the code follows
+//! sprs_suitesparse_umfpack/src/lib.rs:30-46 (opaque handle + Drop) and
+//! sprs_suitesparse_ldl/src/lib.rs:86-127 (cast index types, pass raw pointers).
+//!
+//! `DenseVector` / `DenseVectorMut` are sealed in sprs (dense_vector.rs:305-326),
+//! so device buffers cannot be passed to `sprs::prod::*` itself; this crate
+//! offers twins with the same names, argument order and panics.
+use sprs::{CsMatI, CsMatViewI, SpIndex};
+use sprs_hip_sys as sys;
+use std::ffi::CStr;
+use std::os::raw::c_void;
+
+fn check(status: i32) {
+    if status == sys::SPRS_HIP_OK {
+        return;
+    }
+    let msg = unsafe { CStr::from_ptr(sys::sprs_hip_last_error()) }.to_string_lossy().into_owned();
+    // Contract violations panic with the reference's own text
+    // (prod.rs:114-118, smmp.rs:207, csmat.rs:1794-1797; Guidelines.rst:10-27).
+    panic!("{msg}");
+}
+
+/// A dense f64 vector in HBM.
+pub struct DeviceVec {
+    ptr: *mut f64,
+    len: usize,
+}
+
+impl DeviceVec {
+    pub fn zeros(len: usize) -> Self {
+        let mut p: *mut c_void = std::ptr::null_mut();
+        unsafe {
+            check(sys::sprs_hip_malloc(&mut p, (len * 8) as u64));
+            check(sys::sprs_hip_memset(p, 0, (len * 8) as u64, std::ptr::null_mut()));
+        }
+        Self { ptr: p as *mut f64, len }
+    }
+    pub fn from_slice(x: &[f64]) -> Self {
+        let v = Self::zeros(x.len());
+        unsafe { check(sys::sprs_hip_memcpy_h2d(v.ptr as *mut c_void, x.as_ptr() as *const c_void, (x.len() * 8) as u64)) };
+        v
+    }
+    pub fn to_vec(&self) -> Vec<f64> {
+        let mut out = vec![0.0; self.len];
+        unsafe {
+            check(sys::sprs_hip_synchronize(std::ptr::null_mut()));
+            check(sys::sprs_hip_memcpy_d2h(out.as_mut_ptr() as *mut c_void, self.ptr as *const c_void, (self.len * 8) as u64));
+        }
+        out
+    }
+    pub fn dim(&self) -> usize {
+        self.len
+    }
+}
+
+impl Drop for DeviceVec {
+    fn drop(&mut self) {
+        unsafe { sys::sprs_hip_free(self.ptr as *mut c_void) };
+    }
+}
+
+/// Device twin of `CsMatI<f64, I, Iptr>`.
+pub struct DeviceCsMat {
+    h: *mut sys::sprs_hip_csmat,
+}
+
+// A handle may be shared read-only across host threads (products take &self);
+// the C side guards its lazily built SpMV plan with a mutex.
+unsafe impl Send for DeviceCsMat {}
+unsafe impl Sync for DeviceCsMat {}
+
+impl DeviceCsMat {
+    /// Upload a host matrix (any `SpIndex` types of 4 or 8 bytes).
+    pub fn from_view<I: SpIndex, Iptr: SpIndex>(m: CsMatViewI<f64, I, Iptr>) -> Self {
+        let indptr = m.indptr(); // may be non-proper (slice_outer): the C side rebases
+        let mut h = std::ptr::null_mut();
+        unsafe {
+            check(sys::sprs_hip_csmat_upload(
+                &mut h,
+                if m.is_csr() { sys::SPRS_HIP_CSR } else { sys::SPRS_HIP_CSC },
+                m.rows() as u64,
+                m.cols() as u64,
+                indptr.raw_storage().as_ptr() as *const c_void,
+                std::mem::size_of::<Iptr>() as i32,
+                m.indices().as_ptr() as *const c_void,
+                std::mem::size_of::<I>() as i32,
+                m.data().as_ptr(),
+                0, // the CsMat invariants were already checked on the host
+            ));
+        }
+        Self { h }
+    }
+
+    pub fn shape(&self) -> (usize, usize) {
+        let (mut r, mut c) = (0u64, 0u64);
+        unsafe { check(sys::sprs_hip_csmat_info(self.h, &mut r, &mut c, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut())) };
+        (r as usize, c as usize)
+    }
+
+    pub fn nnz(&self) -> usize {
+        let mut n = 0u64;
+        unsafe { check(sys::sprs_hip_csmat_info(self.h, std::ptr::null_mut(), std::ptr::null_mut(), &mut n, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut())) };
+        n as usize
+    }
+
+    /// Download as a host `CsMatI` (usize/usize handles only in this sketch).
+    pub fn to_csmat(&self) -> CsMatI<f64, usize, usize> {
+        let (rows, cols) = self.shape();
+        let nnz = self.nnz();
+        let mut indptr = vec![0usize; rows + 1];
+        let mut indices = vec![0usize; nnz];
+        let mut data = vec![0f64; nnz];
+        unsafe {
+            check(sys::sprs_hip_csmat_download(self.h, indptr.as_mut_ptr() as *mut c_void, indices.as_mut_ptr() as *mut c_void, data.as_mut_ptr()));
+        }
+        // rows are sorted and in range by construction (smmp.rs:126): the
+        // unchecked constructor is what `new_trusted` is inside sprs (csmat.rs:265-301)
+        unsafe { CsMatI::new_unchecked(sprs::CompressedStorage::CSR, (rows, cols), indptr, indices, data) }
+    }
+}
+
+impl Drop for DeviceCsMat {
+    fn drop(&mut self) {
+        unsafe { sys::sprs_hip_csmat_free(self.h) };
+    }
+}
+
+pub mod prod {
+    use super::*;
+    /// Twin of `sprs::prod::mul_acc_mat_vec_csr` (prod.rs:103-127): `res_vec += mat * in_vec`.
+    pub fn mul_acc_mat_vec_csr(mat: &DeviceCsMat, in_vec: &DeviceVec, res_vec: &mut DeviceVec) {
+        unsafe {
+            check(sys::sprs_hip_spmv_f64(mat.h, in_vec.ptr, in_vec.len as u64, res_vec.ptr, res_vec.len as u64, 1, std::ptr::null_mut()));
+        }
+    }
+}
+
+pub mod smmp {
+    use super::*;
+    /// Twin of `sprs::smmp::mul_csr_csr` (smmp.rs:196-416).
+    pub fn mul_csr_csr(lhs: &DeviceCsMat, rhs: &DeviceCsMat) -> DeviceCsMat {
+        let mut h = std::ptr::null_mut();
+        unsafe { check(sys::sprs_hip_spgemm_f64(lhs.h, rhs.h, &mut h)) };
+        DeviceCsMat { h }
+    }
+}
+
+/// `&A * &x`  (csmat.rs:2119-2160): fresh result, no accumulation.
+impl<'a, 'b> std::ops::Mul<&'b DeviceVec> for &'a DeviceCsMat {
+    type Output = DeviceVec;
+    fn mul(self, rhs: &'b DeviceVec) -> DeviceVec {
+        let out = DeviceVec::zeros(self.shape().0);
+        unsafe {
+            check(sys::sprs_hip_spmv_f64(self.h, rhs.ptr, rhs.len as u64, out.ptr, out.len as u64, 0, std::ptr::null_mut()));
+        }
+        out
+    }
+}
+
+/// `&A * &B`  (csmat.rs:1866-1888 -> csmat_mul_csmat -> smmp::mul_csr_csr).
+impl<'a, 'b> std::ops::Mul<&'b DeviceCsMat> for &'a DeviceCsMat {
+    type Output = DeviceCsMat;
+    fn mul(self, rhs: &'b DeviceCsMat) -> DeviceCsMat {
+        smmp::mul_csr_csr(self, rhs)
+    }
+}

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""SpGEMM A*A on an R-MAT matrix generated on the GPU (BASELINE config 5 shape):
+time of the HIP path, nnz(C), and a row-block parity check against the oracle
+(the full C of config 5 is 53 GB: the host oracle is run on row blocks).
+usage: spgemm_bench.py <n> <nnz_per_row> [idx_bytes] [check_rows]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sprs_amd import gen, smmp                      # noqa: E402
+from sprs_amd.device import DeviceCsMat              # noqa: E402
+
+
+def main():
+    n, k = int(sys.argv[1]), float(sys.argv[2])
+    idx_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    check_rows = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
+    dev = torch.device("cuda", 0)
+    idt = torch.int64 if idx_bytes == 8 else torch.int32
+    indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)
+    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    c = smmp.mul_csr_csr(a, a)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nnz_c = c.nnz()
+    # products P = sum_i sum_{k in A_i} nnz(A_k)
+    rl = (indptr[1:] - indptr[:-1]).to(torch.float64)
+    prods = float(rl[indices.long()].sum())
+    out = {"n": n, "nnz_a": int(indices.numel()), "nnz_c": int(nnz_c), "products": prods, "seconds": round(dt, 4),
+           "gflops": round(2 * prods / dt / 1e9, 3), "idx_bytes": idx_bytes,
+           "compulsory_GB": round(((2 * indices.numel() + nnz_c) * (8 + idx_bytes) + 3 * (n + 1) * 8) / 1e9, 3)}
+    # row-block parity vs the oracle (checker only)
+    from oracle import oracle
+    npi = np.uint64 if idx_bytes == 8 else np.uint32
+    ip_h = indptr.cpu().numpy().view(np.uint64)
+    ix_h = indices.cpu().numpy().view(npi)
+    dt_h = data.cpu().numpy()
+    ok = True
+    worst = 0.0
+    checked = 0
+    for r0 in sorted(set([0, n // 3, max(0, n - check_rows)])):
+        r1 = min(n, r0 + check_rows)
+        s, e = int(ip_h[r0]), int(ip_h[r1])
+        shape, rip, rix, rdt = oracle.mul_csr_csr((r1 - r0, n), ip_h[r0:r1 + 1], ix_h[s:e], dt_h[s:e],
+                                                  (n, n), ip_h, ix_h, dt_h, threads=0)
+        gip, gix, gdt = c.slice_outer_to_host(r0, r1)
+        gip = gip - gip[0]
+        ok &= bool(np.array_equal(gip, rip)) and bool(np.array_equal(gix, rix))
+        if ok and rdt.size:
+            worst = max(worst, float(np.max(np.abs(gdt - rdt) / np.maximum(np.abs(rdt), 1e-300))))
+        checked += int(rix.size)
+    out["parity"] = {"rows_checked": 3 * check_rows, "entries_checked": checked, "structure_bit_exact": ok,
+                     "max_rel_err": worst, "values_bit_exact": worst == 0.0}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -422,6 +422,10 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         if (value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 2048 or 4096");
         o.spmv_tile = value;
     } else if (!strcmp(name, "spmv_xmask")) o.spmv_xmask = value;
+    else if (!strcmp(name, "spmv_xload")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_xload must be 0, 1 or 2");
+        o.spmv_xload = value;
+    }
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }
@@ -434,6 +438,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_nt")) *value = o.spmv_nt;
     else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
     else if (!strcmp(name, "spmv_xmask")) *value = o.spmv_xmask;
+    else if (!strcmp(name, "spmv_xload")) *value = o.spmv_xload;
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }

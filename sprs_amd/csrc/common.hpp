@@ -41,6 +41,7 @@ struct Options {
     int64_t spmv_kernel = 0;   // 0 auto, 1 tiled, 2 wave-per-row
     int64_t spmv_nt = 1;       // non-temporal loads on indices/data streams
     int64_t spmv_tile = 4096;  // nnz per workgroup tile (2048 or 4096)
+    int64_t spmv_xload = 0;    // x gather flavour: 0 plain, 1 non-temporal, 2 sc1 (L1 bypass)
     int64_t spmv_xmask = -1;   // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
 };
 Options &options();

@@ -44,6 +44,15 @@ __device__ __forceinline__ V stream_load(const V *p) {
     else return *p;
 }
 
+// gather of one x entry.  XL = 0: plain load (allocates a 128-byte line in the CU's L1),
+// 1: non-temporal, 2: sc1 (served by L2, bypasses L1: no line fill for 8 useful bytes).
+template <int XL>
+__device__ __forceinline__ double gather_x(const double *p) {
+    if constexpr (XL == 1) return __builtin_nontemporal_load(p);
+    else if constexpr (XL == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
@@ -83,7 +92,7 @@ __global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, u
 // ---------------------------------------------------------------------------
 // main kernel: one workgroup per nnz tile
 // ---------------------------------------------------------------------------
-template <typename IDX, typename PTR, int T, bool ACC, bool NT>
+template <typename IDX, typename PTR, int T, bool ACC, bool NT, int XL>
 __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
     const PTR *__restrict__ indptr, const IDX *__restrict__ indices, const double *__restrict__ data,
     const double *__restrict__ x, double *__restrict__ y, const uint64_t *__restrict__ tile_row,
@@ -124,8 +133,8 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
         double xv[PASSES][V];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            xv[p][0] = x[(uint64_t)ix[p][0] & xmask];
-            xv[p][1] = x[(uint64_t)ix[p][1] & xmask];
+            xv[p][0] = gather_x<XL>(x + ((uint64_t)ix[p][0] & xmask));
+            xv[p][1] = gather_x<XL>(x + ((uint64_t)ix[p][1] & xmask));
         }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
@@ -299,16 +308,24 @@ static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool 
     const dim3 grid((unsigned)pl.ntiles), block(BLOCK);
     const IDX *ix = (const IDX *)a->indices;
     const PTR *ip = (const PTR *)a->indptr;
-#define SPRS_LAUNCH(ACC_, NT_)                                                                              \
-    hipLaunchKernelGGL((spmv_tile_kernel<IDX, PTR, T, ACC_, NT_>), grid, block, 0, stream, ip, ix, a->data, x, y, \
+#define SPRS_LAUNCH(ACC_, NT_, XL_)                                                                              \
+    hipLaunchKernelGGL((spmv_tile_kernel<IDX, PTR, T, ACC_, NT_, XL_>), grid, block, 0, stream, ip, ix, a->data, x, y, \
                        pl.tile_row, carry, a->nnz, pl.ntiles, (uint64_t)options().spmv_xmask)
+#define SPRS_LAUNCH_XL(ACC_, NT_)                 \
+    do {                                          \
+        if (xl == 2) SPRS_LAUNCH(ACC_, NT_, 2);   \
+        else if (xl == 1) SPRS_LAUNCH(ACC_, NT_, 1); \
+        else SPRS_LAUNCH(ACC_, NT_, 0);           \
+    } while (0)
+    const int xl = (int)options().spmv_xload;
     if (acc) {
-        if (nt) SPRS_LAUNCH(true, true);
-        else SPRS_LAUNCH(true, false);
+        if (nt) SPRS_LAUNCH_XL(true, true);
+        else SPRS_LAUNCH_XL(true, false);
     } else {
-        if (nt) SPRS_LAUNCH(false, true);
-        else SPRS_LAUNCH(false, false);
+        if (nt) SPRS_LAUNCH_XL(false, true);
+        else SPRS_LAUNCH_XL(false, false);
     }
+#undef SPRS_LAUNCH_XL
 #undef SPRS_LAUNCH
     SPRS_TRY_HIP(hipGetLastError());
     if (pl.ntiles > 1) {

@@ -1,0 +1,102 @@
+// C++ parity test of the host mirror (include/sprs_hip.hpp) — reads like the
+// reference's own tests:
+//   mul_csr_vec            sprs/src/sparse/prod.rs:375-398
+//   mul_csr_csr            sprs/src/sparse/smmp.rs:467-473 (fixtures sprs/src/test_data.rs:6-11, 63-68)
+//   eye doc test           sprs/src/sparse/csmat.rs:406-415
+//   dimension / storage panics  prod.rs:114-118, smmp.rs:207
+// Built with g++ (no HIP headers needed: the boundary is a C ABI).  Exit code 0 = pass.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../../include/sprs_hip.hpp"
+
+using namespace sprs_hip;
+
+#define REQUIRE(cond)                                                   \
+    do {                                                                \
+        if (!(cond)) {                                                  \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            std::exit(1);                                               \
+        }                                                               \
+    } while (0)
+
+static DeviceCsMat mat1() {
+    return DeviceCsMat(SPRS_HIP_CSR, 5, 5, std::vector<uint64_t>{0, 2, 4, 5, 6, 7},
+                       std::vector<uint64_t>{2, 3, 3, 4, 2, 1, 3}, std::vector<double>{3., 4., 2., 5., 5., 8., 7.});
+}
+
+int main() {
+    int32_t ndev = 0;
+    if (sprs_hip_device_count(&ndev) != SPRS_HIP_OK || ndev < 1) {
+        std::fprintf(stderr, "no HIP device: %s\n", sprs_hip_last_error());
+        return 2;
+    }
+    {   // mul_csr_vec
+        DeviceCsMat mat(SPRS_HIP_CSR, 5, 5, std::vector<uint64_t>{0, 3, 3, 5, 6, 7},
+                        std::vector<uint64_t>{1, 2, 3, 2, 3, 4, 4},
+                        std::vector<double>{0.75672424, 0.1649078, 0.30140296, 0.10358244, 0.6283315, 0.39244208,
+                                            0.57202407});
+        DeviceVec x(std::vector<double>{0.1, 0.2, -0.1, 0.3, 0.9});
+        DeviceVec res(5);
+        prod::mul_acc_mat_vec_csr(mat, x, res);
+        const double expected[5] = {0.22527496, 0., 0.17814121, 0.35319787, 0.51482166};
+        auto got = res.to_host();
+        for (int i = 0; i < 5; ++i) REQUIRE(std::fabs(got[i] - expected[i]) < 1e-7);
+        prod::mul_acc_mat_vec_csr(mat, x, res);   // accumulates
+        got = res.to_host();
+        for (int i = 0; i < 5; ++i) REQUIRE(std::fabs(got[i] - 2 * expected[i]) < 2e-7);
+        auto y = (mat * x).to_host();             // operator form
+        for (int i = 0; i < 5; ++i) REQUIRE(std::fabs(y[i] - expected[i]) < 1e-7);
+    }
+    {   // eye * x == x
+        std::vector<double> xs(1000);
+        for (int i = 0; i < 1000; ++i) xs[i] = 0.5 + i / 1000.0;
+        auto y = (DeviceCsMat::eye(1000) * DeviceVec(xs)).to_host();
+        REQUIRE(y == xs);
+    }
+    {   // mul_csr_csr: mat1 * mat1 == mat1_self_matprod, exactly
+        DeviceCsMat a = mat1();
+        DeviceCsMat c = a * a;
+        std::vector<uint64_t> ip, ix;
+        std::vector<double> dt;
+        c.to_host(ip, ix, dt);
+        REQUIRE((ip == std::vector<uint64_t>{0, 2, 4, 5, 7, 8}));
+        REQUIRE((ix == std::vector<uint64_t>{1, 2, 1, 3, 2, 3, 4, 1}));
+        REQUIRE((dt == std::vector<double>{32., 15., 16., 35., 25., 16., 40., 56.}));
+        REQUIRE(c.rows() == 5 && c.cols() == 5 && c.is_csr());
+    }
+    {   // panics -> exceptions with the reference's text
+        DeviceCsMat a = mat1();
+        DeviceVec x4(4), y5(5);
+        bool threw = false;
+        try {
+            prod::mul_acc_mat_vec_csr(a, x4, y5);
+        } catch (const Error &e) {
+            threw = e.status == SPRS_HIP_DIM_MISMATCH && std::string(e.what()) == "Dimension mismatch";
+        }
+        REQUIRE(threw);
+        DeviceCsMat csc(SPRS_HIP_CSC, 5, 5, std::vector<uint64_t>{0, 0, 1, 3, 6, 7},
+                        std::vector<uint64_t>{3, 0, 2, 0, 1, 4, 1}, std::vector<double>{8., 3., 5., 4., 2., 7., 5.});
+        DeviceVec x5(5);
+        threw = false;
+        try {
+            prod::mul_acc_mat_vec_csr(csc, x5, y5);
+        } catch (const Error &e) {
+            threw = e.status == SPRS_HIP_STORAGE_MISMATCH && std::string(e.what()) == "Storage mismatch";
+        }
+        REQUIRE(threw);
+        DeviceCsMat wide(SPRS_HIP_CSR, 2, 3, std::vector<uint64_t>{0, 1, 2}, std::vector<uint64_t>{0, 2},
+                         std::vector<double>{1., 1.});
+        threw = false;
+        try {
+            DeviceCsMat bad = wide * wide;
+        } catch (const Error &e) {
+            threw = e.status == SPRS_HIP_DIM_MISMATCH;
+        }
+        REQUIRE(threw);
+    }
+    std::printf("host_mirror_test: all passed\n");
+    return 0;
+}

@@ -272,3 +272,16 @@ def test_full_size_properties_config2(hip):
     yb = np.zeros(r1 - r0)
     oracle.mul_acc_mat_vec_csr((r1 - r0, n), ip_h, ix_h, dt_h, x.cpu().numpy(), yb)
     assert rel_err(ax[r0:r1].cpu().numpy(), yb) <= TOL
+
+
+def test_cpp_host_mirror(hip):
+    """include/sprs_hip.hpp (C++ host side, reference-shaped API) through the same C ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "host_mirror_test.bin")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all passed" in r.stdout
