@@ -43,9 +43,8 @@ def main():
     ap.add_argument("--idx-bytes", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", type=int, default=None, help="spmv_kernel option for A/B (1 tiled, 2 wave-per-row)")
-    ap.add_argument("--tile", type=int, default=None)
-    ap.add_argument("--nt", type=int, default=None)
-    ap.add_argument("--xload", type=int, default=None, help="x gather flavour: 0 plain, 1 nt, 2 sc1")
+    ap.add_argument("--xcs", type=int, default=None, help="XCD-sliced plan: 0 auto, 1 on, 2 off")
+    ap.add_argument("--split", type=int, default=None, help="row-length threshold of the sliced part")
     ap.add_argument("--xmask", type=int, default=None, help="timing experiment only: gather x[col & mask]")
     args = ap.parse_args()
 
@@ -72,7 +71,7 @@ def main():
     from sprs_amd import _ffi
     import ctypes as C
     _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
-    for opt, val in (("spmv_kernel", args.kernel), ("spmv_tile", args.tile), ("spmv_nt", args.nt), ("spmv_xmask", args.xmask), ("spmv_xload", args.xload)):
+    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xmask", args.xmask)):
         if val is not None:
             sprs_amd.set_option(opt, val)
 
@@ -156,6 +155,13 @@ def main():
     alg_bytes = algorithmic_bytes(blk_rows, blk_cols, sh.block_nnz, args.idx_bytes, args.idx_bytes)
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
+    if sprs_amd.get_option("spmv_kernel") == 2:
+        kernel_name = "sprs_hip::spmv_rowwave_kernel"
+    elif sprs_amd.get_option("spmv_xcs") == 2:
+        kernel_name = "sprs_hip::spmv_tile_kernel (+ spmv_carry_kernel)"
+    else:
+        kernel_name = ("sprs_hip::spmv_sliced_kernel + spmv_tile_kernel (short rows) + carry/reduce kernels "
+                       "of one SpMV when the XCD-sliced plan applies, else spmv_tile_kernel")
     out = {
         "metric": "CSR SpMV GFLOP/s",
         "value": round(gflops, 3),
@@ -178,7 +184,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "sprs_hip::spmv_tile_kernel" if sprs_amd.get_option("spmv_kernel") != 2 else "sprs_hip::spmv_rowwave_kernel",
+            "kernel": kernel_name,
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

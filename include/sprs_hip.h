@@ -155,9 +155,11 @@ int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat 
 
 /* ---- tuning knobs (A/B runs; never needed for correctness) -------------- */
 
-/* name = "spmv_kernel": 0 auto, 1 nnz-tiled streaming kernel, 2 wave-per-row;
- * name = "spmv_nt": 0/1 non-temporal loads on the matrix streams.
- * Process-wide.  Unknown names return SPRS_HIP_INVALID_ARG. */
+/* name = "spmv_kernel":    0 auto, 1 nnz-tiled streaming kernel, 2 wave-per-row (A/B only);
+ * name = "spmv_xcs":       XCD-sliced plan for long rows: 0 auto, 1 force on, 2 off;
+ * name = "spmv_xcs_split": rows with at least this many entries go to the sliced part (default 64);
+ * name = "spmv_xmask":     timing experiments only (gathers x[col & mask]; results are wrong unless -1).
+ * Process-wide.  Unknown names / bad values return SPRS_HIP_INVALID_ARG. */
 int32_t sprs_hip_set_option(const char *name, int64_t value);
 int32_t sprs_hip_get_option(const char *name, int64_t *value);
 

@@ -50,13 +50,38 @@ Options &options() {
 }
 
 void SpmvPlan::release() {
-    if (tile_row) (void)hipFree(tile_row);
-    for (auto &kv : carry)
-        if (kv.second) (void)hipFree(kv.second);
-    carry.clear();
-    tile_row = nullptr;
-    ntiles = 0;
-    tile = 0;
+    auto drop = [](void *p) {
+        if (p) (void)hipFree(p);
+    };
+    drop(main.tile_row);
+    if (main.owns) {
+        drop(main.indptr);
+        drop(main.indices);
+        drop(main.data);
+    }
+    main = CsrPiece();
+    for (auto &sl : slice) {
+        drop(sl.tile_row);
+        if (sl.owns) {
+            drop(sl.indptr);
+            drop(sl.indices);
+            drop(sl.data);
+        }
+        sl = CsrPiece();
+    }
+    drop(long_rows);
+    drop(slab);
+    long_rows = nullptr;
+    slab = nullptr;
+    for (auto &kv : scratch) {
+        drop(kv.second.carry_main);
+        drop(kv.second.carry_slices);
+        drop(kv.second.partial);
+    }
+    scratch.clear();
+    n_long = 0;
+    built = false;
+    xcs = false;
 }
 
 int32_t alloc_csmat(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols, uint64_t nnz,
@@ -416,17 +441,20 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     clear_error();
     if (!name) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL name");
     Options &o = options();
-    if (!strcmp(name, "spmv_kernel")) o.spmv_kernel = value;
-    else if (!strcmp(name, "spmv_nt")) o.spmv_nt = value;
-    else if (!strcmp(name, "spmv_tile")) {
-        if (value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 2048 or 4096");
-        o.spmv_tile = value;
-    } else if (!strcmp(name, "spmv_xmask")) o.spmv_xmask = value;
-    else if (!strcmp(name, "spmv_xload")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_xload must be 0, 1 or 2");
-        o.spmv_xload = value;
+    if (!strcmp(name, "spmv_kernel")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_kernel must be 0, 1 or 2");
+        o.spmv_kernel = value;
+    } else if (!strcmp(name, "spmv_xcs")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_xcs must be 0 (auto), 1 (on) or 2 (off)");
+        o.spmv_xcs = value;
+    } else if (!strcmp(name, "spmv_xcs_split")) {
+        if (value < 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_xcs_split must be >= 2");
+        o.spmv_xcs_split = value;
+    } else if (!strcmp(name, "spmv_xmask")) {
+        o.spmv_xmask = value;
+    } else {
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     }
-    else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }
 
@@ -435,10 +463,9 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     if (!name || !value) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     Options &o = options();
     if (!strcmp(name, "spmv_kernel")) *value = o.spmv_kernel;
-    else if (!strcmp(name, "spmv_nt")) *value = o.spmv_nt;
-    else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
+    else if (!strcmp(name, "spmv_xcs")) *value = o.spmv_xcs;
+    else if (!strcmp(name, "spmv_xcs_split")) *value = o.spmv_xcs_split;
     else if (!strcmp(name, "spmv_xmask")) *value = o.spmv_xmask;
-    else if (!strcmp(name, "spmv_xload")) *value = o.spmv_xload;
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }

@@ -38,22 +38,47 @@ void clear_error();
 
 // ---- options -------------------------------------------------------------
 struct Options {
-    int64_t spmv_kernel = 0;   // 0 auto, 1 tiled, 2 wave-per-row
-    int64_t spmv_nt = 1;       // non-temporal loads on indices/data streams
-    int64_t spmv_tile = 4096;  // nnz per workgroup tile (2048 or 4096)
-    int64_t spmv_xload = 0;    // x gather flavour: 0 plain, 1 non-temporal, 2 sc1 (L1 bypass)
-    int64_t spmv_xmask = -1;   // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
+    int64_t spmv_kernel = 0;       // 0 auto, 1 nnz-tiled, 2 wave-per-row (A/B only)
+    int64_t spmv_xcs = 0;          // XCD-sliced plan for long rows: 0 auto, 1 force on, 2 off
+    int64_t spmv_xcs_split = 64;   // rows with >= this many entries go to the sliced part
+    int64_t spmv_xmask = -1;       // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
 };
 Options &options();
 
-// ---- SpMV plan: nnz-tile -> first row starting in the tile ----------------
+// ---- SpMV plan ---------------------------------------------------------------
+constexpr int XCS_SLICES = 8;      // one slice of x lines per XCD (each XCD has a private 4 MiB L2)
+
+// One CSR piece the tile kernel runs over.
+struct CsrPiece {
+    void *indptr = nullptr;        // device; PTR of the handle for `main`, uint64 for slices
+    void *indices = nullptr;       // device
+    double *data = nullptr;        // device
+    uint64_t rows = 0, nnz = 0, ntiles = 0;
+    uint64_t *tile_row = nullptr;  // device, ntiles + 1: first row starting at/after tile c
+    bool owns = false;             // arrays allocated by the plan (copies), not borrowed from the handle
+};
+
+struct SpmvScratch {               // per stream: nothing in here is shared between in-flight SpMVs
+    double *carry_main = nullptr;
+    double *carry_slices = nullptr;
+    double *partial = nullptr;     // XCS_SLICES x n_long partial row sums
+};
+
 struct SpmvPlan {
-    uint32_t tile = 0;              // nnz per tile this plan was built for
-    uint64_t ntiles = 0;
-    uint64_t *tile_row = nullptr;   // device, ntiles + 1 entries
-    std::unordered_map<void *, double *> carry;   // per-stream carry scratch (ntiles doubles)
+    bool built = false;
+    bool xcs = false;
+    int64_t opt_xcs = -1, opt_split = -1;   // option values the plan was built with
+    CsrPiece main;                 // the whole matrix (plain plan) or its short rows (sliced plan)
+    CsrPiece slice[XCS_SLICES];    // long rows, entries whose x line hashes to s, rows = n_long
+    uint64_t slice_tile_off[XCS_SLICES + 1] = {0};
+    uint64_t n_long = 0;
+    uint64_t *long_rows = nullptr; // device: original row of long row j
+    void *slab = nullptr;          // backing store of all plan-owned arrays
+    std::unordered_map<void *, SpmvScratch> scratch;
     void release();
 };
+
+int32_t exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t stream);   // scan.hip
 
 }  // namespace sprs_hip
 

@@ -1,0 +1,32 @@
+// Device-side building block shared by spmv.hip / spgemm.hip / scan.hip:
+// exclusive scan of one uint64 per thread across a workgroup (wave shuffles +
+// one LDS hop).  blockDim.x must be a multiple of 64, at most 1024.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace sprs_hip {
+
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *wave_tot /*LDS, >= 16*/, uint64_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+        const uint64_t t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+}  // namespace sprs_hip

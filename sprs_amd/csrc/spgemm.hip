@@ -22,6 +22,7 @@
 // Per-task counts are scanned (hand-written two-level prefix sum) into output
 // offsets; C.indptr falls out of the same scan.  Integer/HBM-bound: no MFMA.
 #include "common.hpp"
+#include "scan.hpp"
 
 namespace sprs_hip {
 
@@ -111,108 +112,6 @@ __global__ void make_tasks_kernel(const uint64_t *__restrict__ ub, const uint64_
         const uint64_t pos = atomicAdd(&counters[1], (unsigned long long)n);
         for (uint64_t j = 0; j < n; ++j) large_list[pos + j] = f + j;
     }
-}
-
-// ---------------------------------------------------------------------------
-// exclusive prefix sum over uint64 (two-level, hand written):
-//   out[i] = sum_{j<i} in[j]  for i = 0..n   (out has n+1 entries, out[n] = total)
-// ---------------------------------------------------------------------------
-constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_ITEMS = 8;
-constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
-
-__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *wave_tot /*LDS, >= 16*/, uint64_t *total) {
-    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    const uint32_t nwaves = blockDim.x / WAVE;
-    uint64_t inc = v;
-#pragma unroll
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const uint64_t o = __shfl_up(inc, off, WAVE);
-        if (lane >= (uint32_t)off) inc += o;
-    }
-    if (lane == WAVE - 1) wave_tot[wave] = inc;
-    __syncthreads();
-    uint64_t base = 0, tot = 0;
-    for (uint32_t w = 0; w < nwaves; ++w) {
-        const uint64_t t = wave_tot[w];
-        if (w < wave) base += t;
-        tot += t;
-    }
-    __syncthreads();
-    *total = tot;
-    return base + inc - v;
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_partial_kernel(const uint64_t *__restrict__ in, uint64_t n,
-                                                                  uint64_t *__restrict__ sums) {
-    __shared__ uint64_t wt[16];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i)
-        if (base + i < n) s += in[base + i];
-    uint64_t tot;
-    (void)block_excl_scan_u64(s, wt, &tot);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(1024) void scan_sums_kernel(uint64_t *__restrict__ sums, uint64_t nblocks) {
-    __shared__ uint64_t wt[16];
-    uint64_t carry = 0;
-    for (uint64_t b0 = 0; b0 < nblocks; b0 += 1024) {
-        const uint64_t i = b0 + threadIdx.x;
-        const uint64_t v = i < nblocks ? sums[i] : 0;
-        uint64_t tot;
-        const uint64_t ex = block_excl_scan_u64(v, wt, &tot);
-        if (i < nblocks) sums[i] = carry + ex;
-        carry += tot;
-    }
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_final_kernel(const uint64_t *__restrict__ in, uint64_t n,
-                                                                const uint64_t *__restrict__ sums,
-                                                                uint64_t *__restrict__ out) {
-    __shared__ uint64_t wt[16];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint64_t v[SCAN_ITEMS];
-    uint64_t s = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        v[i] = base + i < n ? in[base + i] : 0;
-        s += v[i];
-    }
-    uint64_t tot;
-    uint64_t run = sums[blockIdx.x] + block_excl_scan_u64(s, wt, &tot);
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) {
-        if (base + i < n) out[base + i] = run;
-        run += v[i];
-    }
-}
-
-__global__ void scan_total_kernel(const uint64_t *__restrict__ in, const uint64_t *__restrict__ out_excl, uint64_t n,
-                                  uint64_t *__restrict__ out) {
-    // out[n] = out[n-1] + in[n-1]
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[n] = n ? out_excl[n - 1] + in[n - 1] : 0;
-}
-
-static int32_t exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t stream) {
-    if (n == 0) {
-        SPRS_TRY_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), stream));
-        return SPRS_HIP_OK;
-    }
-    const uint64_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
-    uint64_t *sums = nullptr;
-    SPRS_TRY_HIP(hipMalloc((void **)&sums, nblocks * sizeof(uint64_t)));
-    hipLaunchKernelGGL(scan_partial_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, n, sums);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks);
-    hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, n, sums, out);
-    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, stream, in, out, n, out);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(sums);
-    if (e != hipSuccess) return fail_hip(e, "exclusive_scan_u64");
-    return SPRS_HIP_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -4,54 +4,62 @@
 //
 // Design (HBM-bound: 16 B of matrix stream per multiply-add, no reuse, no MFMA):
 //
-//  * The nnz axis, not the row axis, is what gets partitioned: workgroup c owns
-//    the nnz TILE [c*T, (c+1)*T).  Every lane streams `indices` and `data` with
-//    16-byte loads that are perfectly coalesced whatever the row lengths are
-//    (R-MAT rows run from 0 to 2.3e5 entries), and every workgroup moves the
-//    same number of bytes, so the chip is load-balanced by construction.
-//  * products a_ik * x_k are staged in LDS (T doubles), then reduced per row
-//    SEGMENT of the tile: short segments (< 64 entries) by one lane each,
-//    long ones by a whole wave with a shuffle tree.  Row boundaries come from
-//    `indptr`, read once, coalesced, and kept in LDS as tile-local offsets.
-//  * the part of a tile that belongs to a row which started in an earlier tile
-//    (its "head") goes to carry[c]; a second, tiny kernel adds the carries of
-//    a long row in tile order.  No float atomics: results are run-to-run
-//    deterministic.
-//  * tiles are dealt to the 8 XCDs in contiguous chunks (blockIdx -> tile remap)
-//    so that neighbouring tiles, which gather neighbouring x entries on banded
-//    matrices, share one L2.
-//  * indices/data are loaded non-temporally: they are used once, x should keep
-//    the L2 / Infinity Cache.
-//  * products use a separately rounded multiply and add (-ffp-contract=off),
-//    as sprs' MulAcc does (sprs/src/mul_acc.rs:28-30).
+//  1. THE TILE KERNEL.  The nnz axis, not the row axis, is partitioned: workgroup c
+//     owns the nnz TILE [c*T, (c+1)*T).  Every lane streams `indices` and `data` with
+//     16-byte non-temporal loads that are perfectly coalesced whatever the row lengths
+//     are (R-MAT rows run from 0 to 2.3e5 entries), and every workgroup moves the same
+//     number of bytes: load balance by construction.  Products a_ik * x_k are staged
+//     in LDS (T doubles) and reduced per row SEGMENT of the tile — short segments
+//     (< 64 entries) by one lane each, long ones by a whole wave with a shuffle tree;
+//     row boundaries come from `indptr`, read once, coalesced, kept in LDS as
+//     tile-local offsets.  The part of a tile that belongs to a row which started in an
+//     earlier tile goes to carry[c]; a tiny second kernel adds the carries of a long
+//     row in tile order.  No float atomics anywhere: run-to-run deterministic.
+//
+//  2. THE XCD-SLICED PLAN.  On power-law matrices the gathers x[col], not the stream,
+//     set the time: rocprofv3 counters on R-MAT 10M show 286 M L1->L2 gather requests
+//     per SpMV of which 42 % miss the 4 MiB L2, i.e. ~21 GB of fabric traffic for
+//     5.4 GB of algorithmic bytes (profiles/).  MI355X has EIGHT private L2s (one per
+//     XCD); with a plain launch all eight cache the same hot x lines.  The plan
+//     therefore splits the matrix once, at first use: rows shorter than `split` stay
+//     in a CSR piece of their own; for the long rows (90 % of the entries) slice s
+//     holds the entries whose x line (col >> 4) hashes to s, and slice s is
+//     processed by workgroups with blockIdx % 8 == s, i.e. on XCD s.  Each L2 then
+//     serves 1/8 of x: eight times the effective cache.  Slice results are per-row
+//     partials, summed in slice order by a last small kernel (deterministic).
+//     The split is a pure re-layout in HBM (the handle keeps its CSR arrays);
+//     correctness never depends on where a workgroup runs.
+//
+//  3. Products use a separately rounded multiply and add (-ffp-contract=off), as sprs'
+//     MulAcc does (sprs/src/mul_acc.rs:28-30); only the summation order inside a row
+//     differs from the reference (tree instead of left-to-right).
 #include "common.hpp"
+#include "scan.hpp"
 
 namespace sprs_hip {
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
-typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BLOCK = 256;       // 4 waves
 constexpr int WAVE = 64;
 constexpr int NWAVES = BLOCK / WAVE;
+constexpr int TILE = 4096;       // nnz per workgroup: 64 KiB of matrix stream in flight per workgroup
 constexpr int SEG_CHUNK = 2048;  // row boundaries staged per pass
 constexpr uint32_t LONG_SEG = 64;
 
-template <typename V, bool NT>
-__device__ __forceinline__ V stream_load(const V *p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
+struct TileArgs {
+    const void *indptr;          // PTR[rows + 1]
+    const void *indices;         // IDX[nnz]
+    const double *data;
+    const uint64_t *tile_row;    // ntiles + 1
+    double *carry;               // ntiles
+    double *y;
+    uint64_t nnz, ntiles;
+};
 
-// gather of one x entry.  XL = 0: plain load (allocates a 128-byte line in the CU's L1),
-// 1: non-temporal, 2: sc1 (served by L2, bypasses L1: no line fill for 8 useful bytes).
-template <int XL>
-__device__ __forceinline__ double gather_x(const double *p) {
-    if constexpr (XL == 1) return __builtin_nontemporal_load(p);
-    else if constexpr (XL == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
+struct SlicedArgs {
+    TileArgs p[XCS_SLICES];
+};
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -59,7 +67,8 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// blockIdx -> tile, contiguous chunk of tiles per XCD (block b runs on XCD b % 8).
+// blockIdx -> tile, contiguous chunk of tiles per XCD (block b runs on XCD b % 8):
+// neighbouring tiles gather neighbouring x entries on banded matrices and share one L2.
 __device__ __forceinline__ uint64_t tile_of_block(uint64_t bid, uint64_t ntiles) {
     const uint64_t q = ntiles >> 3, rem = ntiles & 7;
     const uint64_t k = bid & 7, j = bid >> 3;
@@ -71,7 +80,7 @@ __device__ __forceinline__ uint64_t tile_of_block(uint64_t bid, uint64_t ntiles)
 //       tile_row[ntiles] = rows
 // ---------------------------------------------------------------------------
 template <typename PTR>
-__global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, uint64_t ntiles, uint32_t T,
+__global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, uint64_t ntiles,
                                 uint64_t *__restrict__ tile_row) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c > ntiles) return;
@@ -79,7 +88,7 @@ __global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, u
         tile_row[c] = rows;
         return;
     }
-    const uint64_t target = c * (uint64_t)T;
+    const uint64_t target = c * (uint64_t)TILE;
     uint64_t lo = 0, hi = rows;   // lower_bound over indptr[0..rows)
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
@@ -90,51 +99,50 @@ __global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, u
 }
 
 // ---------------------------------------------------------------------------
-// main kernel: one workgroup per nnz tile
+// one workgroup, one nnz tile
 // ---------------------------------------------------------------------------
-template <typename IDX, typename PTR, int T, bool ACC, bool NT, int XL>
-__global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
-    const PTR *__restrict__ indptr, const IDX *__restrict__ indices, const double *__restrict__ data,
-    const double *__restrict__ x, double *__restrict__ y, const uint64_t *__restrict__ tile_row,
-    double *__restrict__ carry, uint64_t nnz, uint64_t ntiles, uint64_t xmask) {
+template <typename IDX, typename PTR, bool ACC>
+__device__ __forceinline__ void tile_body(const TileArgs &a, const double *__restrict__ x, uint64_t tile,
+                                          uint64_t xmask) {
     constexpr int V = 2;                          // elements per lane per pass (16 B of data)
-    constexpr int PASSES = T / (BLOCK * V);
+    constexpr int PASSES = TILE / (BLOCK * V);
     typedef IDX idx2 __attribute__((ext_vector_type(2)));
 
-    __shared__ __attribute__((aligned(16))) double prod[T];
+    __shared__ __attribute__((aligned(16))) double prod[TILE];
     __shared__ uint32_t segb[SEG_CHUNK + 1];
-    __shared__ uint32_t longlist[T / LONG_SEG + 1];
+    __shared__ uint32_t longlist[TILE / LONG_SEG + 1];
     __shared__ uint32_t nlong;
 
+    const PTR *__restrict__ indptr = (const PTR *)a.indptr;
+    double *__restrict__ y = a.y;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (WAVE - 1);
     const uint32_t wave = tid / WAVE;
-    const uint64_t tile = tile_of_block(blockIdx.x, ntiles);
-    const uint64_t base = tile * (uint64_t)T;
-    const uint32_t cnt = (nnz - base < (uint64_t)T) ? (uint32_t)(nnz - base) : (uint32_t)T;
+    const uint64_t base = tile * (uint64_t)TILE;
+    const uint32_t cnt = (a.nnz - base < (uint64_t)TILE) ? (uint32_t)(a.nnz - base) : (uint32_t)TILE;
     const uint64_t lim = base + cnt;
-    const uint64_t R0 = tile_row[tile], R1 = tile_row[tile + 1];
+    const uint64_t R0 = a.tile_row[tile], R1 = a.tile_row[tile + 1];
     const uint64_t S = R1 - R0 + 1;               // head + rows starting in this tile
 
     if (tid == 0) nlong = 0;
 
     // ---- phase 1: stream the tile, gather x, products -> LDS ---------------
-    const IDX *ip = indices + base;
-    const double *dp = data + base;
-    if (cnt == (uint32_t)T) {
+    const IDX *ip = (const IDX *)a.indices + base;
+    const double *dp = a.data + base;
+    if (cnt == (uint32_t)TILE) {
         idx2 ix[PASSES];
         dbl2 av[PASSES];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const uint32_t i = p * (BLOCK * V) + tid * V;
-            ix[p] = stream_load<idx2, NT>((const idx2 *)(ip + i));
-            av[p] = stream_load<dbl2, NT>((const dbl2 *)(dp + i));
+            ix[p] = __builtin_nontemporal_load((const idx2 *)(ip + i));   // used once: keep L2 for x
+            av[p] = __builtin_nontemporal_load((const dbl2 *)(dp + i));
         }
         double xv[PASSES][V];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            xv[p][0] = gather_x<XL>(x + ((uint64_t)ix[p][0] & xmask));
-            xv[p][1] = gather_x<XL>(x + ((uint64_t)ix[p][1] & xmask));
+            xv[p][0] = x[(uint64_t)ix[p][0] & xmask];
+            xv[p][1] = x[(uint64_t)ix[p][1] & xmask];
         }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
@@ -172,16 +180,16 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
         __syncthreads();   // prod[], segb[], nlong visible
 
         for (uint32_t t = tid; t < n; t += BLOCK) {
-            const uint32_t a = segb[t], b = segb[t + 1];
-            const uint32_t len = b - a;
+            const uint32_t sa = segb[t], sb = segb[t + 1];
+            const uint32_t len = sb - sa;
             if (len >= LONG_SEG) {
                 longlist[atomicAdd(&nlong, 1u)] = t;
             } else {
                 double s = 0.0;
-                for (uint32_t k = a; k < b; ++k) s += prod[k];
+                for (uint32_t k = sa; k < sb; ++k) s += prod[k];
                 const uint64_t j = j0 + t;
                 if (j == 0) {
-                    carry[tile] = s;
+                    a.carry[tile] = s;
                 } else {
                     const uint64_t r = R0 + j - 1;
                     if constexpr (ACC) {
@@ -197,14 +205,14 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
         const uint32_t nl = nlong;
         for (uint32_t q = wave; q < nl; q += NWAVES) {
             const uint32_t t = longlist[q];
-            const uint32_t a = segb[t], b = segb[t + 1];
+            const uint32_t sa = segb[t], sb = segb[t + 1];
             double s = 0.0;
-            for (uint32_t k = a + lane; k < b; k += WAVE) s += prod[k];
+            for (uint32_t k = sa + lane; k < sb; k += WAVE) s += prod[k];
             s = wave_sum(s);
             if (lane == 0) {
                 const uint64_t j = j0 + t;
                 if (j == 0) {
-                    carry[tile] = s;
+                    a.carry[tile] = s;
                 } else {
                     const uint64_t r = R0 + j - 1;
                     if constexpr (ACC) y[r] = y[r] + s;
@@ -217,22 +225,60 @@ __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(
     }
 }
 
+template <typename IDX, typename PTR, bool ACC>
+__global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(TileArgs a, const double *__restrict__ x, uint64_t xmask) {
+    tile_body<IDX, PTR, ACC>(a, x, tile_of_block(blockIdx.x, a.ntiles), xmask);
+}
+
+// Sliced launch: workgroup b works on slice b % 8 — the dispatcher places block b on
+// XCD b % 8, so slice s's x lines live in ONE L2.  (Placement only affects speed.)
+template <typename IDX>
+__global__ __launch_bounds__(BLOCK) void spmv_sliced_kernel(const SlicedArgs *__restrict__ sa,
+                                                            const double *__restrict__ x, uint64_t xmask) {
+    const uint32_t s = blockIdx.x & (XCS_SLICES - 1);
+    const uint64_t tile = blockIdx.x >> 3;
+    const TileArgs a = sa->p[s];
+    if (tile >= a.ntiles) return;
+    tile_body<IDX, uint64_t, false>(a, x, tile, xmask);
+}
+
 // ---------------------------------------------------------------------------
 // fix-up: a row that spans several tiles gets the heads of the later tiles
 // added in tile order (deterministic).  One thread per tile.
 // ---------------------------------------------------------------------------
 template <typename PTR>
-__global__ void spmv_carry_kernel(const PTR *__restrict__ indptr, const uint64_t *__restrict__ tile_row,
-                                  const double *__restrict__ carry, double *__restrict__ y, uint64_t ntiles,
-                                  uint32_t T) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c + 1 >= ntiles) return;
-    const uint64_t R0 = tile_row[c], R1 = tile_row[c + 1];
-    if (R1 == R0) return;                                    // no row starts in tile c
-    if ((uint64_t)indptr[R1] <= (c + 1) * (uint64_t)T) return;   // last row ends inside tile c
+__device__ __forceinline__ void carry_body(const TileArgs &a, uint64_t c) {
+    if (c + 1 >= a.ntiles) return;
+    const uint64_t R0 = a.tile_row[c], R1 = a.tile_row[c + 1];
+    if (R1 == R0) return;                                                        // no row starts in tile c
+    if ((uint64_t)((const PTR *)a.indptr)[R1] <= (c + 1) * (uint64_t)TILE) return;   // last row ends inside tile c
     double acc = 0.0;
-    for (uint64_t d = c + 1; d < ntiles && tile_row[d] == R1; ++d) acc += carry[d];
-    y[R1 - 1] += acc;
+    for (uint64_t d = c + 1; d < a.ntiles && a.tile_row[d] == R1; ++d) acc += a.carry[d];
+    a.y[R1 - 1] += acc;
+}
+
+template <typename PTR>
+__global__ void spmv_carry_kernel(TileArgs a) {
+    carry_body<PTR>(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__global__ void spmv_sliced_carry_kernel(const SlicedArgs *__restrict__ sa) {
+    const TileArgs a = sa->p[blockIdx.y];
+    carry_body<uint64_t>(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// y[long_rows[j]] (+)= sum over slices, in slice order
+template <bool ACC>
+__global__ void xcs_reduce_kernel(const double *__restrict__ partial, const uint64_t *__restrict__ long_rows,
+                                  double *__restrict__ y, uint64_t n_long) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_long) return;
+    double s = partial[j];
+#pragma unroll
+    for (int k = 1; k < XCS_SLICES; ++k) s += partial[(uint64_t)k * n_long + j];
+    const uint64_t r = long_rows[j];
+    if constexpr (ACC) y[r] = y[r] + s;
+    else y[r] = s;
 }
 
 // ---------------------------------------------------------------------------
@@ -263,77 +309,320 @@ __global__ __launch_bounds__(BLOCK) void spmv_rowwave_kernel(const PTR *__restri
 }
 
 // ---------------------------------------------------------------------------
+// building the XCD-sliced plan (one-time re-layout, all on the device)
+// ---------------------------------------------------------------------------
+template <typename PTR>
+__global__ void xcs_classify_kernel(const PTR *__restrict__ indptr, uint64_t rows, uint64_t split,
+                                    uint64_t *__restrict__ short_len, uint64_t *__restrict__ long_flag) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint64_t len = (uint64_t)indptr[r + 1] - (uint64_t)indptr[r];
+    const bool is_long = len >= split;
+    short_len[r] = is_long ? 0 : len;
+    long_flag[r] = is_long ? 1 : 0;
+}
+
+// short rows: copied into their own CSR piece (long rows become empty rows of it)
+template <typename IDX, typename PTR>
+__global__ void xcs_fill_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
+                                const double *__restrict__ data, uint64_t rows, const uint64_t *__restrict__ long_flag,
+                                const uint64_t *__restrict__ short_ptr, const uint64_t *__restrict__ long_pos,
+                                PTR *__restrict__ s_indptr, IDX *__restrict__ s_indices, double *__restrict__ s_data,
+                                uint64_t *__restrict__ long_rows) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rows) return;
+    s_indptr[r] = (PTR)short_ptr[r];
+    if (r == rows) return;
+    if (long_flag[r]) {
+        long_rows[long_pos[r]] = r;
+        return;
+    }
+    const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
+    uint64_t d = short_ptr[r];
+    for (uint64_t p = s; p < e; ++p, ++d) {
+        s_indices[d] = indices[p];
+        s_data[d] = data[p];
+    }
+}
+
+// slice of an x entry = top 3 bits of a multiplicative (Fibonacci) hash of its 128-byte
+// line number.  A plain bit field ((col >> 4) & 7) is badly unbalanced on R-MAT, whose
+// column bits are each 0 with probability .76 (slice 0 would get 44 % of the entries: the
+// first sliced plan ran 2x slower than no slicing for exactly that reason); the hash is
+// balanced to ~1 % on R-MAT scale 24 and spreads consecutive lines of banded matrices.
+__device__ __forceinline__ uint32_t x_slice(uint64_t col) {
+    return (uint32_t)(((col >> 4) * 0x9E3779B97F4A7C15ull) >> 61);
+}
+
+// long rows: entries per (row, slice); cnt is slice-major: cnt[s * n_long + j]
+template <typename IDX, typename PTR>
+__global__ __launch_bounds__(BLOCK) void xcs_count_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
+                                                          const uint64_t *__restrict__ long_rows, uint64_t n_long,
+                                                          uint64_t *__restrict__ cnt) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint64_t w0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) / WAVE;
+    const uint64_t nw = (uint64_t)gridDim.x * NWAVES;
+    for (uint64_t j = w0; j < n_long; j += nw) {
+        const uint64_t r = long_rows[j];
+        const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
+        uint32_t c[XCS_SLICES] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint64_t p0 = s; p0 < e; p0 += WAVE) {
+            const uint64_t p = p0 + lane;
+            const uint32_t sl = p < e ? x_slice((uint64_t)indices[p]) : XCS_SLICES;
+#pragma unroll
+            for (int k = 0; k < XCS_SLICES; ++k) c[k] += (uint32_t)__popcll(__ballot(sl == (uint32_t)k));
+        }
+        if (lane < XCS_SLICES) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int k = 0; k < XCS_SLICES; ++k) mine = (lane == (uint32_t)k) ? c[k] : mine;
+            cnt[(uint64_t)lane * n_long + j] = mine;
+        }
+    }
+}
+
+struct SliceOut {
+    const uint64_t *ptr[XCS_SLICES];   // per-slice indptr (n_long + 1)
+    void *indices[XCS_SLICES];
+    double *data[XCS_SLICES];
+};
+
+// stable partition of every long row into its 8 slices (column order kept)
+template <typename IDX, typename PTR>
+__global__ __launch_bounds__(BLOCK) void xcs_scatter_kernel(const PTR *__restrict__ indptr,
+                                                            const IDX *__restrict__ indices,
+                                                            const double *__restrict__ data,
+                                                            const uint64_t *__restrict__ long_rows, uint64_t n_long,
+                                                            SliceOut out) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint64_t w0 = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) / WAVE;
+    const uint64_t nw = (uint64_t)gridDim.x * NWAVES;
+    for (uint64_t j = w0; j < n_long; j += nw) {
+        const uint64_t r = long_rows[j];
+        const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
+        uint64_t base[XCS_SLICES];
+#pragma unroll
+        for (int k = 0; k < XCS_SLICES; ++k) base[k] = out.ptr[k][j];
+        for (uint64_t p0 = s; p0 < e; p0 += WAVE) {
+            const uint64_t p = p0 + lane;
+            const bool valid = p < e;
+            const IDX c = valid ? indices[p] : (IDX)0;
+            const double v = valid ? data[p] : 0.0;
+            const uint32_t sl = valid ? x_slice((uint64_t)c) : XCS_SLICES;
+#pragma unroll
+            for (int k = 0; k < XCS_SLICES; ++k) {
+                const unsigned long long m = __ballot(sl == (uint32_t)k);
+                if (sl == (uint32_t)k) {
+                    const uint64_t pos = base[k] + (uint64_t)__popcll(m & below);
+                    ((IDX *)out.indices[k])[pos] = c;
+                    out.data[k][pos] = v;
+                }
+                base[k] += (uint64_t)__popcll(m);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static int32_t ensure_plan(sprs_hip_csmat *a, uint32_t T, hipStream_t stream, double **carry_out) {
-    std::lock_guard<std::mutex> lock(a->mu);
-    SpmvPlan &pl = a->plan;
-    if (pl.tile != T) {
-        pl.release();
-        pl.tile = T;
-        pl.ntiles = (a->nnz + T - 1) / T;
-        if (pl.ntiles) {
-            SPRS_TRY_HIP(hipMalloc((void **)&pl.tile_row, (pl.ntiles + 1) * sizeof(uint64_t)));
-            const uint64_t n = pl.ntiles + 1;
-            const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-            if (a->iptr_bytes == 8)
-                hipLaunchKernelGGL(build_tile_rows<uint64_t>, grid, block, 0, stream, (const uint64_t *)a->indptr,
-                                   a->rows, pl.ntiles, T, pl.tile_row);
-            else
-                hipLaunchKernelGGL(build_tile_rows<uint32_t>, grid, block, 0, stream, (const uint32_t *)a->indptr,
-                                   a->rows, pl.ntiles, T, pl.tile_row);
-            SPRS_TRY_HIP(hipGetLastError());
-            // other streams may use the plan next: make it globally visible once
-            SPRS_TRY_HIP(hipStreamSynchronize(stream));
-        }
+struct TmpBuf {
+    void *p = nullptr;
+    ~TmpBuf() {
+        if (p) (void)hipFree(p);
     }
-    *carry_out = nullptr;
-    if (pl.ntiles) {
-        auto it = pl.carry.find((void *)stream);
-        if (it == pl.carry.end()) {
-            double *c = nullptr;
-            SPRS_TRY_HIP(hipMalloc((void **)&c, pl.ntiles * sizeof(double)));
-            it = pl.carry.emplace((void *)stream, c).first;
-        }
-        *carry_out = it->second;
-    }
+    hipError_t alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    uint64_t *u64() { return (uint64_t *)p; }
+};
+
+template <typename PTR>
+static int32_t make_tile_rows(CsrPiece &pc, hipStream_t stream) {
+    pc.ntiles = (pc.nnz + TILE - 1) / TILE;
+    if (!pc.ntiles) return SPRS_HIP_OK;
+    if (pc.ntiles * XCS_SLICES > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many tiles for one launch");
+    SPRS_TRY_HIP(hipMalloc((void **)&pc.tile_row, (pc.ntiles + 1) * sizeof(uint64_t)));
+    const uint64_t n = pc.ntiles + 1;
+    hipLaunchKernelGGL(build_tile_rows<PTR>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       (const PTR *)pc.indptr, pc.rows, pc.ntiles, pc.tile_row);
+    SPRS_TRY_HIP(hipGetLastError());
     return SPRS_HIP_OK;
 }
 
-template <typename IDX, typename PTR, int T>
-static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool acc, bool nt, double *carry,
-                            hipStream_t stream) {
-    const SpmvPlan &pl = a->plan;
-    if (pl.ntiles > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many tiles for one launch");
-    const dim3 grid((unsigned)pl.ntiles), block(BLOCK);
-    const IDX *ix = (const IDX *)a->indices;
+template <typename IDX, typename PTR>
+static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
+    SpmvPlan &pl = a->plan;
+    const Options &o = options();
+    pl.release();
+    pl.opt_xcs = o.spmv_xcs;
+    pl.opt_split = o.spmv_xcs_split;
+    const uint64_t rows = a->rows, nnz = a->nnz;
     const PTR *ip = (const PTR *)a->indptr;
-#define SPRS_LAUNCH(ACC_, NT_, XL_)                                                                              \
-    hipLaunchKernelGGL((spmv_tile_kernel<IDX, PTR, T, ACC_, NT_, XL_>), grid, block, 0, stream, ip, ix, a->data, x, y, \
-                       pl.tile_row, carry, a->nnz, pl.ntiles, (uint64_t)options().spmv_xmask)
-#define SPRS_LAUNCH_XL(ACC_, NT_)                 \
-    do {                                          \
-        if (xl == 2) SPRS_LAUNCH(ACC_, NT_, 2);   \
-        else if (xl == 1) SPRS_LAUNCH(ACC_, NT_, 1); \
-        else SPRS_LAUNCH(ACC_, NT_, 0);           \
-    } while (0)
-    const int xl = (int)options().spmv_xload;
-    if (acc) {
-        if (nt) SPRS_LAUNCH_XL(true, true);
-        else SPRS_LAUNCH_XL(true, false);
-    } else {
-        if (nt) SPRS_LAUNCH_XL(false, true);
-        else SPRS_LAUNCH_XL(false, false);
-    }
-#undef SPRS_LAUNCH_XL
-#undef SPRS_LAUNCH
-    SPRS_TRY_HIP(hipGetLastError());
-    if (pl.ntiles > 1) {
-        const dim3 g2((unsigned)((pl.ntiles + 255) / 256)), b2(256);
-        hipLaunchKernelGGL(spmv_carry_kernel<PTR>, g2, b2, 0, stream, ip, pl.tile_row, carry, y, pl.ntiles,
-                           (uint32_t)T);
+    const IDX *ix = (const IDX *)a->indices;
+
+    // auto: worth it only when x is much larger than one L2 and the matrix is big enough to amortise
+    bool want = o.spmv_xcs == 1 || (o.spmv_xcs == 0 && a->cols * 8 >= (4ull << 20) && nnz >= (1ull << 22));
+    TmpBuf short_len, long_flag, short_ptr, long_pos;
+    uint64_t nnz_short = 0, n_long = 0;
+    if (want) {
+        SPRS_TRY_HIP(short_len.alloc(rows * 8));
+        SPRS_TRY_HIP(long_flag.alloc(rows * 8));
+        SPRS_TRY_HIP(short_ptr.alloc((rows + 1) * 8));
+        SPRS_TRY_HIP(long_pos.alloc((rows + 1) * 8));
+        hipLaunchKernelGGL(xcs_classify_kernel<PTR>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ip,
+                           rows, (uint64_t)o.spmv_xcs_split, short_len.u64(), long_flag.u64());
         SPRS_TRY_HIP(hipGetLastError());
+        SPRS_TRY(exclusive_scan_u64(short_len.u64(), short_ptr.u64(), rows, stream));
+        SPRS_TRY(exclusive_scan_u64(long_flag.u64(), long_pos.u64(), rows, stream));
+        SPRS_TRY_HIP(hipMemcpy(&nnz_short, short_ptr.u64() + rows, 8, hipMemcpyDeviceToHost));
+        SPRS_TRY_HIP(hipMemcpy(&n_long, long_pos.u64() + rows, 8, hipMemcpyDeviceToHost));
+        // auto mode: slice only if the long rows carry most of the entries
+        if (n_long == 0 || (o.spmv_xcs == 0 && (nnz - nnz_short) * 2 < nnz)) want = false;
     }
+
+    if (!want) {
+        pl.main.indptr = a->indptr;
+        pl.main.indices = a->indices;
+        pl.main.data = a->data;
+        pl.main.rows = rows;
+        pl.main.nnz = nnz;
+        pl.main.owns = false;
+        SPRS_TRY(make_tile_rows<PTR>(pl.main, stream));
+        SPRS_TRY_HIP(hipStreamSynchronize(stream));
+        pl.built = true;
+        return SPRS_HIP_OK;
+    }
+
+    // ---- short part + list of long rows --------------------------------------
+    pl.xcs = true;
+    pl.n_long = n_long;
+    pl.main.rows = rows;
+    pl.main.nnz = nnz_short;
+    pl.main.owns = true;
+    SPRS_TRY_HIP(hipMalloc(&pl.main.indptr, (rows + 1) * sizeof(PTR)));
+    SPRS_TRY_HIP(hipMalloc(&pl.main.indices, (nnz_short ? nnz_short : 2) * sizeof(IDX)));
+    SPRS_TRY_HIP(hipMalloc((void **)&pl.main.data, (nnz_short ? nnz_short : 2) * sizeof(double)));
+    SPRS_TRY_HIP(hipMalloc((void **)&pl.long_rows, n_long * sizeof(uint64_t)));
+    hipLaunchKernelGGL((xcs_fill_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
+                       a->data, rows, long_flag.u64(), short_ptr.u64(), long_pos.u64(), (PTR *)pl.main.indptr,
+                       (IDX *)pl.main.indices, pl.main.data, pl.long_rows);
+    SPRS_TRY_HIP(hipGetLastError());
+
+    // ---- long part: count, scan, scatter ------------------------------------------
+    TmpBuf cnt;
+    SPRS_TRY_HIP(cnt.alloc(XCS_SLICES * n_long * 8));
+    uint64_t wblocks = (n_long + NWAVES - 1) / NWAVES;
+    if (wblocks > 256 * 64) wblocks = 256 * 64;
+    hipLaunchKernelGGL((xcs_count_kernel<IDX, PTR>), dim3((unsigned)wblocks), dim3(BLOCK), 0, stream, ip, ix,
+                       pl.long_rows, n_long, cnt.u64());
+    SPRS_TRY_HIP(hipGetLastError());
+    SliceOut so;
+    for (int s = 0; s < XCS_SLICES; ++s) {
+        CsrPiece &sl = pl.slice[s];
+        sl.rows = n_long;
+        sl.owns = true;
+        SPRS_TRY_HIP(hipMalloc(&sl.indptr, (n_long + 1) * sizeof(uint64_t)));
+        SPRS_TRY(exclusive_scan_u64(cnt.u64() + (uint64_t)s * n_long, (uint64_t *)sl.indptr, n_long, stream));
+        SPRS_TRY_HIP(hipMemcpy(&sl.nnz, (uint64_t *)sl.indptr + n_long, 8, hipMemcpyDeviceToHost));
+        SPRS_TRY_HIP(hipMalloc(&sl.indices, (sl.nnz ? sl.nnz : 2) * sizeof(IDX)));
+        SPRS_TRY_HIP(hipMalloc((void **)&sl.data, (sl.nnz ? sl.nnz : 2) * sizeof(double)));
+        so.ptr[s] = (const uint64_t *)sl.indptr;
+        so.indices[s] = sl.indices;
+        so.data[s] = sl.data;
+    }
+    hipLaunchKernelGGL((xcs_scatter_kernel<IDX, PTR>), dim3((unsigned)wblocks), dim3(BLOCK), 0, stream, ip, ix, a->data,
+                       pl.long_rows, n_long, so);
+    SPRS_TRY_HIP(hipGetLastError());
+
+    SPRS_TRY(make_tile_rows<PTR>(pl.main, stream));
+    pl.slice_tile_off[0] = 0;
+    for (int s = 0; s < XCS_SLICES; ++s) {
+        SPRS_TRY(make_tile_rows<uint64_t>(pl.slice[s], stream));
+        pl.slice_tile_off[s + 1] = pl.slice_tile_off[s] + pl.slice[s].ntiles;
+    }
+    SPRS_TRY_HIP(hipStreamSynchronize(stream));   // plan complete and visible to every stream
+    pl.built = true;
+    return SPRS_HIP_OK;
+}
+
+static int32_t get_scratch(SpmvPlan &pl, hipStream_t stream, SpmvScratch **out) {
+    auto it = pl.scratch.find((void *)stream);
+    if (it == pl.scratch.end()) {
+        SpmvScratch sc;
+        if (pl.main.ntiles) SPRS_TRY_HIP(hipMalloc((void **)&sc.carry_main, pl.main.ntiles * sizeof(double)));
+        if (pl.xcs) {
+            const uint64_t nt = pl.slice_tile_off[XCS_SLICES];
+            SPRS_TRY_HIP(hipMalloc((void **)&sc.carry_slices, (nt ? nt : 1) * sizeof(double)));
+            // partials, followed by the device copy of the per-slice argument table
+            const uint64_t pbytes = XCS_SLICES * pl.n_long * sizeof(double);
+            const uint64_t poff = (pbytes + 255) & ~255ull;
+            SPRS_TRY_HIP(hipMalloc((void **)&sc.partial, poff + sizeof(SlicedArgs)));
+            SlicedArgs sa;
+            for (int s = 0; s < XCS_SLICES; ++s) {
+                const CsrPiece &sl = pl.slice[s];
+                sa.p[s] = TileArgs{sl.indptr, sl.indices, sl.data, sl.tile_row, sc.carry_slices + pl.slice_tile_off[s],
+                                   sc.partial + (uint64_t)s * pl.n_long, sl.nnz, sl.ntiles};
+            }
+            SPRS_TRY_HIP(hipMemcpy((uint8_t *)sc.partial + poff, &sa, sizeof sa, hipMemcpyHostToDevice));
+        }
+        it = pl.scratch.emplace((void *)stream, sc).first;
+    }
+    *out = &it->second;
+    return SPRS_HIP_OK;
+}
+
+template <typename IDX, typename PTR>
+static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool acc, hipStream_t stream) {
+    const Options &o = options();
+    SpmvScratch *sc = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(a->mu);
+        SpmvPlan &pl = a->plan;
+        if (!pl.built || pl.opt_xcs != o.spmv_xcs || pl.opt_split != o.spmv_xcs_split)
+            SPRS_TRY((build_plan<IDX, PTR>(a, stream)));
+        SPRS_TRY(get_scratch(pl, stream, &sc));
+    }
+    const SpmvPlan &pl = a->plan;
+    const uint64_t xmask = (uint64_t)o.spmv_xmask;
+
+    // piece 1: the whole matrix, or its short rows
+    if (pl.main.ntiles) {
+        const TileArgs ta{pl.main.indptr, pl.main.indices, pl.main.data, pl.main.tile_row, sc->carry_main, y,
+                          pl.main.nnz,    pl.main.ntiles};
+        const dim3 grid((unsigned)pl.main.ntiles), block(BLOCK);
+        if (acc) hipLaunchKernelGGL((spmv_tile_kernel<IDX, PTR, true>), grid, block, 0, stream, ta, x, xmask);
+        else hipLaunchKernelGGL((spmv_tile_kernel<IDX, PTR, false>), grid, block, 0, stream, ta, x, xmask);
+        SPRS_TRY_HIP(hipGetLastError());
+        if (pl.main.ntiles > 1) {
+            hipLaunchKernelGGL(spmv_carry_kernel<PTR>, dim3((unsigned)((pl.main.ntiles + 255) / 256)), dim3(256), 0,
+                               stream, ta);
+            SPRS_TRY_HIP(hipGetLastError());
+        }
+    } else if (!acc) {
+        SPRS_TRY_HIP(hipMemsetAsync(y, 0, a->rows * sizeof(double), stream));   // only long rows will be written
+    }
+    if (!pl.xcs) return SPRS_HIP_OK;
+
+    // piece 2: the long rows, slice s on XCD s
+    uint64_t max_tiles = 0;
+    for (int s = 0; s < XCS_SLICES; ++s)
+        if (pl.slice[s].ntiles > max_tiles) max_tiles = pl.slice[s].ntiles;
+    const uint64_t pbytes = XCS_SLICES * pl.n_long * sizeof(double);
+    const SlicedArgs *sa = (const SlicedArgs *)((uint8_t *)sc->partial + ((pbytes + 255) & ~255ull));
+    if (max_tiles) {
+        hipLaunchKernelGGL((spmv_sliced_kernel<IDX>), dim3((unsigned)(max_tiles * XCS_SLICES)), dim3(BLOCK), 0, stream,
+                           sa, x, xmask);
+        SPRS_TRY_HIP(hipGetLastError());
+        if (max_tiles > 1) {
+            hipLaunchKernelGGL(spmv_sliced_carry_kernel, dim3((unsigned)((max_tiles + 255) / 256), XCS_SLICES),
+                               dim3(256), 0, stream, sa);
+            SPRS_TRY_HIP(hipGetLastError());
+        }
+    }
+    const dim3 rg((unsigned)((pl.n_long + 255) / 256)), rb(256);
+    if (acc) hipLaunchKernelGGL(xcs_reduce_kernel<true>, rg, rb, 0, stream, sc->partial, pl.long_rows, y, pl.n_long);
+    else hipLaunchKernelGGL(xcs_reduce_kernel<false>, rg, rb, 0, stream, sc->partial, pl.long_rows, y, pl.n_long);
+    SPRS_TRY_HIP(hipGetLastError());
     return SPRS_HIP_OK;
 }
 
@@ -354,14 +643,8 @@ static int32_t launch_rowwave(sprs_hip_csmat *a, const double *x, double *y, boo
 
 template <typename IDX, typename PTR>
 static int32_t dispatch(sprs_hip_csmat *a, const double *x, double *y, bool acc, hipStream_t stream) {
-    const Options &o = options();
-    if (o.spmv_kernel == 2) return launch_rowwave<IDX, PTR>(a, x, y, acc, stream);
-    const uint32_t T = (uint32_t)o.spmv_tile;
-    double *carry = nullptr;
-    SPRS_TRY(ensure_plan(a, T, stream, &carry));
-    const bool nt = o.spmv_nt != 0;
-    if (T == 2048) return launch_tiled<IDX, PTR, 2048>(a, x, y, acc, nt, carry, stream);
-    return launch_tiled<IDX, PTR, 4096>(a, x, y, acc, nt, carry, stream);
+    if (options().spmv_kernel == 2) return launch_rowwave<IDX, PTR>(a, x, y, acc, stream);
+    return launch_tiled<IDX, PTR>(a, x, y, acc, stream);
 }
 
 int32_t spmv_f64(sprs_hip_csmat *a, const double *x, double *y, bool accumulate, hipStream_t stream) {

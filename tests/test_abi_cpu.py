@@ -41,12 +41,12 @@ def test_status_codes_match_header():
 def test_version_and_options():
     import sprs_amd
     assert "gfx950" in sprs_amd.version()
-    assert sprs_amd.get_option("spmv_tile") in (2048, 4096)
+    assert sprs_amd.get_option("spmv_xcs") == 0 and sprs_amd.get_option("spmv_xcs_split") >= 2
     with pytest.raises(sprs_amd.SprsHipError) as e:
         sprs_amd.set_option("no_such_option", 1)
     assert e.value.status == sprs_amd._ffi.INVALID_ARG and "no_such_option" in str(e.value)
     with pytest.raises(sprs_amd.SprsHipError):
-        sprs_amd.set_option("spmv_tile", 1000)
+        sprs_amd.set_option("spmv_xcs", 7)
 
 
 def test_argument_checks_need_no_device():

@@ -66,12 +66,12 @@ def test_config1_eye_1000(hip):
     assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("tile", [2048, 4096])
+@pytest.mark.parametrize("xcs", [1, 2], ids=["xcd-sliced", "plain"])
 @pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
-def test_rmat_vs_oracle(hip, idx, ptr, tile):
+def test_rmat_vs_oracle(hip, idx, ptr, xcs):
     import torch
     from sprs_amd import gen
-    hip.set_option("spmv_tile", tile)
+    hip.set_option("spmv_xcs", xcs)       # 1: force the XCD-sliced plan, 2: plain tile kernel only
     try:
         n = 60000
         indptr, indices, data = gen.rmat_csr(n, 16)
@@ -89,7 +89,7 @@ def test_rmat_vs_oracle(hip, idx, ptr, tile):
         assert rel_err(y2, ref2) <= TOL
         assert np.array_equal(y2[empty], y0[empty])     # empty rows untouched, bit for bit
     finally:
-        hip.set_option("spmv_tile", 4096)
+        hip.set_option("spmv_xcs", 0)
 
 
 def test_laplacian_componentwise_bound(hip):
@@ -133,8 +133,9 @@ def test_ragged_rows(hip, lens, kernel):
         shape, ip, ix, dt = ragged_csr(lens, cols, seed=len(lens))
         rng = np.random.default_rng(1)
         x = rng.random(cols) + 0.5
-        for tile in (2048, 4096):
-            hip.set_option("spmv_tile", tile)
+        for xcs, split in ((2, 64), (1, 64), (1, 2), (1, 5000)):
+            hip.set_option("spmv_xcs", xcs)
+            hip.set_option("spmv_xcs_split", split)
             y = gpu_spmv(hip, shape, ip, ix, dt, x)
             ref = oracle_spmv(shape, ip, ix, dt, x)
             assert rel_err(y, ref) <= TOL
@@ -145,7 +146,8 @@ def test_ragged_rows(hip, lens, kernel):
             assert np.array_equal(y2[lens_a == 0], y0[lens_a == 0])
     finally:
         hip.set_option("spmv_kernel", 0)
-        hip.set_option("spmv_tile", 4096)
+        hip.set_option("spmv_xcs", 0)
+        hip.set_option("spmv_xcs_split", 64)
 
 
 def test_zero_sized(hip):
@@ -216,8 +218,13 @@ def test_run_to_run_deterministic(hip):
     indptr, indices, data = gen.rmat_csr(n, 20, seed=11)
     ip, ix, dt = indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy()
     x = gen.dense_vector(n).numpy()
-    ys = [gpu_spmv(hip, (n, n), ip, ix, dt, x) for _ in range(3)]
-    assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
+    for xcs in (1, 2):
+        hip.set_option("spmv_xcs", xcs)
+        try:
+            ys = [gpu_spmv(hip, (n, n), ip, ix, dt, x) for _ in range(3)]
+        finally:
+            hip.set_option("spmv_xcs", 0)
+        assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
 
 
 def test_stored_zeros_and_nonfinite(hip):
@@ -259,12 +266,13 @@ def test_full_size_properties_config2(hip):
     rowsum.index_add_(0, rows, data)
     got = mul(ones)
     assert float(((got - rowsum).abs() / rowsum.abs().clamp_min(1e-300)).max()) <= TOL
-    hip.set_option("spmv_kernel", 2)
-    try:
-        other = mul(x)
-    finally:
-        hip.set_option("spmv_kernel", 0)
-    assert float(((other - ax).abs() / ax.abs().clamp_min(1e-300)).max()) <= TOL
+    for opt, val in (("spmv_kernel", 2), ("spmv_xcs", 2), ("spmv_xcs", 1)):
+        hip.set_option(opt, val)
+        try:
+            other = mul(x)
+        finally:
+            hip.set_option(opt, 0)
+        assert float(((other - ax).abs() / ax.abs().clamp_min(1e-300)).max()) <= TOL
     # and a 20k-row block against the oracle
     from oracle import oracle
     r0, r1 = 400000, 420000
