@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=None, help="spmv_kernel option for A/B (1 tiled, 2 wave-per-row)")
     ap.add_argument("--xcs", type=int, default=None, help="XCD-sliced plan: 0 auto, 1 on, 2 off")
     ap.add_argument("--split", type=int, default=None, help="row-length threshold of the sliced part")
+    ap.add_argument("--idx32", type=int, default=None, help="plan copies with 32-bit column ids: 1 on (default), 0 off")
+    ap.add_argument("--tile", type=int, default=None, help="nnz per workgroup tile: 2048 or 4096")
     ap.add_argument("--xmask", type=int, default=None, help="timing experiment only: gather x[col & mask]")
     args = ap.parse_args()
 
@@ -71,7 +73,7 @@ def main():
     from sprs_amd import _ffi
     import ctypes as C
     _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
-    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xmask", args.xmask)):
+    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_tile", args.tile), ("spmv_xmask", args.xmask)):
         if val is not None:
             sprs_amd.set_option(opt, val)
 

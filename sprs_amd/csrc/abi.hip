@@ -450,6 +450,11 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "spmv_xcs_split")) {
         if (value < 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_xcs_split must be >= 2");
         o.spmv_xcs_split = value;
+    } else if (!strcmp(name, "spmv_xcs_idx32")) {
+        o.spmv_xcs_idx32 = value ? 1 : 0;
+    } else if (!strcmp(name, "spmv_tile")) {
+        if (value != 0 && value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 0 (auto), 2048 or 4096");
+        o.spmv_tile = value;
     } else if (!strcmp(name, "spmv_xmask")) {
         o.spmv_xmask = value;
     } else {
@@ -465,6 +470,8 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     if (!strcmp(name, "spmv_kernel")) *value = o.spmv_kernel;
     else if (!strcmp(name, "spmv_xcs")) *value = o.spmv_xcs;
     else if (!strcmp(name, "spmv_xcs_split")) *value = o.spmv_xcs_split;
+    else if (!strcmp(name, "spmv_xcs_idx32")) *value = o.spmv_xcs_idx32;
+    else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
     else if (!strcmp(name, "spmv_xmask")) *value = o.spmv_xmask;
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;

@@ -40,7 +40,9 @@ void clear_error();
 struct Options {
     int64_t spmv_kernel = 0;       // 0 auto, 1 nnz-tiled, 2 wave-per-row (A/B only)
     int64_t spmv_xcs = 0;          // XCD-sliced plan for long rows: 0 auto, 1 force on, 2 off
-    int64_t spmv_xcs_split = 64;   // rows with >= this many entries go to the sliced part
+    int64_t spmv_xcs_split = 32;   // rows with >= this many entries go to the sliced part
+    int64_t spmv_xcs_idx32 = 1;    // plan-owned copies store 32-bit column ids when cols < 2^32
+    int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
     int64_t spmv_xmask = -1;       // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
 };
 Options &options();
@@ -67,7 +69,9 @@ struct SpmvScratch {               // per stream: nothing in here is shared betw
 struct SpmvPlan {
     bool built = false;
     bool xcs = false;
-    int64_t opt_xcs = -1, opt_split = -1;   // option values the plan was built with
+    int64_t opt_xcs = -1, opt_split = -1, opt_idx32 = -1, opt_tile = -1;   // option values the plan was built with
+    uint32_t tile = 0;             // nnz per tile
+    int idx_bytes = 8;             // width of the column ids the kernels read (handle's, or 4 for plan copies)
     CsrPiece main;                 // the whole matrix (plain plan) or its short rows (sliced plan)
     CsrPiece slice[XCS_SLICES];    // long rows, entries whose x line hashes to s, rows = n_long
     uint64_t slice_tile_off[XCS_SLICES + 1] = {0};

@@ -43,7 +43,6 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 constexpr int BLOCK = 256;       // 4 waves
 constexpr int WAVE = 64;
 constexpr int NWAVES = BLOCK / WAVE;
-constexpr int TILE = 4096;       // nnz per workgroup: 64 KiB of matrix stream in flight per workgroup
 constexpr int SEG_CHUNK = 2048;  // row boundaries staged per pass
 constexpr uint32_t LONG_SEG = 64;
 
@@ -80,7 +79,7 @@ __device__ __forceinline__ uint64_t tile_of_block(uint64_t bid, uint64_t ntiles)
 //       tile_row[ntiles] = rows
 // ---------------------------------------------------------------------------
 template <typename PTR>
-__global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, uint64_t ntiles,
+__global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, uint64_t ntiles, uint32_t TILE,
                                 uint64_t *__restrict__ tile_row) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c > ntiles) return;
@@ -101,7 +100,7 @@ __global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, u
 // ---------------------------------------------------------------------------
 // one workgroup, one nnz tile
 // ---------------------------------------------------------------------------
-template <typename IDX, typename PTR, bool ACC>
+template <typename IDX, typename PTR, bool ACC, int TILE>
 __device__ __forceinline__ void tile_body(const TileArgs &a, const double *__restrict__ x, uint64_t tile,
                                           uint64_t xmask) {
     constexpr int V = 2;                          // elements per lane per pass (16 B of data)
@@ -225,21 +224,21 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, const double *__res
     }
 }
 
-template <typename IDX, typename PTR, bool ACC>
+template <typename IDX, typename PTR, bool ACC, int TILE>
 __global__ __launch_bounds__(BLOCK) void spmv_tile_kernel(TileArgs a, const double *__restrict__ x, uint64_t xmask) {
-    tile_body<IDX, PTR, ACC>(a, x, tile_of_block(blockIdx.x, a.ntiles), xmask);
+    tile_body<IDX, PTR, ACC, TILE>(a, x, tile_of_block(blockIdx.x, a.ntiles), xmask);
 }
 
 // Sliced launch: workgroup b works on slice b % 8 — the dispatcher places block b on
 // XCD b % 8, so slice s's x lines live in ONE L2.  (Placement only affects speed.)
-template <typename IDX>
+template <typename IDX, int TILE>
 __global__ __launch_bounds__(BLOCK) void spmv_sliced_kernel(const SlicedArgs *__restrict__ sa,
                                                             const double *__restrict__ x, uint64_t xmask) {
     const uint32_t s = blockIdx.x & (XCS_SLICES - 1);
     const uint64_t tile = blockIdx.x >> 3;
     const TileArgs a = sa->p[s];
     if (tile >= a.ntiles) return;
-    tile_body<IDX, uint64_t, false>(a, x, tile, xmask);
+    tile_body<IDX, uint64_t, false, TILE>(a, x, tile, xmask);
 }
 
 // ---------------------------------------------------------------------------
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void spmv_sliced_kernel(const SlicedArgs *__
 // added in tile order (deterministic).  One thread per tile.
 // ---------------------------------------------------------------------------
 template <typename PTR>
-__device__ __forceinline__ void carry_body(const TileArgs &a, uint64_t c) {
+__device__ __forceinline__ void carry_body(const TileArgs &a, uint64_t c, uint32_t TILE) {
     if (c + 1 >= a.ntiles) return;
     const uint64_t R0 = a.tile_row[c], R1 = a.tile_row[c + 1];
     if (R1 == R0) return;                                                        // no row starts in tile c
@@ -258,13 +257,13 @@ __device__ __forceinline__ void carry_body(const TileArgs &a, uint64_t c) {
 }
 
 template <typename PTR>
-__global__ void spmv_carry_kernel(TileArgs a) {
-    carry_body<PTR>(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+__global__ void spmv_carry_kernel(TileArgs a, uint32_t TILE) {
+    carry_body<PTR>(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, TILE);
 }
 
-__global__ void spmv_sliced_carry_kernel(const SlicedArgs *__restrict__ sa) {
+__global__ void spmv_sliced_carry_kernel(const SlicedArgs *__restrict__ sa, uint32_t TILE) {
     const TileArgs a = sa->p[blockIdx.y];
-    carry_body<uint64_t>(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    carry_body<uint64_t>(a, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, TILE);
 }
 
 // y[long_rows[j]] (+)= sum over slices, in slice order
@@ -323,11 +322,11 @@ __global__ void xcs_classify_kernel(const PTR *__restrict__ indptr, uint64_t row
 }
 
 // short rows: copied into their own CSR piece (long rows become empty rows of it)
-template <typename IDX, typename PTR>
+template <typename IDX, typename PTR, typename CIDX>
 __global__ void xcs_fill_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
                                 const double *__restrict__ data, uint64_t rows, const uint64_t *__restrict__ long_flag,
                                 const uint64_t *__restrict__ short_ptr, const uint64_t *__restrict__ long_pos,
-                                PTR *__restrict__ s_indptr, IDX *__restrict__ s_indices, double *__restrict__ s_data,
+                                PTR *__restrict__ s_indptr, CIDX *__restrict__ s_indices, double *__restrict__ s_data,
                                 uint64_t *__restrict__ long_rows) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > rows) return;
@@ -340,7 +339,7 @@ __global__ void xcs_fill_kernel(const PTR *__restrict__ indptr, const IDX *__res
     const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
     uint64_t d = short_ptr[r];
     for (uint64_t p = s; p < e; ++p, ++d) {
-        s_indices[d] = indices[p];
+        s_indices[d] = (CIDX)indices[p];
         s_data[d] = data[p];
     }
 }
@@ -388,7 +387,7 @@ struct SliceOut {
 };
 
 // stable partition of every long row into its 8 slices (column order kept)
-template <typename IDX, typename PTR>
+template <typename IDX, typename PTR, typename CIDX>
 __global__ __launch_bounds__(BLOCK) void xcs_scatter_kernel(const PTR *__restrict__ indptr,
                                                             const IDX *__restrict__ indices,
                                                             const double *__restrict__ data,
@@ -415,7 +414,7 @@ __global__ __launch_bounds__(BLOCK) void xcs_scatter_kernel(const PTR *__restric
                 const unsigned long long m = __ballot(sl == (uint32_t)k);
                 if (sl == (uint32_t)k) {
                     const uint64_t pos = base[k] + (uint64_t)__popcll(m & below);
-                    ((IDX *)out.indices[k])[pos] = c;
+                    ((CIDX *)out.indices[k])[pos] = (CIDX)c;
                     out.data[k][pos] = v;
                 }
                 base[k] += (uint64_t)__popcll(m);
@@ -437,75 +436,40 @@ struct TmpBuf {
 };
 
 template <typename PTR>
-static int32_t make_tile_rows(CsrPiece &pc, hipStream_t stream) {
+static int32_t make_tile_rows(CsrPiece &pc, uint32_t TILE, hipStream_t stream) {
     pc.ntiles = (pc.nnz + TILE - 1) / TILE;
     if (!pc.ntiles) return SPRS_HIP_OK;
     if (pc.ntiles * XCS_SLICES > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many tiles for one launch");
     SPRS_TRY_HIP(hipMalloc((void **)&pc.tile_row, (pc.ntiles + 1) * sizeof(uint64_t)));
     const uint64_t n = pc.ntiles + 1;
     hipLaunchKernelGGL(build_tile_rows<PTR>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                       (const PTR *)pc.indptr, pc.rows, pc.ntiles, pc.tile_row);
+                       (const PTR *)pc.indptr, pc.rows, pc.ntiles, TILE, pc.tile_row);
     SPRS_TRY_HIP(hipGetLastError());
     return SPRS_HIP_OK;
 }
 
-template <typename IDX, typename PTR>
-static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
+// re-layout of the long rows / short rows into plan-owned pieces whose column ids are CIDX
+template <typename IDX, typename PTR, typename CIDX>
+static int32_t build_sliced(sprs_hip_csmat *a, uint64_t nnz_short, uint64_t n_long, TmpBuf &long_flag,
+                            TmpBuf &short_ptr, TmpBuf &long_pos, hipStream_t stream) {
     SpmvPlan &pl = a->plan;
-    const Options &o = options();
-    pl.release();
-    pl.opt_xcs = o.spmv_xcs;
-    pl.opt_split = o.spmv_xcs_split;
-    const uint64_t rows = a->rows, nnz = a->nnz;
+    const uint64_t rows = a->rows;
     const PTR *ip = (const PTR *)a->indptr;
     const IDX *ix = (const IDX *)a->indices;
-
-    // auto: worth it only when x is much larger than one L2 and the matrix is big enough to amortise
-    bool want = o.spmv_xcs == 1 || (o.spmv_xcs == 0 && a->cols * 8 >= (4ull << 20) && nnz >= (1ull << 22));
-    TmpBuf short_len, long_flag, short_ptr, long_pos;
-    uint64_t nnz_short = 0, n_long = 0;
-    if (want) {
-        SPRS_TRY_HIP(short_len.alloc(rows * 8));
-        SPRS_TRY_HIP(long_flag.alloc(rows * 8));
-        SPRS_TRY_HIP(short_ptr.alloc((rows + 1) * 8));
-        SPRS_TRY_HIP(long_pos.alloc((rows + 1) * 8));
-        hipLaunchKernelGGL(xcs_classify_kernel<PTR>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ip,
-                           rows, (uint64_t)o.spmv_xcs_split, short_len.u64(), long_flag.u64());
-        SPRS_TRY_HIP(hipGetLastError());
-        SPRS_TRY(exclusive_scan_u64(short_len.u64(), short_ptr.u64(), rows, stream));
-        SPRS_TRY(exclusive_scan_u64(long_flag.u64(), long_pos.u64(), rows, stream));
-        SPRS_TRY_HIP(hipMemcpy(&nnz_short, short_ptr.u64() + rows, 8, hipMemcpyDeviceToHost));
-        SPRS_TRY_HIP(hipMemcpy(&n_long, long_pos.u64() + rows, 8, hipMemcpyDeviceToHost));
-        // auto mode: slice only if the long rows carry most of the entries
-        if (n_long == 0 || (o.spmv_xcs == 0 && (nnz - nnz_short) * 2 < nnz)) want = false;
-    }
-
-    if (!want) {
-        pl.main.indptr = a->indptr;
-        pl.main.indices = a->indices;
-        pl.main.data = a->data;
-        pl.main.rows = rows;
-        pl.main.nnz = nnz;
-        pl.main.owns = false;
-        SPRS_TRY(make_tile_rows<PTR>(pl.main, stream));
-        SPRS_TRY_HIP(hipStreamSynchronize(stream));
-        pl.built = true;
-        return SPRS_HIP_OK;
-    }
-
     // ---- short part + list of long rows --------------------------------------
     pl.xcs = true;
     pl.n_long = n_long;
+    pl.idx_bytes = (int)sizeof(CIDX);
     pl.main.rows = rows;
     pl.main.nnz = nnz_short;
     pl.main.owns = true;
     SPRS_TRY_HIP(hipMalloc(&pl.main.indptr, (rows + 1) * sizeof(PTR)));
-    SPRS_TRY_HIP(hipMalloc(&pl.main.indices, (nnz_short ? nnz_short : 2) * sizeof(IDX)));
+    SPRS_TRY_HIP(hipMalloc(&pl.main.indices, (nnz_short ? nnz_short : 4) * sizeof(CIDX)));
     SPRS_TRY_HIP(hipMalloc((void **)&pl.main.data, (nnz_short ? nnz_short : 2) * sizeof(double)));
     SPRS_TRY_HIP(hipMalloc((void **)&pl.long_rows, n_long * sizeof(uint64_t)));
-    hipLaunchKernelGGL((xcs_fill_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
-                       a->data, rows, long_flag.u64(), short_ptr.u64(), long_pos.u64(), (PTR *)pl.main.indptr,
-                       (IDX *)pl.main.indices, pl.main.data, pl.long_rows);
+    hipLaunchKernelGGL((xcs_fill_kernel<IDX, PTR, CIDX>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream,
+                       ip, ix, a->data, rows, long_flag.u64(), short_ptr.u64(), long_pos.u64(), (PTR *)pl.main.indptr,
+                       (CIDX *)pl.main.indices, pl.main.data, pl.long_rows);
     SPRS_TRY_HIP(hipGetLastError());
 
     // ---- long part: count, scan, scatter ------------------------------------------
@@ -524,21 +488,75 @@ static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
         SPRS_TRY_HIP(hipMalloc(&sl.indptr, (n_long + 1) * sizeof(uint64_t)));
         SPRS_TRY(exclusive_scan_u64(cnt.u64() + (uint64_t)s * n_long, (uint64_t *)sl.indptr, n_long, stream));
         SPRS_TRY_HIP(hipMemcpy(&sl.nnz, (uint64_t *)sl.indptr + n_long, 8, hipMemcpyDeviceToHost));
-        SPRS_TRY_HIP(hipMalloc(&sl.indices, (sl.nnz ? sl.nnz : 2) * sizeof(IDX)));
+        SPRS_TRY_HIP(hipMalloc(&sl.indices, (sl.nnz ? sl.nnz : 4) * sizeof(CIDX)));
         SPRS_TRY_HIP(hipMalloc((void **)&sl.data, (sl.nnz ? sl.nnz : 2) * sizeof(double)));
         so.ptr[s] = (const uint64_t *)sl.indptr;
         so.indices[s] = sl.indices;
         so.data[s] = sl.data;
     }
-    hipLaunchKernelGGL((xcs_scatter_kernel<IDX, PTR>), dim3((unsigned)wblocks), dim3(BLOCK), 0, stream, ip, ix, a->data,
-                       pl.long_rows, n_long, so);
+    hipLaunchKernelGGL((xcs_scatter_kernel<IDX, PTR, CIDX>), dim3((unsigned)wblocks), dim3(BLOCK), 0, stream, ip, ix,
+                       a->data, pl.long_rows, n_long, so);
     SPRS_TRY_HIP(hipGetLastError());
 
-    SPRS_TRY(make_tile_rows<PTR>(pl.main, stream));
+    SPRS_TRY(make_tile_rows<PTR>(pl.main, pl.tile, stream));
     pl.slice_tile_off[0] = 0;
     for (int s = 0; s < XCS_SLICES; ++s) {
-        SPRS_TRY(make_tile_rows<uint64_t>(pl.slice[s], stream));
+        SPRS_TRY(make_tile_rows<uint64_t>(pl.slice[s], pl.tile, stream));
         pl.slice_tile_off[s + 1] = pl.slice_tile_off[s] + pl.slice[s].ntiles;
+    }
+    return SPRS_HIP_OK;
+}
+
+template <typename IDX, typename PTR>
+static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
+    SpmvPlan &pl = a->plan;
+    const Options &o = options();
+    pl.release();
+    pl.opt_xcs = o.spmv_xcs;
+    pl.opt_split = o.spmv_xcs_split;
+    pl.opt_idx32 = o.spmv_xcs_idx32;
+    pl.opt_tile = o.spmv_tile;
+    pl.idx_bytes = (int)sizeof(IDX);
+    const uint64_t rows = a->rows, nnz = a->nnz;
+    const PTR *ip = (const PTR *)a->indptr;
+
+    // auto: worth it only when x is much larger than one L2 and the matrix is big enough to amortise
+    bool want = o.spmv_xcs == 1 || (o.spmv_xcs == 0 && a->cols * 8 >= (16ull << 20) && nnz >= (1ull << 22));
+    TmpBuf short_len, long_flag, short_ptr, long_pos;
+    uint64_t nnz_short = 0, n_long = 0;
+    if (want) {
+        SPRS_TRY_HIP(short_len.alloc(rows * 8));
+        SPRS_TRY_HIP(long_flag.alloc(rows * 8));
+        SPRS_TRY_HIP(short_ptr.alloc((rows + 1) * 8));
+        SPRS_TRY_HIP(long_pos.alloc((rows + 1) * 8));
+        hipLaunchKernelGGL(xcs_classify_kernel<PTR>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ip,
+                           rows, (uint64_t)o.spmv_xcs_split, short_len.u64(), long_flag.u64());
+        SPRS_TRY_HIP(hipGetLastError());
+        SPRS_TRY(exclusive_scan_u64(short_len.u64(), short_ptr.u64(), rows, stream));
+        SPRS_TRY(exclusive_scan_u64(long_flag.u64(), long_pos.u64(), rows, stream));
+        SPRS_TRY_HIP(hipMemcpy(&nnz_short, short_ptr.u64() + rows, 8, hipMemcpyDeviceToHost));
+        SPRS_TRY_HIP(hipMemcpy(&n_long, long_pos.u64() + rows, 8, hipMemcpyDeviceToHost));
+        // auto mode: slice only if the long rows carry most of the entries
+        if (n_long == 0 || (o.spmv_xcs == 0 && (nnz - nnz_short) * 2 < nnz)) want = false;
+    }
+    // tile size: measured on MI355X (profiles/r01f_ab_log.txt) — 4096 for the sliced plan and for
+    // plain plans with long rows, 2048 (more workgroups in flight) when rows are short
+    if (o.spmv_tile) pl.tile = (uint32_t)o.spmv_tile;
+    else pl.tile = (want || nnz > 16 * rows) ? 4096u : 2048u;
+
+    if (!want) {
+        pl.main.indptr = a->indptr;
+        pl.main.indices = a->indices;
+        pl.main.data = a->data;
+        pl.main.rows = rows;
+        pl.main.nnz = nnz;
+        pl.main.owns = false;
+        SPRS_TRY(make_tile_rows<PTR>(pl.main, pl.tile, stream));
+    } else if (sizeof(IDX) == 8 && o.spmv_xcs_idx32 && a->cols <= 0xFFFFFFFFull) {
+        // the plan's own copies hold 32-bit column ids: 12 instead of 16 bytes of stream per entry
+        SPRS_TRY((build_sliced<IDX, PTR, uint32_t>(a, nnz_short, n_long, long_flag, short_ptr, long_pos, stream)));
+    } else {
+        SPRS_TRY((build_sliced<IDX, PTR, IDX>(a, nnz_short, n_long, long_flag, short_ptr, long_pos, stream)));
     }
     SPRS_TRY_HIP(hipStreamSynchronize(stream));   // plan complete and visible to every stream
     pl.built = true;
@@ -571,31 +589,23 @@ static int32_t get_scratch(SpmvPlan &pl, hipStream_t stream, SpmvScratch **out) 
     return SPRS_HIP_OK;
 }
 
-template <typename IDX, typename PTR>
-static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool acc, hipStream_t stream) {
-    const Options &o = options();
-    SpmvScratch *sc = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(a->mu);
-        SpmvPlan &pl = a->plan;
-        if (!pl.built || pl.opt_xcs != o.spmv_xcs || pl.opt_split != o.spmv_xcs_split)
-            SPRS_TRY((build_plan<IDX, PTR>(a, stream)));
-        SPRS_TRY(get_scratch(pl, stream, &sc));
-    }
+// CIDX: column-id type of the pieces the kernels read (the handle's, or uint32 for plan copies)
+template <typename CIDX, typename PTR, int TILE>
+static int32_t launch_pieces(sprs_hip_csmat *a, SpmvScratch *sc, const double *x, double *y, bool acc,
+                             hipStream_t stream) {
     const SpmvPlan &pl = a->plan;
-    const uint64_t xmask = (uint64_t)o.spmv_xmask;
-
+    const uint64_t xmask = (uint64_t)options().spmv_xmask;
     // piece 1: the whole matrix, or its short rows
     if (pl.main.ntiles) {
         const TileArgs ta{pl.main.indptr, pl.main.indices, pl.main.data, pl.main.tile_row, sc->carry_main, y,
                           pl.main.nnz,    pl.main.ntiles};
         const dim3 grid((unsigned)pl.main.ntiles), block(BLOCK);
-        if (acc) hipLaunchKernelGGL((spmv_tile_kernel<IDX, PTR, true>), grid, block, 0, stream, ta, x, xmask);
-        else hipLaunchKernelGGL((spmv_tile_kernel<IDX, PTR, false>), grid, block, 0, stream, ta, x, xmask);
+        if (acc) hipLaunchKernelGGL((spmv_tile_kernel<CIDX, PTR, true, TILE>), grid, block, 0, stream, ta, x, xmask);
+        else hipLaunchKernelGGL((spmv_tile_kernel<CIDX, PTR, false, TILE>), grid, block, 0, stream, ta, x, xmask);
         SPRS_TRY_HIP(hipGetLastError());
         if (pl.main.ntiles > 1) {
             hipLaunchKernelGGL(spmv_carry_kernel<PTR>, dim3((unsigned)((pl.main.ntiles + 255) / 256)), dim3(256), 0,
-                               stream, ta);
+                               stream, ta, (uint32_t)TILE);
             SPRS_TRY_HIP(hipGetLastError());
         }
     } else if (!acc) {
@@ -610,12 +620,12 @@ static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool 
     const uint64_t pbytes = XCS_SLICES * pl.n_long * sizeof(double);
     const SlicedArgs *sa = (const SlicedArgs *)((uint8_t *)sc->partial + ((pbytes + 255) & ~255ull));
     if (max_tiles) {
-        hipLaunchKernelGGL((spmv_sliced_kernel<IDX>), dim3((unsigned)(max_tiles * XCS_SLICES)), dim3(BLOCK), 0, stream,
-                           sa, x, xmask);
+        hipLaunchKernelGGL((spmv_sliced_kernel<CIDX, TILE>), dim3((unsigned)(max_tiles * XCS_SLICES)), dim3(BLOCK), 0,
+                           stream, sa, x, xmask);
         SPRS_TRY_HIP(hipGetLastError());
         if (max_tiles > 1) {
             hipLaunchKernelGGL(spmv_sliced_carry_kernel, dim3((unsigned)((max_tiles + 255) / 256), XCS_SLICES),
-                               dim3(256), 0, stream, sa);
+                               dim3(256), 0, stream, sa, (uint32_t)TILE);
             SPRS_TRY_HIP(hipGetLastError());
         }
     }
@@ -624,6 +634,28 @@ static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool 
     else hipLaunchKernelGGL(xcs_reduce_kernel<false>, rg, rb, 0, stream, sc->partial, pl.long_rows, y, pl.n_long);
     SPRS_TRY_HIP(hipGetLastError());
     return SPRS_HIP_OK;
+}
+
+template <typename IDX, typename PTR>
+static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool acc, hipStream_t stream) {
+    const Options &o = options();
+    SpmvScratch *sc = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(a->mu);
+        SpmvPlan &pl = a->plan;
+        if (!pl.built || pl.opt_xcs != o.spmv_xcs || pl.opt_split != o.spmv_xcs_split ||
+            pl.opt_idx32 != o.spmv_xcs_idx32 || pl.opt_tile != o.spmv_tile)
+            SPRS_TRY((build_plan<IDX, PTR>(a, stream)));
+        SPRS_TRY(get_scratch(pl, stream, &sc));
+    }
+    const SpmvPlan &pl = a->plan;
+    const bool small_idx = pl.idx_bytes == 4;
+    if (pl.tile == 2048) {
+        if (small_idx) return launch_pieces<uint32_t, PTR, 2048>(a, sc, x, y, acc, stream);
+        return launch_pieces<uint64_t, PTR, 2048>(a, sc, x, y, acc, stream);
+    }
+    if (small_idx) return launch_pieces<uint32_t, PTR, 4096>(a, sc, x, y, acc, stream);
+    return launch_pieces<uint64_t, PTR, 4096>(a, sc, x, y, acc, stream);
 }
 
 template <typename IDX, typename PTR>

@@ -66,12 +66,13 @@ def test_config1_eye_1000(hip):
     assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("xcs", [1, 2], ids=["xcd-sliced", "plain"])
+@pytest.mark.parametrize("xcs,idx32", [(1, 1), (1, 0), (2, 1)], ids=["xcd-sliced-idx32", "xcd-sliced", "plain"])
 @pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
-def test_rmat_vs_oracle(hip, idx, ptr, xcs):
+def test_rmat_vs_oracle(hip, idx, ptr, xcs, idx32):
     import torch
     from sprs_amd import gen
     hip.set_option("spmv_xcs", xcs)       # 1: force the XCD-sliced plan, 2: plain tile kernel only
+    hip.set_option("spmv_xcs_idx32", idx32)
     try:
         n = 60000
         indptr, indices, data = gen.rmat_csr(n, 16)
@@ -90,6 +91,7 @@ def test_rmat_vs_oracle(hip, idx, ptr, xcs):
         assert np.array_equal(y2[empty], y0[empty])     # empty rows untouched, bit for bit
     finally:
         hip.set_option("spmv_xcs", 0)
+        hip.set_option("spmv_xcs_idx32", 1)
 
 
 def test_laplacian_componentwise_bound(hip):
@@ -133,9 +135,12 @@ def test_ragged_rows(hip, lens, kernel):
         shape, ip, ix, dt = ragged_csr(lens, cols, seed=len(lens))
         rng = np.random.default_rng(1)
         x = rng.random(cols) + 0.5
-        for xcs, split in ((2, 64), (1, 64), (1, 2), (1, 5000)):
+        for xcs, split, idx32, tile in ((2, 64, 1, 4096), (1, 64, 1, 4096), (1, 2, 0, 2048), (1, 5000, 1, 2048),
+                                        (2, 64, 1, 2048)):
             hip.set_option("spmv_xcs", xcs)
             hip.set_option("spmv_xcs_split", split)
+            hip.set_option("spmv_xcs_idx32", idx32)
+            hip.set_option("spmv_tile", tile)
             y = gpu_spmv(hip, shape, ip, ix, dt, x)
             ref = oracle_spmv(shape, ip, ix, dt, x)
             assert rel_err(y, ref) <= TOL
@@ -147,7 +152,9 @@ def test_ragged_rows(hip, lens, kernel):
     finally:
         hip.set_option("spmv_kernel", 0)
         hip.set_option("spmv_xcs", 0)
-        hip.set_option("spmv_xcs_split", 64)
+        hip.set_option("spmv_xcs_split", 32)
+        hip.set_option("spmv_xcs_idx32", 1)
+        hip.set_option("spmv_tile", 0)
 
 
 def test_zero_sized(hip):
