@@ -110,6 +110,12 @@ int32_t sprs_hip_csmat_download(const sprs_hip_csmat *m, void *indptr, void *ind
 int32_t sprs_hip_csmat_download_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end,
                                       void *indptr_out, void *indices_out, double *data_out,
                                       uint64_t *nnz_out);
+/* slice_outer (slicing.rs:65-89) as a NEW owning handle: outer slices [start, end), indptr
+ * rebased (to_proper, indptr.rs:206-214).  The reference's view is zero-copy; the device twin
+ * materialises the slice (one D2D copy) so that it is a self-contained, 16-byte aligned matrix —
+ * this is how the multi-GPU path cuts row blocks. */
+int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end,
+                                   sprs_hip_csmat **out);
 /* transpose_view (csmat.rs:982-991): free, shares the buffers, flips storage + shape */
 int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **out);
 int32_t sprs_hip_csmat_free(sprs_hip_csmat *m);

@@ -437,6 +437,14 @@ int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat 
     return to_other_storage(m, out);
 }
 
+int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end, sprs_hip_csmat **out) {
+    clear_error();
+    if (!m || !out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    if (start > end || end > m->outer()) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "slice_outer range out of bounds");
+    return slice_outer(m, start, end, out);
+}
+
 int32_t sprs_hip_set_option(const char *name, int64_t value) {
     clear_error();
     if (!name) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL name");

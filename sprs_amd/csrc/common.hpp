@@ -109,7 +109,9 @@ namespace sprs_hip {
 int32_t spmv_f64(sprs_hip_csmat *a, const double *x, double *y, bool accumulate, hipStream_t stream);
 // spgemm.hip
 int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c);
+// convert.hip
 int32_t to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out);
+int32_t slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end, sprs_hip_csmat **out);
 // abi.hip
 int32_t alloc_csmat(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols, uint64_t nnz,
                     int32_t iptr_bytes, int32_t idx_bytes);

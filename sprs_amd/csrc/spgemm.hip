@@ -508,8 +508,4 @@ int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_cs
     return spgemm_impl<uint32_t, uint32_t>(a, b, c);
 }
 
-int32_t to_other_storage(const sprs_hip_csmat *, sprs_hip_csmat **) {
-    SPRS_FAIL(SPRS_HIP_INVALID_ARG, "to_other_storage: not built yet");
-}
-
 }  // namespace sprs_hip

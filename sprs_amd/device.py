@@ -156,6 +156,12 @@ class DeviceCsMat:
                                                 _vp(data), None))
         return indptr, indices, data
 
+    def slice_outer(self, start, end):
+        """slice_outer (slicing.rs:65-89) + to_proper, materialised on the device."""
+        h = C.c_void_p()
+        check(lib.sprs_hip_csmat_slice_outer(self._h, start, end, C.byref(h)))
+        return DeviceCsMat(h.value)
+
     def transpose_view(self):
         """csmat.rs:982-991: free, shares buffers."""
         h = C.c_void_p()
