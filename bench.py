@@ -157,6 +157,19 @@ def main():
     alg_bytes = algorithmic_bytes(blk_rows, blk_cols, sh.block_nnz, args.idx_bytes, args.idx_bytes)
     achieved = alg_bytes / (kern_avg_ms * 1e-3) / 1e9
 
+    # PMC counters cannot be collected inside this process: `traffic` comes from the committed
+    # counter passes of the same command (scripts/gpu_pmc.sh -> profiles/pmc_traffic.json) and is
+    # only filled in when workload, index width and options match that run.
+    traffic = None
+    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.tile, args.xmask))
+    try:
+        if world == 1 and defaults:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                for e in json.load(f)["entries"]:
+                    if e["workload"] == wl and e["index_bytes"] == args.idx_bytes:
+                        traffic = e["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
     if sprs_amd.get_option("spmv_kernel") == 2:
         kernel_name = "sprs_hip::spmv_rowwave_kernel"
     elif sprs_amd.get_option("spmv_xcs") == 2:
@@ -194,7 +207,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms_avg": round(kern_avg_ms, 5),
             "kernel_ms_min": round(float(np.min(kern_ms)), 5),
-            "traffic": None,   # rocprofv3 --pmc passes: see profiles/ and DESIGN.md
+            "traffic": traffic,   # HBM bytes per SpMV from committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or null
         },
     }
 

@@ -42,6 +42,9 @@ constexpr int LG_WAVES = LG_BLOCK / WAVE;
 constexpr int WORDS_PER_THREAD = WORDS / LG_BLOCK;   // 16
 constexpr int SUPER_WORDS = 64;           // words per superblock (4096 columns)
 constexpr int NSUPER = WORDS / SUPER_WORDS;          // 128
+constexpr int MIN_WIN_LOG2 = 13;          // heavy rows: windows down to 8192 columns
+constexpr uint64_t HEAVY_PRODUCTS = 65536;   // target products per task of a heavy row
+constexpr int ACC_CAP = 8192;             // tasks with at most this many outputs accumulate in LDS (64 KiB)
 
 template <typename IDX, typename PTR>
 struct CsrView {
@@ -76,8 +79,8 @@ __device__ __forceinline__ uint64_t lower_bound_col(const IDX *__restrict__ idx,
 // ---------------------------------------------------------------------------
 template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
-                                                       uint64_t nwin, uint64_t *__restrict__ ub,
-                                                       uint64_t *__restrict__ ntasks) {
+                                                       uint64_t b_cols, uint64_t *__restrict__ ub,
+                                                       uint64_t *__restrict__ ntasks, uint8_t *__restrict__ wlog) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
@@ -91,7 +94,22 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
         acc = wave_sum_u64(acc);
         if (lane == 0) {
             ub[r] = acc;
-            ntasks[r] = acc == 0 ? 0 : (acc <= SMALL_MAX ? 1 : nwin);
+            // Window width of a large row: 2^19 columns, narrowed (down to 2^13) for heavy rows so that
+            // a hub row becomes many tasks of ~HEAVY_PRODUCTS products instead of one serial chain.
+            uint32_t wl = WIN_LOG2;
+            if (acc > SMALL_MAX) {
+                uint64_t want = acc / HEAVY_PRODUCTS;          // desired number of tasks ...
+                const uint64_t by_len = (e - s) / 256;         // ... but only rows with a long k walk are worth
+                if (want > by_len) want = by_len;              //     the extra binary searches of narrow windows
+                if (want < 1) want = 1;
+                uint64_t width = b_cols / want;                // columns per task
+                wl = width <= 1 ? 0 : 63 - __clzll((long long)width);   // floor(log2)
+                if (wl > (uint32_t)WIN_LOG2) wl = WIN_LOG2;
+                if (wl < (uint32_t)MIN_WIN_LOG2) wl = MIN_WIN_LOG2;
+            }
+            wlog[r] = (uint8_t)wl;
+            const uint64_t width = 1ull << wl;
+            ntasks[r] = acc == 0 ? 0 : (acc <= SMALL_MAX ? 1 : (b_cols + width - 1) / width);
         }
     }
 }
@@ -248,14 +266,17 @@ __global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, P
                                                                   const uint64_t *__restrict__ task_row,
                                                                   const uint64_t *__restrict__ first_task,
                                                                   const uint64_t *__restrict__ ntasks,
+                                                                  const uint8_t *__restrict__ wlog,
                                                                   uint64_t *__restrict__ count) {
     __shared__ unsigned long long bm[WORDS];
     __shared__ uint64_t red[LG_WAVES];
     const uint64_t t = large_list[blockIdx.x];
     const uint64_t r = task_row[t];
     const uint64_t w = t - first_task[r];
-    const uint64_t wlo = w * WIN, whi = (wlo + WIN < b_cols) ? wlo + WIN : b_cols;
-    for (int i = threadIdx.x; i < WORDS; i += LG_BLOCK) bm[i] = 0;
+    const uint32_t wl = wlog[r];
+    const int words = (int)((1ull << wl) / 64);
+    const uint64_t wlo = w << wl, whi = (wlo + (1ull << wl) < b_cols) ? wlo + (1ull << wl) : b_cols;
+    for (int i = threadIdx.x; i < words; i += LG_BLOCK) bm[i] = 0;
     __syncthreads();
     uint32_t fresh = 0;
     set_window_bits(A, B, (uint64_t)A.indptr[r], (uint64_t)A.indptr[r + 1], wlo, whi, ntasks[r] == 1, bm, fresh);
@@ -275,24 +296,31 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                                                                  const uint64_t *__restrict__ task_row,
                                                                  const uint64_t *__restrict__ first_task,
                                                                  const uint64_t *__restrict__ ntasks,
+                                                                 const uint8_t *__restrict__ wlog,
                                                                  const uint64_t *__restrict__ count,
                                                                  const uint64_t *__restrict__ off,
                                                                  IDX *__restrict__ c_indices, double *__restrict__ c_data) {
     __shared__ unsigned long long bm[WORDS];        // 64 KiB
     __shared__ uint16_t sub[WORDS];                 // 16 KiB: rank of a word inside its superblock
     __shared__ uint32_t super[NSUPER + 1];          // outputs before each 4096-column superblock
+    __shared__ double acc[ACC_CAP];                 // 32 KiB: accumulators of tasks with few outputs
     __shared__ uint64_t wt[16];
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const uint64_t t = large_list[blockIdx.x];
     const uint64_t r = task_row[t];
     const uint64_t w = t - first_task[r];
-    const uint64_t wlo = w * WIN, whi = (wlo + WIN < b_cols) ? wlo + WIN : b_cols;
+    const uint32_t wl = wlog[r];
+    const int words = (int)((1ull << wl) / 64);
+    const uint64_t wlo = w << wl, whi = (wlo + (1ull << wl) < b_cols) ? wlo + (1ull << wl) : b_cols;
     const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
     const uint64_t out = off[t];
     const uint32_t cnt = (uint32_t)count[t];
     if (cnt == 0) return;                           // window without outputs (block-uniform)
+    const bool in_lds = cnt <= (uint32_t)ACC_CAP;   // block-uniform
 
-    for (int i = tid; i < WORDS; i += LG_BLOCK) bm[i] = 0;
+    for (int i = tid; i < words; i += LG_BLOCK) bm[i] = 0;
+    if (in_lds)
+        for (uint32_t i = tid; i < cnt; i += LG_BLOCK) acc[i] = 0.0;
     __syncthreads();
     uint32_t fresh = 0;
     set_window_bits(A, B, as, ae, wlo, whi, ntasks[r] == 1, bm, fresh);
@@ -303,8 +331,9 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     uint32_t mine = 0;
 #pragma unroll
     for (int i = 0; i < WORDS_PER_THREAD; ++i) {
+        const int word = tid * WORDS_PER_THREAD + i;
         local[i] = mine;
-        mine += (uint32_t)__popcll(bm[tid * WORDS_PER_THREAD + i]);
+        mine += word < words ? (uint32_t)__popcll(bm[word]) : 0u;
     }
     uint64_t tot;
     const uint32_t tpre = (uint32_t)block_excl_scan_u64(mine, wt, &tot);
@@ -313,18 +342,19 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     if (tid == 0) super[NSUPER] = (uint32_t)tot;
     __syncthreads();
     const uint32_t sbase = super[tid / THREADS_PER_SUPER];
-    // indices come out sorted: walk the set bits in order; zero the accumulators
+    // indices come out sorted: walk the set bits in order; zero the global accumulators
     uint32_t run = tpre;
 #pragma unroll 1
     for (int i = 0; i < WORDS_PER_THREAD; ++i) {
         const int word = tid * WORDS_PER_THREAD + i;
+        if (word >= words) break;
         sub[word] = (uint16_t)(tpre + local[i] - sbase);
         unsigned long long m = bm[word];
         while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
             c_indices[out + run] = (IDX)(wlo + (uint64_t)word * 64 + (uint64_t)b);
-            c_data[out + run] = 0.0;
+            if (!in_lds) c_data[out + run] = 0.0;
             ++run;
         }
     }
@@ -332,9 +362,10 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
 
     // each wave OWNS a contiguous range of superblocks holding ~cnt/8 outputs, and walks
     // every k in ascending order for it: one owner per accumulator, reference order.
+    const int nsuper = (words + SUPER_WORDS - 1) / SUPER_WORDS;
     auto boundary = [&](uint32_t target) -> uint32_t {   // number of superblocks with super[sb] < target
         uint32_t n = 0;
-        for (int sb = lane; sb < NSUPER; sb += WAVE) n += (super[sb] < target) ? 1u : 0u;
+        for (int sb = lane; sb < nsuper; sb += WAVE) n += (super[sb] < target) ? 1u : 0u;
         return (uint32_t)wave_sum_u64(n);
     };
     uint32_t sb_lo = boundary((uint32_t)(((uint64_t)cnt * wave) / LG_WAVES));
@@ -342,44 +373,53 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     sb_lo = __shfl(sb_lo, 0, WAVE);
     sb_hi = __shfl(sb_hi, 0, WAVE);
     if (wave == 0) sb_lo = 0;
-    if (wave == LG_WAVES - 1) sb_hi = NSUPER;
-    if (sb_hi <= sb_lo) return;
+    if (wave == LG_WAVES - 1) sb_hi = (uint32_t)nsuper;
     const uint64_t clo = wlo + (uint64_t)sb_lo * (SUPER_WORDS * 64);
     uint64_t chi = wlo + (uint64_t)sb_hi * (SUPER_WORDS * 64);
     if (chi > whi) chi = whi;
-    if (clo >= chi) return;
 
-    for (uint64_t p0 = as; p0 < ae; p0 += WAVE) {
-        const uint64_t p = p0 + lane;
-        const bool valid = p < ae;
-        const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
-        const double av = valid ? A.data[p] : 0.0;
-        uint64_t s = valid ? (uint64_t)B.indptr[k] : 0, e = valid ? (uint64_t)B.indptr[k + 1] : 0;
-        if (e > s) {
-            s = lower_bound_col(B.indices, s, e, clo);
-            e = lower_bound_col(B.indices, s, e, chi);
-        }
-        unsigned long long live = __ballot(e > s);
-        while (live) {                                  // ascending j == ascending k
-            const int j = __ffsll((long long)live) - 1;
-            live &= live - 1;
-            const uint64_t sj = __shfl(s, j, WAVE), ej = __shfl(e, j, WAVE);
-            const double avj = __shfl(av, j, WAVE);
-            for (uint64_t b = sj + lane; b < ej; b += WAVE) {
-                const uint64_t c = (uint64_t)B.indices[b] - wlo;
-                const double pr = avj * B.data[b];
-                const uint32_t word = (uint32_t)(c >> 6);
-                const uint32_t rank = super[word / SUPER_WORDS] + sub[word] +
-                                      (uint32_t)__popcll(bm[word] & ((1ull << (c & 63)) - 1ull));
-                double *dst = c_data + out + rank;
-                // accumulator lives in L2: read around the (per-CU, write-through) L1
-                double v = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v += pr;
-                __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sb_hi > sb_lo && clo < chi) {
+        for (uint64_t p0 = as; p0 < ae; p0 += WAVE) {
+            const uint64_t p = p0 + lane;
+            const bool valid = p < ae;
+            const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
+            const double av = valid ? A.data[p] : 0.0;
+            uint64_t s = valid ? (uint64_t)B.indptr[k] : 0, e = valid ? (uint64_t)B.indptr[k + 1] : 0;
+            if (e > s) {
+                s = lower_bound_col(B.indices, s, e, clo);
+                e = lower_bound_col(B.indices, s, e, chi);
             }
-            // the next k may hit the same accumulators: its loads must follow these stores
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long live = __ballot(e > s);
+            while (live) {                                  // ascending j == ascending k
+                const int j = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                const uint64_t sj = __shfl(s, j, WAVE), ej = __shfl(e, j, WAVE);
+                const double avj = __shfl(av, j, WAVE);
+                for (uint64_t b = sj + lane; b < ej; b += WAVE) {
+                    const uint64_t c = (uint64_t)B.indices[b] - wlo;
+                    const double pr = avj * B.data[b];
+                    const uint32_t word = (uint32_t)(c >> 6);
+                    const uint32_t rank = super[word / SUPER_WORDS] + sub[word] +
+                                          (uint32_t)__popcll(bm[word] & ((1ull << (c & 63)) - 1ull));
+                    if (in_lds) {
+                        acc[rank] += pr;                    // LDS, one owner wave, program order
+                    } else {
+                        double *dst = c_data + out + rank;
+                        // accumulator lives in L2: read around the (per-CU, write-through) L1
+                        double v = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v += pr;
+                        __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                // the next k may hit the same accumulators: its loads must follow these stores
+                if (in_lds) __builtin_amdgcn_wave_barrier();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += LG_BLOCK) c_data[out + i] = acc[i];
     }
 }
 
@@ -407,9 +447,9 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     const uint64_t rows = a->rows, b_cols = b->cols;
     CsrView<IDX, PTR> A{(const PTR *)a->indptr, (const IDX *)a->indices, a->data};
     CsrView<IDX, PTR> B{(const PTR *)b->indptr, (const IDX *)b->indices, b->data};
-    const uint64_t nwin = b_cols ? (b_cols + WIN - 1) / WIN : 1;
 
-    DevBuf ub, ntasks, first_task, counters;
+    DevBuf ub, ntasks, first_task, counters, wlog;
+    SPRS_TRY_HIP(wlog.alloc(rows));
     SPRS_TRY_HIP(ub.alloc(rows * 8));
     SPRS_TRY_HIP(ntasks.alloc(rows * 8));
     SPRS_TRY_HIP(first_task.alloc((rows + 1) * 8));
@@ -419,8 +459,8 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     if (rows) {
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
-        hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, nwin,
-                           ub.as<uint64_t>(), ntasks.as<uint64_t>());
+        hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
+                           ub.as<uint64_t>(), ntasks.as<uint64_t>(), wlog.as<uint8_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
     SPRS_TRY(exclusive_scan_u64(ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows, stream));
@@ -461,7 +501,7 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     if (n_large) {
         hipLaunchKernelGGL((large_symbolic_kernel<IDX, PTR>), dim3((unsigned)n_large), dim3(LG_BLOCK), 0, stream, A, B,
                            b_cols, large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),
-                           ntasks.as<uint64_t>(), count.as<uint64_t>());
+                           ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
 
@@ -486,8 +526,8 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     if (n_large)
         hipLaunchKernelGGL((large_numeric_kernel<IDX, PTR>), dim3((unsigned)n_large), dim3(LG_BLOCK), 0, stream, A, B,
                            b_cols, large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),
-                           ntasks.as<uint64_t>(), count.as<uint64_t>(), off.as<uint64_t>(), (IDX *)c->indices,
-                           c->data);
+                           ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>(), off.as<uint64_t>(),
+                           (IDX *)c->indices, c->data);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
