@@ -595,13 +595,15 @@ static int32_t launch_pieces(sprs_hip_csmat *a, SpmvScratch *sc, const double *x
                              hipStream_t stream) {
     const SpmvPlan &pl = a->plan;
     const uint64_t xmask = (uint64_t)options().spmv_xmask;
+    // dynamic LDS requested on top of the static arrays only limits how many workgroups share a CU
+    const unsigned lds_pad = (unsigned)options().spmv_lds_pad;
     // piece 1: the whole matrix, or its short rows
     if (pl.main.ntiles) {
         const TileArgs ta{pl.main.indptr, pl.main.indices, pl.main.data, pl.main.tile_row, sc->carry_main, y,
                           pl.main.nnz,    pl.main.ntiles};
         const dim3 grid((unsigned)pl.main.ntiles), block(BLOCK);
-        if (acc) hipLaunchKernelGGL((spmv_tile_kernel<CIDX, PTR, true, TILE>), grid, block, 0, stream, ta, x, xmask);
-        else hipLaunchKernelGGL((spmv_tile_kernel<CIDX, PTR, false, TILE>), grid, block, 0, stream, ta, x, xmask);
+        if (acc) hipLaunchKernelGGL((spmv_tile_kernel<CIDX, PTR, true, TILE>), grid, block, lds_pad, stream, ta, x, xmask);
+        else hipLaunchKernelGGL((spmv_tile_kernel<CIDX, PTR, false, TILE>), grid, block, lds_pad, stream, ta, x, xmask);
         SPRS_TRY_HIP(hipGetLastError());
         if (pl.main.ntiles > 1) {
             hipLaunchKernelGGL(spmv_carry_kernel<PTR>, dim3((unsigned)((pl.main.ntiles + 255) / 256)), dim3(256), 0,
@@ -620,8 +622,8 @@ static int32_t launch_pieces(sprs_hip_csmat *a, SpmvScratch *sc, const double *x
     const uint64_t pbytes = XCS_SLICES * pl.n_long * sizeof(double);
     const SlicedArgs *sa = (const SlicedArgs *)((uint8_t *)sc->partial + ((pbytes + 255) & ~255ull));
     if (max_tiles) {
-        hipLaunchKernelGGL((spmv_sliced_kernel<CIDX, TILE>), dim3((unsigned)(max_tiles * XCS_SLICES)), dim3(BLOCK), 0,
-                           stream, sa, x, xmask);
+        hipLaunchKernelGGL((spmv_sliced_kernel<CIDX, TILE>), dim3((unsigned)(max_tiles * XCS_SLICES)), dim3(BLOCK),
+                           lds_pad, stream, sa, x, xmask);
         SPRS_TRY_HIP(hipGetLastError());
         if (max_tiles > 1) {
             hipLaunchKernelGGL(spmv_sliced_carry_kernel, dim3((unsigned)((max_tiles + 255) / 256), XCS_SLICES),
