@@ -20,6 +20,9 @@ def main():
     n, k = int(sys.argv[1]), float(sys.argv[2])
     idx_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     check_rows = int(sys.argv[4]) if len(sys.argv) > 4 else 2000
+    if len(sys.argv) > 5:
+        import sprs_amd
+        sprs_amd.set_option("spgemm_heavy", int(sys.argv[5]))
     dev = torch.device("cuda", 0)
     idt = torch.int64 if idx_bytes == 8 else torch.int32
     indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)

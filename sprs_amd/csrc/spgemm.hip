@@ -43,7 +43,6 @@ constexpr int WORDS_PER_THREAD = WORDS / LG_BLOCK;   // 16
 constexpr int SUPER_WORDS = 64;           // words per superblock (4096 columns)
 constexpr int NSUPER = WORDS / SUPER_WORDS;          // 128
 constexpr int MIN_WIN_LOG2 = 13;          // heavy rows: windows down to 8192 columns
-constexpr uint64_t HEAVY_PRODUCTS = 65536;   // target products per task of a heavy row
 constexpr int ACC_CAP = 8192;             // tasks with at most this many outputs accumulate in LDS (64 KiB)
 
 template <typename IDX, typename PTR>
@@ -79,8 +78,9 @@ __device__ __forceinline__ uint64_t lower_bound_col(const IDX *__restrict__ idx,
 // ---------------------------------------------------------------------------
 template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
-                                                       uint64_t b_cols, uint64_t *__restrict__ ub,
-                                                       uint64_t *__restrict__ ntasks, uint8_t *__restrict__ wlog) {
+                                                       uint64_t b_cols, uint64_t heavy_products,
+                                                       uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks,
+                                                       uint8_t *__restrict__ wlog) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
@@ -98,9 +98,7 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
             // a hub row becomes many tasks of ~HEAVY_PRODUCTS products instead of one serial chain.
             uint32_t wl = WIN_LOG2;
             if (acc > SMALL_MAX) {
-                uint64_t want = acc / HEAVY_PRODUCTS;          // desired number of tasks ...
-                const uint64_t by_len = (e - s) / 256;         // ... but only rows with a long k walk are worth
-                if (want > by_len) want = by_len;              //     the extra binary searches of narrow windows
+                uint64_t want = acc / heavy_products;          // desired number of tasks
                 if (want < 1) want = 1;
                 uint64_t width = b_cols / want;                // columns per task
                 wl = width <= 1 ? 0 : 63 - __clzll((long long)width);   // floor(log2)
@@ -460,7 +458,7 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
-                           ub.as<uint64_t>(), ntasks.as<uint64_t>(), wlog.as<uint8_t>());
+                           (uint64_t)options().spgemm_heavy, ub.as<uint64_t>(), ntasks.as<uint64_t>(), wlog.as<uint8_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
     SPRS_TRY(exclusive_scan_u64(ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows, stream));
