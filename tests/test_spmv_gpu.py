@@ -300,3 +300,35 @@ def test_cpp_host_mirror(hip):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all passed" in r.stdout
+
+
+@pytest.mark.parametrize("parts", [2, 8])
+def test_virtual_ranks_row_partition(hip, parts):
+    """Multi-GPU path on ONE device: the nnz-balanced row blocks of sprs_amd.dist,
+    each cut with slice_outer on the device and multiplied on its own handle, concatenate to the
+    single-handle result bit for bit (per-row arithmetic does not depend on the partition when
+    the same plan kind is used) and match the oracle."""
+    import torch
+    from sprs_amd import gen
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    n = 80000
+    indptr, indices, data = gen.rmat_csr(n, 12, seed=4)
+    ip, ix, dt = indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy()
+    x = gen.dense_vector(n).numpy()
+    hip.set_option("spmv_xcs", 2)            # same (plain) plan for every shard and for the whole
+    try:
+        a = DeviceCsMat.from_host((n, n), ip, ix, dt)
+        xv = DeviceVec.from_host(x)
+        whole = (a * xv).to_host()
+        cuts = gen.balanced_row_blocks(indptr, parts)
+        y = np.zeros(n)
+        for g in range(parts):
+            blk = a.slice_outer(cuts[g], cuts[g + 1])
+            assert blk.shape() == (cuts[g + 1] - cuts[g], n)
+            y[cuts[g]:cuts[g + 1]] = (blk * xv).to_host()
+    finally:
+        hip.set_option("spmv_xcs", 0)
+    assert rel_err(y, oracle_spmv((n, n), ip, ix, dt, x)) <= TOL
+    assert rel_err(y, whole) <= 1e-14
+    nnz_blocks = [int(ip[cuts[g + 1]] - ip[cuts[g]]) for g in range(parts)]
+    assert max(nnz_blocks) <= ix.size / parts + int(np.diff(ip.astype(np.int64)).max())
