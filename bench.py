@@ -195,7 +195,7 @@ def main():
             "workload": name,
             "rows": n, "cols": n, "nnz": nnz_total,
             "index_bytes": args.idx_bytes, "indptr_bytes": args.idx_bytes,
-            "partition": "cost-balanced (nnz + 5/row) contiguous row blocks x%d, direct all-gather-v of y" % world if world > 1 else "single GPU",
+            "partition": "cost-balanced (nnz + 8/row) contiguous row blocks x%d, direct all-gather-v of y" % world if world > 1 else "single GPU",
             "generate_s": round(gen_s, 2),
         },
         "roofline": {

@@ -2,7 +2,7 @@
 
 The reference has no distributed code; the shard is its own `slice_outer`
 (sprs/src/sparse/slicing.rs:65-89): rank g owns the contiguous row block
-[r_g, r_{g+1}) chosen so that every block has ~1/G of the cost (nnz + 5 per row), keeps a
+[r_g, r_{g+1}) chosen so that every block has ~1/G of the cost (nnz + 8 per row), keeps a
 full replica of x and computes y[r_g:r_{g+1}) = A[r_g:r_{g+1}, :] * x with the
 single-GPU kernel.  The one exchange step is an all-gather-v of y.
 
@@ -31,12 +31,12 @@ class RowShardedSpMV:
     block = (rows, cols, indptr, indices, data) with a zero-based indptr.
     """
 
-    def __init__(self, shape, indptr, indices, data, local_spmv, group=None, row_weight=5.0):
+    def __init__(self, shape, indptr, indices, data, local_spmv, group=None, row_weight=8.0):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rows, self.cols = shape
-        # blocks of equal cost nnz + row_weight * rows (a row costs about 5 entries on MI355X)
+        # blocks of equal cost nnz + row_weight * rows (a row costs ~5 entries of compute on MI355X; 8 also evens out the y blocks of the exchange)
         self.cuts = gen.balanced_row_blocks(indptr, self.world, row_weight=row_weight)
         r0, r1 = self.cuts[self.rank], self.cuts[self.rank + 1]
         lo, hi = int(indptr[r0]), int(indptr[r1])
