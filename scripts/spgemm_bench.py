@@ -23,6 +23,12 @@ def main():
     if len(sys.argv) > 5:
         import sprs_amd
         sprs_amd.set_option("spgemm_heavy", int(sys.argv[5]))
+    if len(sys.argv) > 6:
+        import sprs_amd
+        sprs_amd.set_option("spgemm_bucket", int(sys.argv[6]))
+    if os.environ.get("SPGEMM_PROF"):
+        import sprs_amd
+        sprs_amd.set_option("spgemm_prof", 1)
     dev = torch.device("cuda", 0)
     idt = torch.int64 if idx_bytes == 8 else torch.int32
     indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)

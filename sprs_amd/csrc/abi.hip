@@ -463,6 +463,10 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "spmv_tile")) {
         if (value != 0 && value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 0 (auto), 2048 or 4096");
         o.spmv_tile = value;
+    } else if (!strcmp(name, "spgemm_bucket")) {
+        o.spgemm_bucket = value ? 1 : 0;
+    } else if (!strcmp(name, "spgemm_prof")) {
+        o.spgemm_prof = value ? 1 : 0;
     } else if (!strcmp(name, "spgemm_heavy")) {
         if (value < 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_heavy must be >= 1024");
         o.spgemm_heavy = value;
@@ -486,6 +490,8 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_xcs_split")) *value = o.spmv_xcs_split;
     else if (!strcmp(name, "spmv_xcs_idx32")) *value = o.spmv_xcs_idx32;
     else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
+    else if (!strcmp(name, "spgemm_bucket")) *value = o.spgemm_bucket;
+    else if (!strcmp(name, "spgemm_prof")) *value = o.spgemm_prof;
     else if (!strcmp(name, "spgemm_heavy")) *value = o.spgemm_heavy;
     else if (!strcmp(name, "spmv_lds_pad")) *value = o.spmv_lds_pad;
     else if (!strcmp(name, "spmv_xmask")) *value = o.spmv_xmask;

@@ -43,6 +43,8 @@ struct Options {
     int64_t spmv_xcs_split = 32;   // rows with >= this many entries go to the sliced part
     int64_t spmv_xcs_idx32 = 1;    // plan-owned copies store 32-bit column ids when cols < 2^32
     int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
+    int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
+    int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
     int64_t spgemm_heavy = 65536;  // SpGEMM: target products per task of a heavy row (narrower column windows)
     int64_t spmv_lds_pad = 0;      // extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning)
     int64_t spmv_xmask = -1;       // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)

@@ -10,17 +10,29 @@
 // (smmp.rs:174-181, mul_acc.rs:28-30) — the same order as the reference, by a
 // single owner, so results are deterministic (no float atomics anywhere).
 //
-// Work decomposition: a TASK is (row i, column window w of 2^19 columns).
+// Work decomposition: a TASK is (row i, column window w).
 //   * rows whose product count  ub_i = sum_{k in A_i} nnz(B_k)  is <= 512 are one
 //     task handled by ONE WAVE with an LDS hash table (keys + f64 accumulators),
 //     then a bitonic sort of the table in LDS;
-//   * larger rows get one task per column window, handled by a 512-thread
-//     workgroup with a 64 KiB LDS BITMAP of the window: setting bits is the
+//   * larger rows get one task per column window — 2^19 columns, narrowed down to 2^13 for
+//     heavy rows so that a hub row becomes many tasks — handled by a 512-thread workgroup
+//     with an LDS BITMAP of the window (64 KiB at most): setting bits is the
 //     symbolic pass, a popcount prefix over the bitmap turns a column into its
-//     rank inside the (sorted!) output row, so indices come out sorted for free
-//     and the accumulators are the output values themselves.
-// Per-task counts are scanned (hand-written two-level prefix sum) into output
-// offsets; C.indptr falls out of the same scan.  Integer/HBM-bound: no MFMA.
+//     rank inside the (sorted!) output row, so indices come out sorted for free.
+//     Values are accumulated in LDS, in passes of <= 6144 outputs (superblock ranges of
+//     the window); within a pass every wave owns a product-balanced range of 4096-column
+//     superblocks and applies the k's in ascending order (8 k's prefetched at a time).
+//   * a column-bucket table of B (entries of every row before each 4096-column boundary,
+//     built per call, 4 B per row per 4096 columns) replaces the binary searches that
+//     locate a row inside a window / superblock range, and yields the per-superblock
+//     product counts used for the balancing.
+// Per-task counts are scanned (hand-written two-level prefix sum, scan.hip) into output
+// offsets; C.indptr falls out of the same scan.  Integer/LDS/HBM-bound: no MFMA.
+// History of what was measured (profiles/): per-row windows + LDS accumulators 1.96 s ->
+// 0.50 s on config 5; bucket table, product balancing, LDS staging of the k metadata,
+// LDS-only passes and 8-deep prefetch together -> 0.465 s; a flattened (load-balanced)
+// entry walk was slower and was dropped.  SPGEMM_PROF (option spgemm_prof) prints the
+// phase profile of the large-row numeric kernel.
 #include "common.hpp"
 #include "scan.hpp"
 
@@ -43,24 +55,8 @@ constexpr int WORDS_PER_THREAD = WORDS / LG_BLOCK;   // 16
 constexpr int SUPER_WORDS = 64;           // words per superblock (4096 columns)
 constexpr int NSUPER = WORDS / SUPER_WORDS;          // 128
 constexpr int MIN_WIN_LOG2 = 13;          // heavy rows: windows down to 8192 columns
-constexpr int ACC_CAP = 8192;             // tasks with at most this many outputs accumulate in LDS (64 KiB)
-
-template <typename IDX, typename PTR>
-struct CsrView {
-    const PTR *indptr;
-    const IDX *indices;
-    const double *data;
-};
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t hash_slot(uint32_t c, int lg) { return (c * 0x9E3779B1u) >> (32 - lg); }
-
-__device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }
+constexpr int ACC_CAP = 6144;             // tasks with at most this many outputs accumulate in LDS (48 KiB)
+constexpr int K_CAP = 256;                // k's whose metadata is staged in LDS per pass
 
 // first position in [lo, hi) whose column is >= v
 template <typename IDX>
@@ -72,6 +68,68 @@ __device__ __forceinline__ uint64_t lower_bound_col(const IDX *__restrict__ idx,
     }
     return lo;
 }
+
+template <typename IDX, typename PTR>
+struct CsrView {
+    const PTR *indptr;
+    const IDX *indices;
+    const double *data;
+    // optional column-bucket table of the right operand: bucket[k * nb + b] = number of entries of
+    // row k with column < b * 4096.  Turns "where does row k enter column window [lo,hi)" — two
+    // binary searches, ~20 dependent loads per (row, window) — into two independent loads.
+    const uint32_t *bucket;
+    uint64_t nb;
+};
+
+constexpr int BUCKET_LOG2 = 12;   // = one superblock of the LDS bitmap (64 words x 64 columns)
+
+// sub-range [s,e) of row k (given its [s,e) = whole row) inside columns [lo, hi); lo is a multiple
+// of 4096 and hi is either a multiple of 4096 or the number of columns
+template <typename IDX, typename PTR>
+__device__ __forceinline__ void row_window(const CsrView<IDX, PTR> &B, uint64_t k, uint64_t lo, uint64_t hi,
+                                           uint64_t &s, uint64_t &e) {
+    if (B.bucket) {
+        const uint32_t *t = B.bucket + k * B.nb;
+        const uint64_t row0 = s;
+        s = row0 + t[lo >> BUCKET_LOG2];
+        e = row0 + t[(hi + ((1ull << BUCKET_LOG2) - 1)) >> BUCKET_LOG2];
+    } else {
+        s = lower_bound_col(B.indices, s, e, lo);
+        e = lower_bound_col(B.indices, s, e, hi);
+    }
+}
+
+// bucket table build: one wave per row
+template <typename IDX, typename PTR>
+__global__ __launch_bounds__(256) void build_bucket_kernel(const PTR *__restrict__ indptr,
+                                                           const IDX *__restrict__ indices, uint64_t rows,
+                                                           uint64_t nb, uint32_t *__restrict__ bucket) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / 64;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / 64);
+    for (uint64_t r = w0; r < rows; r += nw) {
+        const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
+        uint32_t *t = bucket + r * nb;
+        // entry q (first of its bucket b, previous entry in bucket pb < b) defines t[pb+1 .. b] = q
+        for (uint64_t p = s + lane; p < e; p += 64) {
+            const uint64_t b = (uint64_t)indices[p] >> BUCKET_LOG2;
+            const int64_t pb = p > s ? (int64_t)((uint64_t)indices[p - 1] >> BUCKET_LOG2) : -1;
+            for (int64_t bb = pb + 1; bb <= (int64_t)b; ++bb) t[bb] = (uint32_t)(p - s);
+        }
+        const int64_t lastb = e > s ? (int64_t)((uint64_t)indices[e - 1] >> BUCKET_LOG2) : -1;
+        for (uint64_t bb = (uint64_t)(lastb + 1) + lane; bb < nb; bb += 64) t[bb] = (uint32_t)(e - s);
+    }
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t c, int lg) { return (c * 0x9E3779B1u) >> (32 - lg); }
+
+__device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }
 
 // ---------------------------------------------------------------------------
 // pass 0: per-row product count and number of tasks
@@ -239,20 +297,39 @@ __device__ __forceinline__ void set_window_bits(const CsrView<IDX, PTR> &A, cons
         const bool valid = p < ae;
         const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
         uint64_t s = valid ? (uint64_t)B.indptr[k] : 0, e = valid ? (uint64_t)B.indptr[k + 1] : 0;
-        if (!whole_row && e > s) {
-            s = lower_bound_col(B.indices, s, e, wlo);
-            e = lower_bound_col(B.indices, s, e, whi);
-        }
+        if (!whole_row && e > s) row_window(B, k, wlo, whi, s, e);
         unsigned long long live = __ballot(e > s);
+        constexpr int PF = 8;                       // steps loaded together (see large_numeric_kernel)
         while (live) {
-            const int j = __ffsll((long long)live) - 1;
-            live &= live - 1;
-            const uint64_t sj = __shfl(s, j, WAVE), ej = __shfl(e, j, WAVE);
-            for (uint64_t b = sj + lane; b < ej; b += WAVE) {
-                const uint64_t c = (uint64_t)B.indices[b] - wlo;
-                const unsigned long long bit = 1ull << (c & 63);
-                const unsigned long long old = atomicOr(&bm[c >> 6], bit);
-                fresh += (old & bit) ? 0u : 1u;
+            int js[PF];
+            int n = 0;
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                js[d] = 0;
+                if (live) {
+                    js[d] = __ffsll((long long)live) - 1;
+                    live &= live - 1;
+                    n = d + 1;
+                }
+            }
+            uint64_t sj[PF], ej[PF], cc[PF];
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                sj[d] = __shfl(s, js[d], WAVE);
+                ej[d] = __shfl(e, js[d], WAVE);
+                cc[d] = 0;
+                if (d < n && sj[d] + lane < ej[d]) cc[d] = (uint64_t)B.indices[sj[d] + lane];
+            }
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                if (d < n) {
+                    for (uint64_t b = sj[d] + lane; b < ej[d]; b += WAVE) {
+                        const uint64_t c = (b == sj[d] + lane ? cc[d] : (uint64_t)B.indices[b]) - wlo;
+                        const unsigned long long bit = 1ull << (c & 63);
+                        const unsigned long long old = atomicOr(&bm[c >> 6], bit);
+                        fresh += (old & bit) ? 0u : 1u;
+                    }
+                }
             }
         }
     }
@@ -297,7 +374,8 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                                                                  const uint8_t *__restrict__ wlog,
                                                                  const uint64_t *__restrict__ count,
                                                                  const uint64_t *__restrict__ off,
-                                                                 IDX *__restrict__ c_indices, double *__restrict__ c_data) {
+                                                                 IDX *__restrict__ c_indices, double *__restrict__ c_data,
+                                                                 unsigned long long *__restrict__ prof) {
     __shared__ unsigned long long bm[WORDS];        // 64 KiB
     __shared__ uint16_t sub[WORDS];                 // 16 KiB: rank of a word inside its superblock
     __shared__ uint32_t super[NSUPER + 1];          // outputs before each 4096-column superblock
@@ -314,15 +392,28 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     const uint64_t out = off[t];
     const uint32_t cnt = (uint32_t)count[t];
     if (cnt == 0) return;                           // window without outputs (block-uniform)
-    const bool in_lds = cnt <= (uint32_t)ACC_CAP;   // block-uniform
+    // accumulators: LDS when the task has few outputs, and ALWAYS with the bucket table (a wide
+    // window is then processed in passes of <= ACC_CAP outputs); else the row's slots in L2
+    const bool in_lds = cnt <= (uint32_t)ACC_CAP || B.bucket != nullptr;   // block-uniform
+    uint32_t base_rank = 0;                          // first output of the current pass
+    // optional phase profile (debug option spgemm_prof): cycles of thread 0 per phase, summed over tasks
+    long long t_prev = prof ? (long long)clock64() : 0;
+    auto mark = [&](int phase) {
+        if (prof && tid == 0) {
+            const long long now = (long long)clock64();
+            atomicAdd(&prof[phase], (unsigned long long)(now - t_prev));
+            t_prev = now;
+        }
+    };
 
     for (int i = tid; i < words; i += LG_BLOCK) bm[i] = 0;
-    if (in_lds)
+    if (in_lds && !B.bucket)
         for (uint32_t i = tid; i < cnt; i += LG_BLOCK) acc[i] = 0.0;
     __syncthreads();
     uint32_t fresh = 0;
     set_window_bits(A, B, as, ae, wlo, whi, ntasks[r] == 1, bm, fresh);
     __syncthreads();
+    mark(0);   // clear + bits
 
     // popcount prefix: thread tid owns words [16 tid, 16 tid + 16)
     uint32_t local[WORDS_PER_THREAD];
@@ -357,68 +448,209 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
         }
     }
     __syncthreads();   // sub/super complete; zeroed accumulators have reached L2 (release at workgroup scope)
+    mark(1);   // prefix + emit indices
 
-    // each wave OWNS a contiguous range of superblocks holding ~cnt/8 outputs, and walks
-    // every k in ascending order for it: one owner per accumulator, reference order.
+    // Each wave OWNS a contiguous range of superblocks and walks every k in ascending order for
+    // it: one owner per accumulator, reference order.  The ranges are balanced by PRODUCTS when
+    // the column-bucket table of B is available (one bucket = one superblock, so the products of
+    // superblock b are sum_k (t_k[b+1] - t_k[b]) — no pass over the entries needed), else by
+    // outputs.
     const int nsuper = (words + SUPER_WORDS - 1) / SUPER_WORDS;
-    auto boundary = [&](uint32_t target) -> uint32_t {   // number of superblocks with super[sb] < target
+    __shared__ uint32_t pcnt[NSUPER];
+    __shared__ uint32_t ppre[NSUPER + 1];
+    if (B.bucket) {
+        if (tid < NSUPER) pcnt[tid] = 0;
+        __syncthreads();
+        const uint64_t wb0 = wlo >> BUCKET_LOG2;
+        const uint64_t i0 = wb0 + lane, i1 = wb0 + lane + 64, last = B.nb - 1;
+        uint32_t c0 = 0, c1 = 0;
+        for (uint64_t p = as + wave; p < ae; p += LG_WAVES) {
+            const uint32_t *t = B.bucket + (uint64_t)A.indices[p] * B.nb;
+            if ((int)lane < nsuper) c0 += t[i0 + 1 < last ? i0 + 1 : last] - t[i0 < last ? i0 : last];
+            if ((int)lane + 64 < nsuper) c1 += t[i1 + 1 < last ? i1 + 1 : last] - t[i1 < last ? i1 : last];
+        }
+        if (c0) atomicAdd(&pcnt[lane], c0);
+        if (c1) atomicAdd(&pcnt[lane + 64], c1);
+        __syncthreads();
+        uint64_t ptot;
+        const uint64_t ex = block_excl_scan_u64((int)tid < nsuper ? pcnt[tid] : 0u, wt, &ptot);
+        if ((int)tid < nsuper) ppre[tid] = (uint32_t)ex;
+        if ((int)tid == nsuper) ppre[tid] = (uint32_t)ptot;
+        __syncthreads();
+    }
+    mark(2);   // product counts per superblock
+    // number of superblocks sb in [from, to) with bal[sb] - bal[from] < target
+    auto boundary = [&](const uint32_t *bal, uint32_t from, uint32_t to, uint32_t target) -> uint32_t {
         uint32_t n = 0;
-        for (int sb = lane; sb < nsuper; sb += WAVE) n += (super[sb] < target) ? 1u : 0u;
-        return (uint32_t)wave_sum_u64(n);
+        const uint32_t b0 = bal[from];
+        for (uint32_t sb = from + lane; sb < to; sb += WAVE) n += (bal[sb] - b0 < target) ? 1u : 0u;
+        return __shfl((uint32_t)wave_sum_u64(n), 0, WAVE);
     };
-    uint32_t sb_lo = boundary((uint32_t)(((uint64_t)cnt * wave) / LG_WAVES));
-    uint32_t sb_hi = boundary((uint32_t)(((uint64_t)cnt * (wave + 1)) / LG_WAVES));
-    sb_lo = __shfl(sb_lo, 0, WAVE);
-    sb_hi = __shfl(sb_hi, 0, WAVE);
-    if (wave == 0) sb_lo = 0;
-    if (wave == LG_WAVES - 1) sb_hi = (uint32_t)nsuper;
+    uint32_t sb_lo = 0, sb_hi = 0;
+    if (!B.bucket) {
+        sb_lo = boundary(super, 0, (uint32_t)nsuper, (uint32_t)(((uint64_t)cnt * wave) / LG_WAVES));
+        sb_hi = boundary(super, 0, (uint32_t)nsuper, (uint32_t)(((uint64_t)cnt * (wave + 1)) / LG_WAVES));
+        if (wave == 0) sb_lo = 0;
+        if (wave == LG_WAVES - 1) sb_hi = (uint32_t)nsuper;
+    }
     const uint64_t clo = wlo + (uint64_t)sb_lo * (SUPER_WORDS * 64);
     uint64_t chi = wlo + (uint64_t)sb_hi * (SUPER_WORDS * 64);
     if (chi > whi) chi = whi;
 
-    if (sb_hi > sb_lo && clo < chi) {
+    // apply one batch of up to 64 sub-ranges [s,e) (lane j holds k_j's), ascending j == ascending k
+    auto apply_batch = [&](uint64_t s, uint64_t e, double av) {
+        // PF steps (k's) are loaded together before any of them is applied: a step's entries
+        // are a dependent global load (~1.4 us under load), and with 8 waves per CU one step at
+        // a time left the CU 85 % idle.  Application order stays ascending k.
+        constexpr int PF = 8;
+        unsigned long long live = __ballot(e > s);
+        while (live) {
+            int js[PF];
+            int n = 0;
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                js[d] = 0;
+                if (live) {
+                    js[d] = __ffsll((long long)live) - 1;
+                    live &= live - 1;
+                    n = d + 1;
+                }
+            }
+            uint64_t sj[PF], ej[PF];
+            uint64_t cc[PF];
+            double vv[PF];
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                sj[d] = __shfl(s, js[d], WAVE);
+                ej[d] = __shfl(e, js[d], WAVE);
+                cc[d] = 0;
+                vv[d] = 0.0;
+                if (d < n && sj[d] + lane < ej[d]) {
+                    cc[d] = (uint64_t)B.indices[sj[d] + lane];
+                    vv[d] = B.data[sj[d] + lane];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                if (d < n) {                                  // wave-uniform
+                    const double avj = __shfl(av, js[d], WAVE);
+                    for (uint64_t b = sj[d] + lane; b < ej[d]; b += WAVE) {
+                        uint64_t c;
+                        double bv;
+                        if (b == sj[d] + lane) {
+                            c = cc[d];
+                            bv = vv[d];
+                        } else {                              // sub-range longer than one wave: rare
+                            c = (uint64_t)B.indices[b];
+                            bv = B.data[b];
+                        }
+                        c -= wlo;
+                        const double pr = avj * bv;
+                        const uint32_t word = (uint32_t)(c >> 6);
+                        const uint32_t rank = super[word / SUPER_WORDS] + sub[word] +
+                                              (uint32_t)__popcll(bm[word] & ((1ull << (c & 63)) - 1ull));
+                        if (in_lds) {
+                            acc[rank - base_rank] += pr;        // LDS, one owner wave, program order
+                        } else {
+                            double *dst = c_data + out + rank;
+                            // The accumulator lives in this XCD's L2.  LOAD with sc1 (served by L2, around
+                            // the per-CU L1 that other waves' stores never refresh); STORE plain: a plain
+                            // store is written through to L2 and KEEPS the line there, whereas an sc1 /
+                            // atomic store drops it to memory (profiles/r01q_spgemm_pmc.txt).
+                            double v = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            v += pr;
+                            *(volatile double *)dst = v;
+                        }
+                    }
+                    // the next k may hit the same accumulators: its loads must follow these stores
+                    if (in_lds) __builtin_amdgcn_wave_barrier();
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+        }
+    };
+
+    if (B.bucket) {
+        // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) holding at most
+        // ACC_CAP outputs (one superblock has <= 4096), so the accumulators of a pass always fit in
+        // LDS.  (Before: tasks with more outputs accumulated through L2 with one global round trip
+        // per k — 28 % of config 5's tasks took 46 % of this kernel's time, scripts/spgemm_bench.py
+        // with SPGEMM_PROF=1.)  Inside a pass the k metadata is gathered ONCE per workgroup into
+        // LDS: row start, the bucket offsets at the 9 wave boundaries, the A value.
+        __shared__ uint64_t k_row0[K_CAP];
+        __shared__ double k_val[K_CAP];
+        __shared__ uint32_t k_bnd[K_CAP][LG_WAVES + 1];
+        __shared__ uint32_t w_bnd[LG_WAVES + 1];
+        const uint64_t wb0 = wlo >> BUCKET_LOG2, last = B.nb - 1;
+        uint32_t pb = 0;
+        while (pb < (uint32_t)nsuper) {
+            uint32_t pe = pb + 1;
+            while (pe < (uint32_t)nsuper && super[pe + 1] - super[pb] <= (uint32_t)ACC_CAP) ++pe;
+            base_rank = super[pb];
+            const uint32_t pass_out = super[pe] - base_rank;
+            if (pass_out) {                                  // block-uniform
+                for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) acc[i] = 0.0;
+                // wave ownership inside the pass, balanced by products
+                const uint32_t pprod = ppre[pe] - ppre[pb];
+                const uint32_t lo_w = pb + boundary(ppre, pb, pe, (uint32_t)(((uint64_t)pprod * wave) / LG_WAVES));
+                if (lane == 0) w_bnd[wave] = wave == 0 ? pb : lo_w;
+                if (tid == 0) w_bnd[LG_WAVES] = pe;
+                __syncthreads();
+                const bool mine = w_bnd[wave + 1] > w_bnd[wave];
+                for (uint64_t kc = as; kc < ae; kc += K_CAP) {
+                    const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
+                    for (uint32_t i = tid; i < n * (LG_WAVES + 1); i += LG_BLOCK) {
+                        const uint32_t kk = i / (LG_WAVES + 1), g = i % (LG_WAVES + 1);
+                        const uint64_t k = (uint64_t)A.indices[kc + kk];
+                        const uint64_t bi = wb0 + w_bnd[g];
+                        k_bnd[kk][g] = B.bucket[k * B.nb + (bi < last ? bi : last)];
+                        if (g == 0) {
+                            k_row0[kk] = (uint64_t)B.indptr[k];
+                            k_val[kk] = A.data[kc + kk];
+                        }
+                    }
+                    __syncthreads();
+                    if (mine) {
+                        for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+                            const uint32_t j = j0 + lane;
+                            uint64_t s = 0, e = 0;
+                            double av = 0.0;
+                            if (j < n) {
+                                s = k_row0[j] + k_bnd[j][wave];
+                                e = k_row0[j] + k_bnd[j][wave + 1];
+                                av = k_val[j];
+                            }
+                            apply_batch(s, e, av);
+                        }
+                    }
+                    __syncthreads();
+                }
+                for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
+                __syncthreads();
+            }
+            pb = pe;
+        }
+        mark(3);
+    } else if (sb_hi > sb_lo && clo < chi) {
         for (uint64_t p0 = as; p0 < ae; p0 += WAVE) {
             const uint64_t p = p0 + lane;
             const bool valid = p < ae;
             const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
             const double av = valid ? A.data[p] : 0.0;
             uint64_t s = valid ? (uint64_t)B.indptr[k] : 0, e = valid ? (uint64_t)B.indptr[k + 1] : 0;
-            if (e > s) {
-                s = lower_bound_col(B.indices, s, e, clo);
-                e = lower_bound_col(B.indices, s, e, chi);
-            }
-            unsigned long long live = __ballot(e > s);
-            while (live) {                                  // ascending j == ascending k
-                const int j = __ffsll((long long)live) - 1;
-                live &= live - 1;
-                const uint64_t sj = __shfl(s, j, WAVE), ej = __shfl(e, j, WAVE);
-                const double avj = __shfl(av, j, WAVE);
-                for (uint64_t b = sj + lane; b < ej; b += WAVE) {
-                    const uint64_t c = (uint64_t)B.indices[b] - wlo;
-                    const double pr = avj * B.data[b];
-                    const uint32_t word = (uint32_t)(c >> 6);
-                    const uint32_t rank = super[word / SUPER_WORDS] + sub[word] +
-                                          (uint32_t)__popcll(bm[word] & ((1ull << (c & 63)) - 1ull));
-                    if (in_lds) {
-                        acc[rank] += pr;                    // LDS, one owner wave, program order
-                    } else {
-                        double *dst = c_data + out + rank;
-                        // accumulator lives in L2: read around the (per-CU, write-through) L1
-                        double v = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v += pr;
-                        __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                // the next k may hit the same accumulators: its loads must follow these stores
-                if (in_lds) __builtin_amdgcn_wave_barrier();
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (e > s) row_window(B, k, clo, chi, s, e);
+            apply_batch(s, e, av);
         }
     }
-    if (in_lds) {
+    if (in_lds && !B.bucket) {
         __syncthreads();
+        mark(3);   // accumulate (LDS accumulators)
         for (uint32_t i = tid; i < cnt; i += LG_BLOCK) c_data[out + i] = acc[i];
+        mark(5);   // write back
+    } else if (!in_lds) {
+        mark(4);   // accumulate (L2 accumulators)
     }
+    if (prof && tid == 0) atomicAdd(&prof[in_lds ? 6 : 7], 1ull);   // task counts
 }
 
 template <typename PTR>
@@ -443,8 +675,24 @@ template <typename IDX, typename PTR>
 int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c_out) {
     hipStream_t stream = nullptr;
     const uint64_t rows = a->rows, b_cols = b->cols;
-    CsrView<IDX, PTR> A{(const PTR *)a->indptr, (const IDX *)a->indices, a->data};
-    CsrView<IDX, PTR> B{(const PTR *)b->indptr, (const IDX *)b->indices, b->data};
+    CsrView<IDX, PTR> A{(const PTR *)a->indptr, (const IDX *)a->indices, a->data, nullptr, 0};
+    CsrView<IDX, PTR> B{(const PTR *)b->indptr, (const IDX *)b->indices, b->data, nullptr, 0};
+    // column-bucket table of B (4 bytes per 4096 columns per row) when it fits a budget of 8 GiB
+    DevBuf bucket;
+    {
+        const uint64_t nb = (b_cols >> BUCKET_LOG2) + 2;
+        const uint64_t bytes = b->rows * nb * sizeof(uint32_t);
+        if (options().spgemm_bucket && b->rows && bytes <= (8ull << 30)) {
+            SPRS_TRY_HIP(bucket.alloc(bytes));
+            uint64_t blocks = (b->rows + 3) / 4;
+            if (blocks > 256 * 64) blocks = 256 * 64;
+            hipLaunchKernelGGL((build_bucket_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, B.indptr,
+                               B.indices, b->rows, nb, bucket.as<uint32_t>());
+            SPRS_TRY_HIP(hipGetLastError());
+            B.bucket = bucket.as<uint32_t>();
+            B.nb = nb;
+        }
+    }
 
     DevBuf ub, ntasks, first_task, counters, wlog;
     SPRS_TRY_HIP(wlog.alloc(rows));
@@ -517,6 +765,11 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
                        first_task.as<uint64_t>(), off.as<uint64_t>(), rows, (PTR *)c->indptr);
 
     // ---- numeric -------------------------------------------------------------
+    DevBuf prof;
+    if (options().spgemm_prof) {
+        SPRS_TRY_HIP(prof.alloc(64));
+        SPRS_TRY_HIP(hipMemsetAsync(prof.p, 0, 64, stream));
+    }
     if (n_small)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true>), small_grid(), dim3(SM_BLOCK), 0, stream, A, B,
                            small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
@@ -525,12 +778,20 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         hipLaunchKernelGGL((large_numeric_kernel<IDX, PTR>), dim3((unsigned)n_large), dim3(LG_BLOCK), 0, stream, A, B,
                            b_cols, large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),
                            ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>(), off.as<uint64_t>(),
-                           (IDX *)c->indices, c->data);
+                           (IDX *)c->indices, c->data, prof.as<unsigned long long>());
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
         sprs_hip_csmat_free(c);
         return fail_hip(e, "spgemm numeric");
+    }
+    if (prof.p) {
+        unsigned long long h[8];
+        if (hipMemcpy(h, prof.p, 64, hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr,
+                    "[spgemm_prof] thread-0 cycles summed over large tasks: bits %llu, prefix+emit %llu, prodcount %llu, "
+                    "accumulate(LDS) %llu, accumulate(L2) %llu, writeback %llu; tasks LDS %llu, L2 %llu\n",
+                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     }
     *c_out = c;
     return SPRS_HIP_OK;
