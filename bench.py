@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--xcs", type=int, default=None, help="XCD-sliced plan: 0 auto, 1 on, 2 off")
     ap.add_argument("--split", type=int, default=None, help="row-length threshold of the sliced part")
     ap.add_argument("--idx32", type=int, default=None, help="plan copies with 32-bit column ids: 1 on (default), 0 off")
+    ap.add_argument("--sort", type=int, default=None, help="plan copies with column-sorted tiles: 1 on (default), 0 off")
     ap.add_argument("--tile", type=int, default=None, help="nnz per workgroup tile: 2048 or 4096")
     ap.add_argument("--ldspad", type=int, default=None, help="extra dynamic LDS per workgroup (occupancy cap, tuning)")
     ap.add_argument("--xmask", type=int, default=None, help="timing experiment only: gather x[col & mask]")
@@ -74,7 +75,7 @@ def main():
     from sprs_amd import _ffi
     import ctypes as C
     _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
-    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_tile", args.tile), ("spmv_lds_pad", args.ldspad), ("spmv_xmask", args.xmask)):
+    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_lds_pad", args.ldspad), ("spmv_xmask", args.xmask)):
         if val is not None:
             sprs_amd.set_option(opt, val)
 
@@ -162,7 +163,7 @@ def main():
     # counter passes of the same command (scripts/gpu_pmc.sh -> profiles/pmc_traffic.json) and is
     # only filled in when workload, index width and options match that run.
     traffic = None
-    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.tile, args.ldspad, args.xmask))
+    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.sort, args.tile, args.ldspad, args.xmask))
     try:
         if world == 1 and defaults:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -165,6 +165,7 @@ int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat 
  * name = "spmv_xcs":       XCD-sliced plan for long rows: 0 auto, 1 force on, 2 off;
  * name = "spmv_xcs_split": rows with at least this many entries go to the sliced part (default 32);
  * name = "spmv_xcs_idx32": 1 (default): the sliced plan's own copies hold 32-bit column ids when cols < 2^32;
+ * name = "spmv_sort_tiles": 1: tiles of the sliced plan's copies are stored sorted by column (default 0: measured slower);
  * name = "spmv_tile":      nnz per workgroup tile: 0 auto (default), 2048 or 4096;
  * name = "spmv_xmask":     timing experiments only (gathers x[col & mask]; results are wrong unless -1).
  * Process-wide.  Unknown names / bad values return SPRS_HIP_INVALID_ARG. */

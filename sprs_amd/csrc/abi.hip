@@ -54,6 +54,7 @@ void SpmvPlan::release() {
         if (p) (void)hipFree(p);
     };
     drop(main.tile_row);
+    drop(main.pos);
     if (main.owns) {
         drop(main.indptr);
         drop(main.indices);
@@ -62,6 +63,7 @@ void SpmvPlan::release() {
     main = CsrPiece();
     for (auto &sl : slice) {
         drop(sl.tile_row);
+        drop(sl.pos);
         if (sl.owns) {
             drop(sl.indptr);
             drop(sl.indices);
@@ -460,6 +462,8 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         o.spmv_xcs_split = value;
     } else if (!strcmp(name, "spmv_xcs_idx32")) {
         o.spmv_xcs_idx32 = value ? 1 : 0;
+    } else if (!strcmp(name, "spmv_sort_tiles")) {
+        o.spmv_sort_tiles = value ? 1 : 0;
     } else if (!strcmp(name, "spmv_tile")) {
         if (value != 0 && value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 0 (auto), 2048 or 4096");
         o.spmv_tile = value;
@@ -489,6 +493,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_xcs")) *value = o.spmv_xcs;
     else if (!strcmp(name, "spmv_xcs_split")) *value = o.spmv_xcs_split;
     else if (!strcmp(name, "spmv_xcs_idx32")) *value = o.spmv_xcs_idx32;
+    else if (!strcmp(name, "spmv_sort_tiles")) *value = o.spmv_sort_tiles;
     else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
     else if (!strcmp(name, "spgemm_bucket")) *value = o.spgemm_bucket;
     else if (!strcmp(name, "spgemm_prof")) *value = o.spgemm_prof;

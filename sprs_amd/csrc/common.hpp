@@ -42,6 +42,7 @@ struct Options {
     int64_t spmv_xcs = 0;          // XCD-sliced plan for long rows: 0 auto, 1 force on, 2 off
     int64_t spmv_xcs_split = 32;   // rows with >= this many entries go to the sliced part
     int64_t spmv_xcs_idx32 = 1;    // plan-owned copies store 32-bit column ids when cols < 2^32
+    int64_t spmv_sort_tiles = 0;   // plan copies: entries of a tile sorted by column (measured 10 % SLOWER: profiles/r01v)
     int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
     int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
@@ -59,6 +60,7 @@ struct CsrPiece {
     void *indptr = nullptr;        // device; PTR of the handle for `main`, uint64 for slices
     void *indices = nullptr;       // device
     double *data = nullptr;        // device
+    uint16_t *pos = nullptr;       // device, plan copies only: tile-local origin of each entry (tiles sorted by column)
     uint64_t rows = 0, nnz = 0, ntiles = 0;
     uint64_t *tile_row = nullptr;  // device, ntiles + 1: first row starting at/after tile c
     bool owns = false;             // arrays allocated by the plan (copies), not borrowed from the handle
@@ -73,7 +75,7 @@ struct SpmvScratch {               // per stream: nothing in here is shared betw
 struct SpmvPlan {
     bool built = false;
     bool xcs = false;
-    int64_t opt_xcs = -1, opt_split = -1, opt_idx32 = -1, opt_tile = -1;   // option values the plan was built with
+    int64_t opt_xcs = -1, opt_split = -1, opt_idx32 = -1, opt_tile = -1, opt_sort = -1;   // option values the plan was built with
     uint32_t tile = 0;             // nnz per tile
     int idx_bytes = 8;             // width of the column ids the kernels read (handle's, or 4 for plan copies)
     CsrPiece main;                 // the whole matrix (plain plan) or its short rows (sliced plan)

@@ -66,13 +66,15 @@ def test_config1_eye_1000(hip):
     assert np.array_equal(x, y)
 
 
-@pytest.mark.parametrize("xcs,idx32", [(1, 1), (1, 0), (2, 1)], ids=["xcd-sliced-idx32", "xcd-sliced", "plain"])
+@pytest.mark.parametrize("xcs,idx32,srt", [(1, 1, 1), (1, 0, 1), (1, 1, 0), (2, 1, 1)],
+                         ids=["xcd-sliced-idx32-sorted", "xcd-sliced-sorted", "xcd-sliced-idx32", "plain"])
 @pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
-def test_rmat_vs_oracle(hip, idx, ptr, xcs, idx32):
+def test_rmat_vs_oracle(hip, idx, ptr, xcs, idx32, srt):
     import torch
     from sprs_amd import gen
     hip.set_option("spmv_xcs", xcs)       # 1: force the XCD-sliced plan, 2: plain tile kernel only
     hip.set_option("spmv_xcs_idx32", idx32)
+    hip.set_option("spmv_sort_tiles", srt)
     try:
         n = 60000
         indptr, indices, data = gen.rmat_csr(n, 16)
@@ -92,6 +94,7 @@ def test_rmat_vs_oracle(hip, idx, ptr, xcs, idx32):
     finally:
         hip.set_option("spmv_xcs", 0)
         hip.set_option("spmv_xcs_idx32", 1)
+        hip.set_option("spmv_sort_tiles", 0)
 
 
 def test_laplacian_componentwise_bound(hip):
@@ -137,6 +140,7 @@ def test_ragged_rows(hip, lens, kernel):
         x = rng.random(cols) + 0.5
         for xcs, split, idx32, tile in ((2, 64, 1, 4096), (1, 64, 1, 4096), (1, 2, 0, 2048), (1, 5000, 1, 2048),
                                         (2, 64, 1, 2048)):
+            hip.set_option("spmv_sort_tiles", 1 if split != 2 else 0)
             hip.set_option("spmv_xcs", xcs)
             hip.set_option("spmv_xcs_split", split)
             hip.set_option("spmv_xcs_idx32", idx32)
@@ -155,6 +159,7 @@ def test_ragged_rows(hip, lens, kernel):
         hip.set_option("spmv_xcs_split", 32)
         hip.set_option("spmv_xcs_idx32", 1)
         hip.set_option("spmv_tile", 0)
+        hip.set_option("spmv_sort_tiles", 0)
 
 
 def test_zero_sized(hip):
