@@ -20,6 +20,22 @@ def mul_acc_mat_vec_csr(mat, in_vec, res_vec, stream=None):
                                 res_vec.n, 1, _stream_ptr(stream)))
 
 
+def mul_acc_mat_vec_csc(mat, in_vec, res_vec, stream=None):
+    """prod::mul_acc_mat_vec_csc (prod.rs:74-99): res_vec += mat * in_vec for a CSC matrix.
+    The reference scatters column by column; on the device the matrix is converted once to CSR
+    (to_other_storage, csmat.rs:1405-1426 — cached on the Python object) and the CSR kernel
+    runs: same result up to the summation order inside a row."""
+    if not mat.is_csc():
+        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")       # prod.rs:92
+    if mat.cols() != in_vec.n or mat.rows() != res_vec.n:
+        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:88-91
+    csr = getattr(mat, "_as_csr", None)
+    if csr is None:
+        csr = mat.to_other_storage()
+        mat._as_csr = csr
+    mul_acc_mat_vec_csr(csr, in_vec, res_vec, stream)
+
+
 def csr_mulacc_dense_colmaj(lhs, rhs_cols, out_cols, stream=None):
     """prod::csr_mulacc_dense_colmaj (prod.rs:274-298) with the rhs / out given
     as lists of column vectors: out[:, j] += lhs * rhs[:, j]."""
@@ -35,8 +51,12 @@ def csmat_mul_vec(mat, vec, out=None, stream=None):
     if out is None:
         out = DeviceVec(mat.rows())
     if mat.is_csc():
-        # csmat.rs:2149-2156 uses csc_mulacc_dense_colmaj; not on the device yet
-        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")
+        # csmat.rs:2149-2156 (csc_mulacc_dense_colmaj): one conversion to CSR, then the CSR kernel
+        if mat.cols() != vec.n or mat.rows() != out.n:
+            raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
+        check(lib.sprs_hip_memset(C.c_void_p(out.ptr), 0, out.n * 8, _stream_ptr(stream)))
+        mul_acc_mat_vec_csc(mat, vec, out, stream)
+        return out
     check(lib.sprs_hip_spmv_f64(mat._h, C.c_void_p(vec.ptr), vec.n, C.c_void_p(out.ptr), out.n, 0,
                                 _stream_ptr(stream)))
     return out

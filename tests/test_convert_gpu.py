@@ -125,3 +125,22 @@ def test_slice_outer_and_transpose_view(hip, golden):
     full = (a * DeviceVec.from_host(x)).to_host()
     part = (s * DeviceVec.from_host(x)).to_host()
     assert np.array_equal(part, full[1:4])
+
+
+def test_mul_csc_vec_golden(hip, golden):
+    # prod.rs:325-373 mul_csc_vec / mul_csc_vec_ndarray, and `&A_csc * &x` (csmat.rs:2149-2156)
+    from sprs_amd import _ffi, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    fx = golden["mul_csc_vec"]
+    shape, ip, ix, dt = as_csr(fx)
+    m = DeviceCsMat.from_host(shape, ip, ix, dt, storage=_ffi.CSC)
+    x = DeviceVec.from_host(np.array(fx["x"]))
+    y = DeviceVec.zeros(5)
+    prod.mul_acc_mat_vec_csc(m, x, y)
+    assert np.all(np.abs(y.to_host() - np.array(fx["expected"])) < fx["epsilon"])
+    prod.mul_acc_mat_vec_csc(m, x, y)                                   # accumulates
+    assert np.all(np.abs(y.to_host() - 2 * np.array(fx["expected"])) < 2 * fx["epsilon"])
+    assert np.all(np.abs((m * x).to_host() - np.array(fx["expected"])) < fx["epsilon"])
+    csr = DeviceCsMat.from_host(shape, ip, ix, dt)
+    with pytest.raises(hip.SprsHipError, match="Storage mismatch"):
+        prod.mul_acc_mat_vec_csc(csr, x, y)
