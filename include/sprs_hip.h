@@ -143,6 +143,18 @@ int32_t sprs_hip_spmv_f64_host(uint64_t rows, uint64_t cols, const void *indptr,
                                const double *data, const double *x, uint64_t x_len, double *y,
                                uint64_t y_len, int32_t accumulate);
 
+/* ---- SpMM: CSR x dense row-major ------------------------------------------ */
+
+/* Twin of prod::csr_mulacc_dense_rowmaj (prod.rs:189-214), the kernel `&CsMat * &Array2` uses for
+ * a rhs of >= 8 columns (csmat.rs:2002-2016):  out[i, :] += A[i, c] * rhs[c, :]  over the stored
+ * entries of row i (accumulate != 0), or the same on a zeroed `out` (accumulate == 0).
+ * rhs_dev: rhs_rows x k doubles, row-major, leading dimension ld_rhs (>= k); out_dev: out_rows x k,
+ * leading dimension ld_out.  SPRS_HIP_DIM_MISMATCH unless A.cols == rhs_rows && A.rows == out_rows;
+ * SPRS_HIP_STORAGE_MISMATCH unless A is CSR.  Asynchronous on `stream`; deterministic. */
+int32_t sprs_hip_spmm_rowmaj_f64(const sprs_hip_csmat *a, const double *rhs_dev, uint64_t rhs_rows,
+                                 uint64_t k, uint64_t ld_rhs, double *out_dev, uint64_t out_rows,
+                                 uint64_t ld_out, int32_t accumulate, void *stream);
+
 /* ---- SpGEMM ------------------------------------------------------------- */
 
 /* Twin of smmp::mul_csr_csr (smmp.rs:196-416): C = A * B, all CSR, same index

@@ -68,6 +68,10 @@ extern "C" {
         idx_bytes: i32, data: *const f64, x: *const f64, x_len: u64, y: *mut f64, y_len: u64,
         accumulate: i32,
     ) -> i32;
+    pub fn sprs_hip_spmm_rowmaj_f64(
+        a: *const sprs_hip_csmat, rhs_dev: *const f64, rhs_rows: u64, k: u64, ld_rhs: u64,
+        out_dev: *mut f64, out_rows: u64, ld_out: u64, accumulate: i32, stream: *mut c_void,
+    ) -> i32;
     pub fn sprs_hip_spgemm_f64(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_csmat_to_other_storage(m: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_set_option(name: *const c_char, value: i64) -> i32;

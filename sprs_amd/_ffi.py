@@ -49,6 +49,7 @@ SIGNATURES = {
     "sprs_hip_csmat_free": (i32, [vp]),
     "sprs_hip_spmv_f64": (i32, [vp, vp, u64, vp, u64, i32, vp]),
     "sprs_hip_spmv_f64_host": (i32, [u64, u64, vp, i32, vp, i32, vp, vp, u64, vp, u64, i32]),
+    "sprs_hip_spmm_rowmaj_f64": (i32, [vp, vp, u64, u64, u64, vp, u64, u64, i32, vp]),
     "sprs_hip_spgemm_f64": (i32, [vp, vp, P(vp)]),
     "sprs_hip_csmat_to_other_storage": (i32, [vp, P(vp)]),
     "sprs_hip_set_option": (i32, [C.c_char_p, i64]),

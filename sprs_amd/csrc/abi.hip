@@ -373,6 +373,7 @@ int32_t sprs_hip_csmat_free(sprs_hip_csmat *m) {
     clear_error();
     if (!m) return SPRS_HIP_OK;
     m->plan.release();
+    m->mm.release();
     if (m->owns) {
         if (m->indptr) (void)hipFree(m->indptr);
         if (m->indices) (void)hipFree(m->indices);
@@ -419,6 +420,20 @@ int32_t sprs_hip_spmv_f64_host(uint64_t rows, uint64_t cols, const void *indptr,
         tl_hip_code = keep_code;
     }
     return st;
+}
+
+int32_t sprs_hip_spmm_rowmaj_f64(const sprs_hip_csmat *a, const double *rhs_dev, uint64_t rhs_rows, uint64_t k,
+                                 uint64_t ld_rhs, double *out_dev, uint64_t out_rows, uint64_t ld_out,
+                                 int32_t accumulate, void *stream) {
+    clear_error();
+    if (!a) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    // prod.rs:199-202: three dimension asserts, then storage
+    if (a->cols != rhs_rows || a->rows != out_rows) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if (a->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    if (ld_rhs < k || ld_out < k) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "leading dimension smaller than the column count");
+    if (k && ((rhs_rows && !rhs_dev) || (out_rows && !out_dev))) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL matrix");
+    return spmm_rowmaj_f64(const_cast<sprs_hip_csmat *>(a), rhs_dev, k, ld_rhs, out_dev, ld_out, accumulate != 0,
+                           (hipStream_t)stream);
 }
 
 int32_t sprs_hip_spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {

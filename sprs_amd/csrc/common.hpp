@@ -90,6 +90,17 @@ struct SpmvPlan {
 
 int32_t exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, hipStream_t stream);   // scan.hip
 
+// ---- SpMM plan: rows cut into chunks of <= 512 entries (spmm.hip) -------------------------------
+struct SpmmPlan {
+    bool built = false;
+    uint64_t nchunks = 0, n_multi = 0;
+    uint64_t *first_chunk = nullptr;   // device, rows + 1
+    uint64_t *chunk_row = nullptr;     // device, nchunks
+    uint64_t *multi_rows = nullptr;    // device, rows spanning several chunks
+    std::unordered_map<void *, std::pair<double *, uint64_t>> partial;   // per stream: buffer, bytes
+    void release();
+};
+
 }  // namespace sprs_hip
 
 // Device twin of CsMatBase (sprs/src/sparse.rs:94-122).
@@ -104,6 +115,7 @@ struct sprs_hip_csmat {
     int device = 0;
     std::mutex mu;             // guards plan
     sprs_hip::SpmvPlan plan;
+    sprs_hip::SpmmPlan mm;
 
     uint64_t outer() const { return storage == SPRS_HIP_CSR ? rows : cols; }
     uint64_t inner() const { return storage == SPRS_HIP_CSR ? cols : rows; }
@@ -115,6 +127,9 @@ namespace sprs_hip {
 int32_t spmv_f64(sprs_hip_csmat *a, const double *x, double *y, bool accumulate, hipStream_t stream);
 // spgemm.hip
 int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c);
+// spmm.hip
+int32_t spmm_rowmaj_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, double *out,
+                        uint64_t ld_out, bool accumulate, hipStream_t stream);
 // convert.hip
 int32_t to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out);
 int32_t slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end, sprs_hip_csmat **out);

@@ -181,6 +181,8 @@ class DeviceCsMat:
             return prod.csmat_mul_vec(self, rhs)          # csmat.rs:2119-2160
         if isinstance(rhs, DeviceCsMat):
             return prod.csmat_mul_csmat(self, rhs)        # csmat.rs:1866-1949
+        if isinstance(rhs, prod.DeviceMat):
+            return prod.csmat_mul_dense(self, rhs)        # csmat.rs:1989-2048
         return NotImplemented
 
     __matmul__ = __mul__

@@ -45,6 +45,42 @@ def csr_mulacc_dense_colmaj(lhs, rhs_cols, out_cols, stream=None):
         mul_acc_mat_vec_csr(lhs, r, o, stream)
 
 
+class DeviceMat:
+    """Dense row-major f64 matrix in HBM (what `Array2<f64>` in standard layout is on the host)."""
+
+    def __init__(self, rows, cols, vec=None):
+        self.rows, self.cols = int(rows), int(cols)
+        self.vec = vec if vec is not None else DeviceVec.zeros(self.rows * self.cols)
+        assert self.vec.n == self.rows * self.cols
+
+    @classmethod
+    def from_host(cls, arr):
+        import numpy as np
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        return cls(arr.shape[0], arr.shape[1], DeviceVec.from_host(arr.reshape(-1)))
+
+    def to_host(self):
+        return self.vec.to_host().reshape(self.rows, self.cols)
+
+
+def csr_mulacc_dense_rowmaj(lhs, rhs, out, stream=None):
+    """prod::csr_mulacc_dense_rowmaj (prod.rs:189-214): out += lhs * rhs, rhs/out dense row-major."""
+    if rhs.cols != out.cols:
+        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:201
+    check(lib.sprs_hip_spmm_rowmaj_f64(lhs._h, C.c_void_p(rhs.vec.ptr), rhs.rows, rhs.cols, rhs.cols,
+                                       C.c_void_p(out.vec.ptr), out.rows, out.cols, 1, _stream_ptr(stream)))
+
+
+def csmat_mul_dense(mat, rhs, stream=None):
+    """`&CsMat * &Array2` (csmat.rs:1989-2048) for a CSR lhs: fresh zero result; >= 8 columns use the
+    row-major kernel, fewer go column by column like csr_mulacc_dense_colmaj (prod.rs:274-298) —
+    here through one strided pass of the same kernel, the result stays row-major."""
+    out = DeviceMat(mat.rows(), rhs.cols, DeviceVec(mat.rows() * rhs.cols))
+    check(lib.sprs_hip_spmm_rowmaj_f64(mat._h, C.c_void_p(rhs.vec.ptr), rhs.rows, rhs.cols, rhs.cols,
+                                       C.c_void_p(out.vec.ptr), out.rows, out.cols, 0, _stream_ptr(stream)))
+    return out
+
+
 def csmat_mul_vec(mat, vec, out=None, stream=None):
     """`&CsMat * &Array1` (csmat.rs:2119-2160): fresh zero result, CSR goes
     through csr_mulacc_dense_colmaj with one column."""

@@ -1,0 +1,101 @@
+"""GPU parity tests of the SpMM path (prod::csr_mulacc_dense_rowmaj twin, prod.rs:189-214) against
+the reference's golden vectors and the oracle (SpMM == SpMV per rhs column, prod.rs:274-298)."""
+import numpy as np
+import pytest
+
+from conftest import IDX_COMBOS, as_csr
+from helpers import ragged_csr, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import sprs_amd
+    if sprs_amd.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need the MI355X (no CPU fallback exists)")
+    return sprs_amd
+
+
+def oracle_spmm(shape, ip, ix, dt, rhs, out0=None):
+    from oracle import oracle
+    out = np.zeros((shape[0], rhs.shape[1])) if out0 is None else out0.copy()
+    for j in range(rhs.shape[1]):
+        col = np.ascontiguousarray(out[:, j])
+        oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, np.ascontiguousarray(rhs[:, j]), col)
+        out[:, j] = col
+    return out
+
+
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_golden_mul_csr_dense_rowmaj(hip, golden, idx, ptr):
+    # prod.rs:502-542: eye(3) * eye(3); mat1 * mat_dense1 (exact); mat5 * mat_dense2 (eps 1e-8)
+    from sprs_amd import prod
+    from sprs_amd.device import DeviceCsMat
+    e = DeviceCsMat.eye(3)
+    a = prod.DeviceMat.from_host(np.eye(3))
+    res = prod.DeviceMat(3, 3)
+    prod.csr_mulacc_dense_rowmaj(e, a, res)
+    assert np.array_equal(res.to_host(), np.eye(3))
+    for mk, dk, ek in (("mat1", "mat_dense1", "mat1_times_mat_dense1"), ("mat5", "mat_dense2", "mat5_times_mat_dense2")):
+        m = DeviceCsMat.from_host(*as_csr(golden[mk], idx, ptr))
+        b = prod.DeviceMat.from_host(np.array(golden[dk]))
+        exp = np.array(golden[ek]["rows"])
+        res = prod.DeviceMat(exp.shape[0], exp.shape[1])
+        prod.csr_mulacc_dense_rowmaj(m, b, res)
+        assert np.all(np.abs(res.to_host() - exp) <= golden[ek]["epsilon"])
+        c = (m * b).to_host()                                  # `&a * &b` (csmat.rs:1989-2048)
+        assert np.all(np.abs(c - exp) <= golden[ek]["epsilon"])
+        prod.csr_mulacc_dense_rowmaj(m, b, res)                # accumulates
+        assert np.all(np.abs(res.to_host() - 2 * exp) <= 2 * golden[ek]["epsilon"] + 1e-12)
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 16, 33, 64, 100])
+def test_rmat_vs_oracle(hip, k):
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat
+    n = 30000
+    indptr, indices, data = gen.rmat_csr(n, 10, seed=13)        # rows longer than one 512-entry chunk too
+    ip, ix, dt = indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy()
+    assert int(np.diff(ip.astype(np.int64)).max()) > 1500
+    rng = np.random.default_rng(k)
+    rhs = rng.random((n, k)) + 0.5
+    a = DeviceCsMat.from_host((n, n), ip, ix, dt)
+    got = (a * prod.DeviceMat.from_host(rhs)).to_host()
+    ref = oracle_spmm((n, n), ip, ix, dt, rhs)
+    assert rel_err(got, ref) <= TOL
+    empty = np.diff(ip.astype(np.int64)) == 0
+    assert empty.any() and np.all(got[empty] == 0.0)
+    out0 = rng.random((n, k))
+    res = prod.DeviceMat.from_host(out0)
+    prod.csr_mulacc_dense_rowmaj(a, prod.DeviceMat.from_host(rhs), res)
+    got2 = res.to_host()
+    assert rel_err(got2, oracle_spmm((n, n), ip, ix, dt, rhs, out0)) <= TOL
+    assert np.array_equal(got2[empty], out0[empty])             # empty rows untouched
+    again = (a * prod.DeviceMat.from_host(rhs)).to_host()
+    assert np.array_equal(got, again)                           # deterministic
+
+
+def test_ragged_and_contract(hip, golden):
+    from sprs_amd import SprsHipError, _ffi, prod
+    from sprs_amd.device import DeviceCsMat
+    lens = [0, 511, 512, 513, 0, 1, 2000, 3, 0]
+    shape, ip, ix, dt = ragged_csr(lens, 5000, seed=2, positive=False)
+    rng = np.random.default_rng(0)
+    rhs = rng.standard_normal((5000, 12))
+    a = DeviceCsMat.from_host(shape, ip, ix, dt)
+    got = (a * prod.DeviceMat.from_host(rhs)).to_host()
+    ref = oracle_spmm(shape, ip, ix, dt, rhs)
+    bound = oracle_spmm(shape, ip, ix, np.abs(dt), np.abs(rhs))
+    assert np.all(np.abs(got - ref) <= TOL * bound)
+    m = DeviceCsMat.from_host(*as_csr(golden["mat3"]))           # 5 x 4
+    with pytest.raises(SprsHipError, match="Dimension mismatch") as e:      # prod.rs:199-201
+        prod.csr_mulacc_dense_rowmaj(m, prod.DeviceMat(5, 3), prod.DeviceMat(5, 3))
+    assert e.value.status == _ffi.DIM_MISMATCH
+    with pytest.raises(SprsHipError, match="Dimension mismatch"):
+        prod.csr_mulacc_dense_rowmaj(m, prod.DeviceMat(4, 3), prod.DeviceMat(5, 2))
+    shape, ip, ix, dt = as_csr(golden["mat1_csc"])
+    csc = DeviceCsMat.from_host(shape, ip, ix, dt, storage=_ffi.CSC)
+    with pytest.raises(SprsHipError, match="Storage mismatch"):             # prod.rs:202
+        prod.csr_mulacc_dense_rowmaj(csc, prod.DeviceMat(5, 2), prod.DeviceMat(5, 2))
