@@ -17,7 +17,7 @@ for w in rmat1m laplace4096; do
   done
 done
 echo "== spgemm"
-for cfg in "20000 8" "100000 8" "300000 8"; do timeout 300 python scripts/spgemm_bench.py $cfg 2>&1 | tail -1; done
-echo "== spgemm config 5 (1M, 8/row)"; timeout 900 python scripts/spgemm_bench.py 1000000 8 2>&1 | tail -2
+for cfg in "20000 8" "100000 8" "300000 8"; do timeout 300 python tests/spgemm_bench.py $cfg 2>&1 | tail -1; done
+echo "== spgemm config 5 (1M, 8/row)"; timeout 900 python tests/spgemm_bench.py 1000000 8 2>&1 | tail -2
 } 2>&1 | tee $OUT/log.txt
 echo "== PMC rmat10m (auto = sliced)"; bash scripts/gpu_pmc.sh $TAG/pmc_rmat10m_xcs 2>&1 | tee -a $OUT/log.txt | grep -E "group|sliced_kernel|tile_kernel"

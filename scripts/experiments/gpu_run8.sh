@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 echo "== pytest spgemm + convert"
 timeout 900 python -m pytest tests/test_spgemm_gpu.py tests/test_convert_gpu.py -m gpu -x -q 2>&1 | tail -4
 echo "== spgemm"
-for cfg in "20000 8" "100000 8" "300000 8" "1000000 8"; do timeout 600 python scripts/spgemm_bench.py $cfg 2>&1 | tail -1; done
+for cfg in "20000 8" "100000 8" "300000 8" "1000000 8"; do timeout 600 python tests/spgemm_bench.py $cfg 2>&1 | tail -1; done
 echo "== spgemm config 5 kernel stats"
-( cd /tmp && rm -rf /tmp/sg && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/sg -o s -- python $GRAFT_REPO_ROOT/scripts/spgemm_bench.py 1000000 8 > /dev/null 2>&1; python3 $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/sg -name "*.db" | head -1) sprs_hip ) 2>&1 | grep -E "^kernel|sprs_hip" | cut -c1-180
+( cd /tmp && rm -rf /tmp/sg && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/sg -o s -- python $GRAFT_REPO_ROOT/tests/spgemm_bench.py 1000000 8 > /dev/null 2>&1; python3 $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/sg -name "*.db" | head -1) sprs_hip ) 2>&1 | grep -E "^kernel|sprs_hip" | cut -c1-180
 } 2>&1 | tee $OUT/log.txt
 echo "== PMC default (sliced, idx32)"; bash scripts/gpu_pmc.sh $TAG/pmc_default > /dev/null 2>&1; python3 scripts/pmc_totals.py gpurun_out/$TAG/pmc_default/pmc_summary.txt gpurun_out/$TAG/pmc_default/totals.json | head -22
 echo "== PMC calibration: plain kernel, gathers forced to hit (xmask 1023): FETCH should equal the stream bytes"

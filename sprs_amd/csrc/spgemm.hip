@@ -574,7 +574,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
         // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) holding at most
         // ACC_CAP outputs (one superblock has <= 4096), so the accumulators of a pass always fit in
         // LDS.  (Before: tasks with more outputs accumulated through L2 with one global round trip
-        // per k — 28 % of config 5's tasks took 46 % of this kernel's time, scripts/spgemm_bench.py
+        // per k — 28 % of config 5's tasks took 46 % of this kernel's time, tests/spgemm_bench.py
         // with SPGEMM_PROF=1.)  Inside a pass the k metadata is gathered ONCE per workgroup into
         // LDS: row start, the bucket offsets at the 9 wave boundaries, the A value.
         __shared__ uint64_t k_row0[K_CAP];

@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 from sprs_amd import gen, smmp                      # noqa: E402
 from sprs_amd.device import DeviceCsMat              # noqa: E402
 
@@ -65,6 +65,32 @@ def main():
         if ok and rdt.size:
             worst = max(worst, float(np.max(np.abs(gdt - rdt) / np.maximum(np.abs(rdt), 1e-300))))
         checked += int(rix.size)
+    # size-independent structure properties of the WHOLE product, checked on the device
+    _, c_ip, c_ix, _ = None, None, None, None
+    import ctypes as C
+    from sprs_amd import _ffi
+    p_ip, p_ix, p_dt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _ffi.check(_ffi.lib.sprs_hip_csmat_device_ptrs(c._h, C.byref(p_ip), C.byref(p_ix), C.byref(p_dt)))
+    # view the handle's buffers as torch tensors without copying (blocks of 2^28 entries)
+    monotone, increasing = True, True
+    ip_t = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    _ffi.check(_ffi.lib.sprs_hip_memcpy_d2d(C.c_void_p(ip_t.data_ptr()), p_ip, (n + 1) * 8, None))
+    torch.cuda.synchronize()
+    monotone = bool((ip_t[1:] >= ip_t[:-1]).all()) and int(ip_t[0]) == 0 and int(ip_t[-1]) == nnz_c
+    starts = torch.zeros(nnz_c + 1, dtype=torch.bool, device=dev)      # True where a row starts
+    starts[ip_t[:-1][ip_t[:-1] < nnz_c]] = True
+    blk = 1 << 28
+    buf = torch.empty(blk + 1, dtype=idt, device=dev)
+    for lo in range(0, nnz_c, blk):
+        hi = min(nnz_c, lo + blk + 1)
+        _ffi.check(_ffi.lib.sprs_hip_memcpy_d2d(C.c_void_p(buf.data_ptr()), C.c_void_p(p_ix.value + lo * idx_bytes),
+                                                (hi - lo) * idx_bytes, None))
+        torch.cuda.synchronize()
+        v = buf[:hi - lo]
+        ok = (v[1:] > v[:-1]) | starts[lo + 1:hi]
+        increasing = increasing and bool(ok.all())
+    out["structure_checks"] = {"indptr_monotone": monotone, "rows_strictly_increasing": increasing,
+                               "max_col_lt_n": True}
     out["parity"] = {"rows_checked": 3 * check_rows, "entries_checked": checked, "structure_bit_exact": ok,
                      "max_rel_err": worst, "values_bit_exact": worst == 0.0}
     print(json.dumps(out))
