@@ -66,7 +66,6 @@ def main():
             worst = max(worst, float(np.max(np.abs(gdt - rdt) / np.maximum(np.abs(rdt), 1e-300))))
         checked += int(rix.size)
     # size-independent structure properties of the WHOLE product, checked on the device
-    _, c_ip, c_ix, _ = None, None, None, None
     import ctypes as C
     from sprs_amd import _ffi
     p_ip, p_ix, p_dt = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -87,8 +86,8 @@ def main():
                                                 (hi - lo) * idx_bytes, None))
         torch.cuda.synchronize()
         v = buf[:hi - lo]
-        ok = (v[1:] > v[:-1]) | starts[lo + 1:hi]
-        increasing = increasing and bool(ok.all())
+        good = (v[1:] > v[:-1]) | starts[lo + 1:hi]
+        increasing = increasing and bool(good.all())
     out["structure_checks"] = {"indptr_monotone": monotone, "rows_strictly_increasing": increasing,
                                "max_col_lt_n": True}
     out["parity"] = {"rows_checked": 3 * check_rows, "entries_checked": checked, "structure_bit_exact": ok,
