@@ -127,6 +127,17 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
+// value of `v` in lane `src`, `src` wave-uniform: v_readlane (a few cycles) instead of the
+// ds_bpermute (an LDS round trip, ~100+ cycles) that __shfl with a variable index compiles to
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), src));
+}
+
 __device__ __forceinline__ uint32_t hash_slot(uint32_t c, int lg) { return (c * 0x9E3779B1u) >> (32 - lg); }
 
 __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }
@@ -315,8 +326,8 @@ __device__ __forceinline__ void set_window_bits(const CsrView<IDX, PTR> &A, cons
             uint64_t sj[PF], ej[PF], cc[PF];
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
-                sj[d] = __shfl(s, js[d], WAVE);
-                ej[d] = __shfl(e, js[d], WAVE);
+                sj[d] = readlane_u64(s, js[d]);
+                ej[d] = readlane_u64(e, js[d]);
                 cc[d] = 0;
                 if (d < n && sj[d] + lane < ej[d]) cc[d] = (uint64_t)B.indices[sj[d] + lane];
             }
@@ -497,6 +508,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     uint64_t chi = wlo + (uint64_t)sb_hi * (SUPER_WORDS * 64);
     if (chi > whi) chi = whi;
 
+    uint32_t n_steps = 0, n_entries = 0;            // profiling only
     // apply one batch of up to 64 sub-ranges [s,e) (lane j holds k_j's), ascending j == ascending k
     auto apply_batch = [&](uint64_t s, uint64_t e, double av) {
         // PF steps (k's) are loaded together before any of them is applied: a step's entries
@@ -504,6 +516,10 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
         // a time left the CU 85 % idle.  Application order stays ascending k.
         constexpr int PF = 8;
         unsigned long long live = __ballot(e > s);
+        if (prof) {
+            n_steps += (uint32_t)__popcll(live);
+            n_entries += (uint32_t)wave_sum_u64(e - s);
+        }
         while (live) {
             int js[PF];
             int n = 0;
@@ -521,8 +537,8 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
             double vv[PF];
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
-                sj[d] = __shfl(s, js[d], WAVE);
-                ej[d] = __shfl(e, js[d], WAVE);
+                sj[d] = readlane_u64(s, js[d]);
+                ej[d] = readlane_u64(e, js[d]);
                 cc[d] = 0;
                 vv[d] = 0.0;
                 if (d < n && sj[d] + lane < ej[d]) {
@@ -533,7 +549,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
 #pragma unroll
             for (int d = 0; d < PF; ++d) {
                 if (d < n) {                                  // wave-uniform
-                    const double avj = __shfl(av, js[d], WAVE);
+                    const double avj = readlane_f64(av, js[d]);
                     for (uint64_t b = sj[d] + lane; b < ej[d]; b += WAVE) {
                         uint64_t c;
                         double bv;
@@ -610,6 +626,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                         }
                     }
                     __syncthreads();
+                    mark(8);
                     if (mine) {
                         for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
                             const uint32_t j = j0 + lane;
@@ -624,13 +641,19 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                         }
                     }
                     __syncthreads();
+                    mark(9);
                 }
                 for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
                 __syncthreads();
+                mark(10);
+                if (prof && tid == 0) atomicAdd(&prof[11], 1ull);
             }
             pb = pe;
         }
-        mark(3);
+        if (prof && lane == 0) {
+            atomicAdd(&prof[12], (unsigned long long)n_steps);
+            atomicAdd(&prof[13], (unsigned long long)n_entries);
+        }
     } else if (sb_hi > sb_lo && clo < chi) {
         for (uint64_t p0 = as; p0 < ae; p0 += WAVE) {
             const uint64_t p = p0 + lane;
@@ -767,8 +790,8 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     // ---- numeric -------------------------------------------------------------
     DevBuf prof;
     if (options().spgemm_prof) {
-        SPRS_TRY_HIP(prof.alloc(64));
-        SPRS_TRY_HIP(hipMemsetAsync(prof.p, 0, 64, stream));
+        SPRS_TRY_HIP(prof.alloc(128));
+        SPRS_TRY_HIP(hipMemsetAsync(prof.p, 0, 128, stream));
     }
     if (n_small)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true>), small_grid(), dim3(SM_BLOCK), 0, stream, A, B,
@@ -786,12 +809,17 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         return fail_hip(e, "spgemm numeric");
     }
     if (prof.p) {
-        unsigned long long h[8];
-        if (hipMemcpy(h, prof.p, 64, hipMemcpyDeviceToHost) == hipSuccess)
+        unsigned long long h[16];
+        if (hipMemcpy(h, prof.p, 128, hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr,
+                    "[spgemm_prof] inside accumulate: staging %llu, apply %llu, writeback %llu cycles; passes %llu, "
+                    "k-steps %llu (all waves), entries %llu\n",
+                    h[8], h[9], h[10], h[11], h[12], h[13]);
             fprintf(stderr,
                     "[spgemm_prof] thread-0 cycles summed over large tasks: bits %llu, prefix+emit %llu, prodcount %llu, "
                     "accumulate(LDS) %llu, accumulate(L2) %llu, writeback %llu; tasks LDS %llu, L2 %llu\n",
                     h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        }
     }
     *c_out = c;
     return SPRS_HIP_OK;
