@@ -116,6 +116,11 @@ int32_t sprs_hip_csmat_download_outer(const sprs_hip_csmat *m, uint64_t start, u
  * this is how the multi-GPU path cuts row blocks. */
 int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end,
                                    sprs_hip_csmat **out);
+/* Handles are immutable snapshots, like a `&CsMat`: the multiply plans cached inside a handle
+ * (tile index, XCD-sliced copy, SpMM chunks) are derived from its arrays on first use.  After
+ * modifying the arrays of a WRAPPED handle in place (sprs_hip_csmat_wrap_device), call this to drop
+ * the cached plans; they are rebuilt by the next multiply. */
+int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m);
 /* transpose_view (csmat.rs:982-991): free, shares the buffers, flips storage + shape */
 int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **out);
 int32_t sprs_hip_csmat_free(sprs_hip_csmat *m);

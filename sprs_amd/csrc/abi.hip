@@ -350,6 +350,16 @@ int32_t sprs_hip_csmat_download_outer(const sprs_hip_csmat *m, uint64_t start, u
     return SPRS_HIP_OK;
 }
 
+int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m) {
+    clear_error();
+    if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    SPRS_TRY_HIP(hipDeviceSynchronize());     // nothing in flight may still read the plan copies
+    std::lock_guard<std::mutex> lock(m->mu);
+    m->plan.release();
+    m->mm.release();
+    return SPRS_HIP_OK;
+}
+
 int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
     clear_error();
     if (!m || !out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");

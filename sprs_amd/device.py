@@ -162,6 +162,10 @@ class DeviceCsMat:
         check(lib.sprs_hip_csmat_slice_outer(self._h, start, end, C.byref(h)))
         return DeviceCsMat(h.value)
 
+    def refresh(self):
+        """Drop the cached multiply plans after the wrapped device arrays were modified in place."""
+        check(lib.sprs_hip_csmat_refresh(self._h))
+
     def transpose_view(self):
         """csmat.rs:982-991: free, shares buffers."""
         h = C.c_void_p()

@@ -337,3 +337,29 @@ def test_virtual_ranks_row_partition(hip, parts):
     assert rel_err(y, whole) <= 1e-14
     nnz_blocks = [int(ip[cuts[g + 1]] - ip[cuts[g]]) for g in range(parts)]
     assert max(nnz_blocks) <= ix.size / parts + int(np.diff(ip.astype(np.int64)).max())
+
+
+def test_refresh_after_in_place_update(hip):
+    """A wrapped handle caches plan copies of its arrays (XCD-sliced plan): after the caller scales the
+    values in place, refresh() makes the next multiply see them."""
+    import torch
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    dev = torch.device("cuda", 0)
+    n = 60000
+    indptr, indices, data = gen.rmat_csr(n, 16, device=dev)
+    x = gen.dense_vector(n, device=dev)
+    hip.set_option("spmv_xcs", 1)
+    try:
+        a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+        y1 = torch.empty(n, dtype=torch.float64, device=dev)
+        prod.csmat_mul_vec(a, DeviceVec.borrow(x), out=DeviceVec.borrow(y1))
+        torch.cuda.synchronize()
+        data.mul_(2.0)
+        a.refresh()
+        y2 = torch.empty(n, dtype=torch.float64, device=dev)
+        prod.csmat_mul_vec(a, DeviceVec.borrow(x), out=DeviceVec.borrow(y2))
+        torch.cuda.synchronize()
+    finally:
+        hip.set_option("spmv_xcs", 0)
+    assert torch.equal(y2, 2.0 * y1)          # scaling by 2 is exact in binary floating point
