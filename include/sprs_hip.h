@@ -71,6 +71,12 @@ int32_t sprs_hip_memcpy_d2h(void *host_dst, const void *dev_src, uint64_t bytes)
 int32_t sprs_hip_memcpy_d2d(void *dev_dst, const void *dev_src, uint64_t bytes, void *stream);
 int32_t sprs_hip_memset(void *dev_dst, int32_t byte_value, uint64_t bytes, void *stream);
 int32_t sprs_hip_synchronize(void *stream); /* NULL = whole device */
+/* Result matrices (sprs_hip_spgemm_f64, sprs_hip_csmat_to_other_storage, uploads) take their index/value
+ * blocks from a pool of previously released ones and return them there on sprs_hip_csmat_free (options
+ * "pool" = 1, "pool_max_bytes"): the driver needs seconds to re-issue tens of GB that were just freed.
+ * sprs_hip_pool_trim hands everything cached back to the driver (Rust analogue: dropping the CsMat really
+ * frees — call this where that matters, e.g. before another library needs the memory). */
+int32_t sprs_hip_pool_trim(uint64_t *freed_bytes /* may be NULL */);
 
 /* ---- device CSR/CSC container: twin of CsMatBase (sparse.rs:94-122) ---- */
 

@@ -18,6 +18,15 @@ def device_count():
     return n.value if st == _ffi.OK else 0
 
 
+def pool_trim():
+    """Hand the pooled result blocks back to the driver (include/sprs_hip.h: sprs_hip_pool_trim);
+    returns the number of bytes released."""
+    import ctypes
+    freed = ctypes.c_uint64(0)
+    _ffi.check(_ffi.lib.sprs_hip_pool_trim(ctypes.byref(freed)))
+    return int(freed.value)
+
+
 def set_option(name, value):
     _ffi.check(_ffi.lib.sprs_hip_set_option(name.encode(), int(value)))
 

@@ -38,6 +38,7 @@ SIGNATURES = {
     "sprs_hip_memcpy_d2d": (i32, [vp, vp, u64, vp]),
     "sprs_hip_memset": (i32, [vp, i32, u64, vp]),
     "sprs_hip_synchronize": (i32, [vp]),
+    "sprs_hip_pool_trim": (i32, [P(u64)]),
     "sprs_hip_csmat_upload": (i32, [P(vp), i32, u64, u64, vp, i32, vp, i32, vp, i32]),
     "sprs_hip_csmat_wrap_device": (i32, [P(vp), i32, u64, u64, u64, vp, i32, vp, i32, vp]),
     "sprs_hip_csmat_info": (i32, [vp, P(u64), P(u64), P(u64), P(i32), P(i32), P(i32)]),

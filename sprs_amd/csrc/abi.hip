@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include <map>
 
 namespace sprs_hip {
 
@@ -47,6 +48,82 @@ int32_t fail_hip(hipError_t e, const char *what) {
 Options &options() {
     static Options o;
     return o;
+}
+
+// ---- pool of released result blocks ------------------------------------------------------------
+// A product like config 5's is 2 x 26.5 GB.  The driver hands such blocks out in ~30 ms the first
+// time, but takes SECONDS when the same amount has just been released (measured 2.0-3.4 s for the
+// second A*A of a process, against 0.23 s of kernels: profiles/r01z_spgemm_v3_sweep.txt) — a loop
+// that forms a product per iteration would spend 90 % of its time there.  Owned blocks of >= 1 MiB
+// therefore go back to a per-device pool and the next result takes the best fit (<= 25 % slack).
+// hipFree synchronises the device before a block can be reused; so does pool_free.
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::multimap<std::pair<int, uint64_t>, void *> blocks;   // (device, bytes) -> block
+    uint64_t cached = 0;
+};
+Pool &pool() {
+    static Pool p;
+    return p;
+}
+constexpr uint64_t POOL_MIN = 1ull << 20;
+}  // namespace
+
+uint64_t pool_trim() {
+    Pool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    const uint64_t freed = p.cached;
+    for (auto &kv : p.blocks) (void)hipFree(kv.second);
+    p.blocks.clear();
+    p.cached = 0;
+    return freed;
+}
+
+uint64_t pool_cached_bytes() {
+    Pool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    return p.cached;
+}
+
+hipError_t pool_alloc(void **out, uint64_t bytes, uint64_t *cap, int device) {
+    if (bytes == 0) bytes = 8;       // hipMalloc(0) returns nullptr; kernels never see NULL
+    if (options().pool && bytes >= POOL_MIN) {
+        Pool &p = pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        auto it = p.blocks.lower_bound({device, bytes});
+        if (it != p.blocks.end() && it->first.first == device && it->first.second <= bytes + bytes / 4) {
+            *out = it->second;
+            *cap = it->first.second;
+            p.cached -= it->first.second;
+            p.blocks.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory && pool_trim()) {
+        (void)hipGetLastError();
+        e = hipMalloc(out, bytes);
+    }
+    *cap = bytes;
+    return e;
+}
+
+void pool_free(void *ptr, uint64_t cap, int device) {
+    if (!ptr) return;
+    if (options().pool && cap >= POOL_MIN) {
+        Pool &p = pool();
+        // the block may still be read by kernels in flight: same guarantee as hipFree
+        if (hipDeviceSynchronize() == hipSuccess) {
+            std::lock_guard<std::mutex> g(p.mu);
+            if (p.cached + cap <= (uint64_t)options().pool_max_bytes) {
+                p.blocks.insert({{device, cap}, ptr});
+                p.cached += cap;
+                return;
+            }
+        }
+    }
+    (void)hipFree(ptr);
 }
 
 void SpmvPlan::release() {
@@ -98,13 +175,12 @@ int32_t alloc_csmat(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64
     m->owns = true;
     hipError_t e = hipGetDevice(&m->device);
     if (e == hipSuccess) e = hipMalloc(&m->indptr, (m->outer() + 1) * (uint64_t)iptr_bytes);
-    // hipMalloc(0) is legal but returns nullptr; keep one element so kernels never see NULL
-    if (e == hipSuccess) e = hipMalloc(&m->indices, (nnz ? nnz : 1) * (uint64_t)idx_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&m->data, (nnz ? nnz : 1) * sizeof(double));
+    if (e == hipSuccess) e = pool_alloc(&m->indices, nnz * (uint64_t)idx_bytes, &m->cap_indices, m->device);
+    if (e == hipSuccess) e = pool_alloc((void **)&m->data, nnz * sizeof(double), &m->cap_data, m->device);
     if (e != hipSuccess) {
         if (m->indptr) (void)hipFree(m->indptr);
-        if (m->indices) (void)hipFree(m->indices);
-        if (m->data) (void)hipFree(m->data);
+        pool_free(m->indices, m->cap_indices, m->device);
+        pool_free(m->data, m->cap_data, m->device);
         delete m;
         return fail_hip(e, "alloc_csmat");
     }
@@ -200,6 +276,13 @@ int32_t sprs_hip_memcpy_d2d(void *dev_dst, const void *dev_src, uint64_t bytes, 
 int32_t sprs_hip_memset(void *dev_dst, int32_t byte_value, uint64_t bytes, void *stream) {
     clear_error();
     if (bytes) SPRS_TRY_HIP(hipMemsetAsync(dev_dst, byte_value, bytes, (hipStream_t)stream));
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_pool_trim(uint64_t *freed_bytes) {
+    clear_error();
+    const uint64_t f = pool_trim();
+    if (freed_bytes) *freed_bytes = f;
     return SPRS_HIP_OK;
 }
 
@@ -386,8 +469,8 @@ int32_t sprs_hip_csmat_free(sprs_hip_csmat *m) {
     m->mm.release();
     if (m->owns) {
         if (m->indptr) (void)hipFree(m->indptr);
-        if (m->indices) (void)hipFree(m->indices);
-        if (m->data) (void)hipFree(m->data);
+        pool_free(m->indices, m->cap_indices, m->device);
+        pool_free(m->data, m->cap_data, m->device);
     }
     delete m;
     return SPRS_HIP_OK;
@@ -496,6 +579,15 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         o.spgemm_bucket = value ? 1 : 0;
     } else if (!strcmp(name, "spgemm_prof")) {
         o.spgemm_prof = value ? 1 : 0;
+    } else if (!strcmp(name, "spgemm_winlog")) {
+        if (value < 16 || value > 19) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_winlog must be 16..19");
+        o.spgemm_winlog = value;
+    } else if (!strcmp(name, "pool")) {
+        o.pool = value ? 1 : 0;
+        if (!value) (void)pool_trim();
+    } else if (!strcmp(name, "pool_max_bytes")) {
+        if (value < 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "pool_max_bytes must be >= 0");
+        o.pool_max_bytes = value;
     } else if (!strcmp(name, "spgemm_heavy")) {
         if (value < 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_heavy must be >= 1024");
         o.spgemm_heavy = value;
@@ -523,6 +615,10 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_bucket")) *value = o.spgemm_bucket;
     else if (!strcmp(name, "spgemm_prof")) *value = o.spgemm_prof;
     else if (!strcmp(name, "spgemm_heavy")) *value = o.spgemm_heavy;
+    else if (!strcmp(name, "pool")) *value = o.pool;
+    else if (!strcmp(name, "pool_max_bytes")) *value = o.pool_max_bytes;
+    else if (!strcmp(name, "pool_cached_bytes")) *value = (int64_t)pool_cached_bytes();
+    else if (!strcmp(name, "spgemm_winlog")) *value = o.spgemm_winlog;
     else if (!strcmp(name, "spmv_lds_pad")) *value = o.spmv_lds_pad;
     else if (!strcmp(name, "spmv_xmask")) *value = o.spmv_xmask;
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);

@@ -46,7 +46,10 @@ struct Options {
     int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
     int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
+    int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)
     int64_t spgemm_heavy = 65536;  // SpGEMM: target products per task of a heavy row (narrower column windows)
+    int64_t pool = 1;              // keep released result blocks (>= 1 MiB) for the next result instead of hipFree
+    int64_t pool_max_bytes = 128ll << 30;   // cap on the bytes the pool may hold
     int64_t spmv_lds_pad = 0;      // extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning)
     int64_t spmv_xmask = -1;       // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
 };
@@ -112,6 +115,7 @@ struct sprs_hip_csmat {
     void *indices = nullptr;   // device, nnz entries
     double *data = nullptr;    // device, nnz entries
     bool owns = false;
+    uint64_t cap_indices = 0, cap_data = 0;   // bytes of the owned blocks (>= what nnz needs: blocks come from the pool)
     int device = 0;
     std::mutex mu;             // guards plan
     sprs_hip::SpmvPlan plan;
@@ -122,6 +126,12 @@ struct sprs_hip_csmat {
 };
 
 namespace sprs_hip {
+
+// abi.hip: result-block pool
+hipError_t pool_alloc(void **p, uint64_t bytes, uint64_t *cap, int device);
+void pool_free(void *p, uint64_t cap, int device);
+uint64_t pool_trim();
+uint64_t pool_cached_bytes();
 
 // spmv.hip
 int32_t spmv_f64(sprs_hip_csmat *a, const double *x, double *y, bool accumulate, hipStream_t stream);

@@ -46,17 +46,28 @@ constexpr uint64_t SMALL_MAX = 512;       // products per row handled by the wav
 constexpr int SMALL_TAB = 1024;           // hash slots per wave (load factor <= 0.5)
 constexpr int SM_BLOCK = 256;             // 4 waves
 constexpr int SM_WAVES = SM_BLOCK / WAVE;
-constexpr int WIN_LOG2 = 19;              // columns per window
-constexpr uint64_t WIN = 1ull << WIN_LOG2;
-constexpr int WORDS = (int)(WIN / 64);    // 8192 64-bit words = 64 KiB
+constexpr int MAX_WIN_LOG2 = 19;          // widest column window of a large-row task (option spgemm_winlog <= this)
 constexpr int LG_BLOCK = 512;             // 8 waves
 constexpr int LG_WAVES = LG_BLOCK / WAVE;
-constexpr int WORDS_PER_THREAD = WORDS / LG_BLOCK;   // 16
-constexpr int SUPER_WORDS = 64;           // words per superblock (4096 columns)
-constexpr int NSUPER = WORDS / SUPER_WORDS;          // 128
+constexpr int SUPER_WORDS = 32;           // bitmap words per superblock (2048 columns)
 constexpr int MIN_WIN_LOG2 = 13;          // heavy rows: windows down to 8192 columns
-constexpr int ACC_CAP = 6144;             // tasks with at most this many outputs accumulate in LDS (48 KiB)
-constexpr int K_CAP = 256;                // k's whose metadata is staged in LDS per pass
+constexpr uint32_t NO_TAG = 0xFFFFFFFFu;
+
+// LDS layout of the large-row kernels for windows of up to 2^WL columns.  The narrower the window
+// the more workgroups share a CU (each phase of a task ends in a barrier, so a lone workgroup
+// leaves the CU idle while its loads are in flight): 2^19 -> 1 per CU, 2^18 -> 2, 2^17 -> 3, 2^16 -> 4.
+template <int WL>
+struct LgCfg {
+    static constexpr int WORDS = 1 << (WL - 6);                 // 64-bit bitmap words
+    static constexpr int WPT = WORDS / LG_BLOCK;                // words per thread in the popcount prefix
+    static constexpr int NSUPER = WORDS / SUPER_WORDS;
+    static constexpr int TPS = SUPER_WORDS / WPT;               // threads per superblock
+    // accumulators (+ order tags) of one pass; a superblock alone (<= 2048 outputs) must fit
+    static constexpr int ACC_CAP = WL >= 19 ? 5632 : WL == 18 ? 2304 : WL == 17 ? 2048 : 2048;
+    static constexpr int K_CAP = WL >= 18 ? 512 : 256;          // k's staged in LDS per group (<= one per thread)
+    static_assert(WL >= 16 && WL <= MAX_WIN_LOG2, "window");
+    static_assert(ACC_CAP >= SUPER_WORDS * 64, "a superblock must fit one pass");
+};
 
 // first position in [lo, hi) whose column is >= v
 template <typename IDX>
@@ -75,24 +86,32 @@ struct CsrView {
     const IDX *indices;
     const double *data;
     // optional column-bucket table of the right operand: bucket[k * nb + b] = number of entries of
-    // row k with column < b * 4096.  Turns "where does row k enter column window [lo,hi)" — two
+    // row k with column < b * 2048.  Turns "where does row k enter column window [lo,hi)" — two
     // binary searches, ~20 dependent loads per (row, window) — into two independent loads.
     const uint32_t *bucket;
     uint64_t nb;
 };
 
-constexpr int BUCKET_LOG2 = 12;   // = one superblock of the LDS bitmap (64 words x 64 columns)
+constexpr int BUCKET_LOG2 = 11;   // 2048 columns = one superblock of the LDS bitmap: pass and window bounds are free
 
-// sub-range [s,e) of row k (given its [s,e) = whole row) inside columns [lo, hi); lo is a multiple
-// of 4096 and hi is either a multiple of 4096 or the number of columns
+// sub-range [s,e) of row k (given its [s,e) = whole row) inside columns [lo, hi).  With the bucket
+// table a bound that is a multiple of 2048 costs one load (callers round hi UP past the last
+// column instead of clamping it); any other bound adds a binary search inside its bucket.
 template <typename IDX, typename PTR>
 __device__ __forceinline__ void row_window(const CsrView<IDX, PTR> &B, uint64_t k, uint64_t lo, uint64_t hi,
                                            uint64_t &s, uint64_t &e) {
     if (B.bucket) {
         const uint32_t *t = B.bucket + k * B.nb;
         const uint64_t row0 = s;
-        s = row0 + t[lo >> BUCKET_LOG2];
-        e = row0 + t[(hi + ((1ull << BUCKET_LOG2) - 1)) >> BUCKET_LOG2];
+        auto first_ge = [&](uint64_t v) -> uint64_t {
+            const uint64_t b = v >> BUCKET_LOG2;
+            if (b >= B.nb - 1) return row0 + t[B.nb - 1];          // past the last column: the whole row
+            const uint64_t p0 = row0 + t[b];
+            if ((v & ((1ull << BUCKET_LOG2) - 1)) == 0) return p0;
+            return lower_bound_col(B.indices, p0, row0 + t[b + 1], v);
+        };
+        s = first_ge(lo);
+        e = first_ge(hi);
     } else {
         s = lower_bound_col(B.indices, s, e, lo);
         e = lower_bound_col(B.indices, s, e, hi);
@@ -127,17 +146,6 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
-// value of `v` in lane `src`, `src` wave-uniform: v_readlane (a few cycles) instead of the
-// ds_bpermute (an LDS round trip, ~100+ cycles) that __shfl with a variable index compiles to
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), src));
-}
-
 __device__ __forceinline__ uint32_t hash_slot(uint32_t c, int lg) { return (c * 0x9E3779B1u) >> (32 - lg); }
 
 __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }
@@ -147,7 +155,7 @@ __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 3
 // ---------------------------------------------------------------------------
 template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
-                                                       uint64_t b_cols, uint64_t heavy_products,
+                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t max_wl,
                                                        uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks,
                                                        uint8_t *__restrict__ wlog) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -163,16 +171,17 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
         acc = wave_sum_u64(acc);
         if (lane == 0) {
             ub[r] = acc;
-            // Window width of a large row: 2^19 columns, narrowed (down to 2^13) for heavy rows so that
+            // Window width of a large row: 2^max_wl columns, narrowed (down to 2^13) for heavy rows so that
             // a hub row becomes many tasks of ~HEAVY_PRODUCTS products instead of one serial chain.
-            uint32_t wl = WIN_LOG2;
+            uint32_t wl = max_wl;
             if (acc > SMALL_MAX) {
                 uint64_t want = acc / heavy_products;          // desired number of tasks
                 if (want < 1) want = 1;
                 uint64_t width = b_cols / want;                // columns per task
                 wl = width <= 1 ? 0 : 63 - __clzll((long long)width);   // floor(log2)
-                if (wl > (uint32_t)WIN_LOG2) wl = WIN_LOG2;
+                if (wl > max_wl) wl = max_wl;
                 if (wl < (uint32_t)MIN_WIN_LOG2) wl = MIN_WIN_LOG2;
+                if (wl > max_wl) wl = max_wl;
             }
             wlog[r] = (uint8_t)wl;
             const uint64_t width = 1ull << wl;
@@ -298,55 +307,120 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
 // ---------------------------------------------------------------------------
 // large rows: one workgroup per (row, column window) task, LDS bitmap
 // ---------------------------------------------------------------------------
-template <typename IDX, typename PTR>
+// ---------------------------------------------------------------------------
+// large rows: one workgroup per (row, column window) task
+//
+// Entries are processed ENTRY-parallel, not k-step by k-step: the k's of the row are staged in
+// groups of K_CAP (their sub-range of B inside the window and the exclusive prefix of the
+// sub-range lengths, in LDS); the concatenation of those sub-ranges — the expansion of the task
+// in the reference's own order, k ascending, columns ascending inside a k — is then walked by all
+// 512 threads, thread t taking flat positions t, t + 512, ...: every load is independent.
+// (The first design let each wave walk "its" columns one k at a time: 332 M steps of 16 entries,
+// ~2 000 cycles of dependent LDS latency each, 56 % of the kernel — profiles/r01y.)
+// ---------------------------------------------------------------------------
+
+template <int K_CAP, typename IDX, typename PTR>
+__device__ __forceinline__ uint32_t stage_k_group(const CsrView<IDX, PTR> &A, const CsrView<IDX, PTR> &B,
+                                                  uint64_t kc, uint32_t n, uint64_t wlo, uint64_t whi, bool whole_row,
+                                                  uint64_t *kS, uint32_t *kP, double *kA, uint64_t *wt) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t len = 0;                      // < 2^32: a window holds at most 2^19 columns of a row
+    if (tid < n) {
+        const uint64_t k = (uint64_t)A.indices[kc + tid];
+        uint64_t s = (uint64_t)B.indptr[k], e = (uint64_t)B.indptr[k + 1];
+        // with the bucket table the window bounds do not depend on the row bounds: the two pairs of
+        // loads go out together (one memory round trip less on the task's critical path)
+        if (!whole_row && (B.bucket || e > s)) row_window(B, k, wlo, whi, s, e);
+        kS[tid] = s;
+        len = (uint32_t)(e - s);
+        if (kA) kA[tid] = A.data[kc + tid];
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_u32(len, (uint32_t *)wt, &tot);
+    if (tid < n) kP[tid] = ex;
+    if (tid == 0) kP[n] = tot;
+    for (uint32_t i = n + 1 + tid; i <= (uint32_t)K_CAP; i += LG_BLOCK) kP[i] = 0xFFFFFFFFu;   // sentinels for the search
+    __syncthreads();
+    return tot;
+}
+
+// owner of flat position t < total: the last k with kP[k] <= t.  kP[0 .. K_CAP] is non-decreasing
+// (total at [n], sentinels behind it), so a fixed-trip, branch-free descent finds it.
+template <int K_CAP>
+__device__ __forceinline__ uint32_t flat_owner(const uint32_t *kP, uint32_t t) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (int step = K_CAP / 2; step > 0; step >>= 1)
+        if (kP[lo + step] <= t) lo += step;
+    return lo;
+}
+
+// A thread walks E CONSECUTIVE flat positions: one search for the first, then it only steps to the
+// next k when a position crosses the boundary (one LDS compare per entry instead of a search).
+struct FlatWalk {
+    uint32_t o, nxt;
+    uint64_t base;            // kS[o] - kP[o]: position t lives at B entry base + t
+    template <int K_CAP>
+    __device__ __forceinline__ void start(const uint64_t *kS, const uint32_t *kP, uint32_t t) {
+        o = flat_owner<K_CAP>(kP, t);
+        nxt = kP[o + 1];
+        base = kS[o] - kP[o];
+    }
+    // returns true when the owner changed
+    __device__ __forceinline__ bool advance(const uint64_t *kS, const uint32_t *kP, uint32_t t) {
+        if (t < nxt) return false;
+        do {
+            ++o;
+            nxt = kP[o + 1];
+        } while (t >= nxt);
+        base = kS[o] - kP[o];
+        return true;
+    }
+};
+
+template <int K_CAP, typename IDX, typename PTR>
 __device__ __forceinline__ void set_window_bits(const CsrView<IDX, PTR> &A, const CsrView<IDX, PTR> &B, uint64_t as,
                                                 uint64_t ae, uint64_t wlo, uint64_t whi, bool whole_row,
-                                                unsigned long long *bm, uint32_t &fresh) {
-    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    for (uint64_t p0 = as + (uint64_t)wave * WAVE; p0 < ae; p0 += (uint64_t)LG_WAVES * WAVE) {
-        const uint64_t p = p0 + lane;
-        const bool valid = p < ae;
-        const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
-        uint64_t s = valid ? (uint64_t)B.indptr[k] : 0, e = valid ? (uint64_t)B.indptr[k + 1] : 0;
-        if (!whole_row && e > s) row_window(B, k, wlo, whi, s, e);
-        unsigned long long live = __ballot(e > s);
-        constexpr int PF = 8;                       // steps loaded together (see large_numeric_kernel)
-        while (live) {
-            int js[PF];
-            int n = 0;
+                                                unsigned long long *bm, uint64_t *kS, uint32_t *kP, double *kA,
+                                                uint64_t *wt, uint32_t &fresh) {
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t kc = as; kc < ae; kc += K_CAP) {
+        const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
+        const uint32_t tot = stage_k_group<K_CAP>(A, B, kc, n, wlo, whi, whole_row, kS, kP, kA, wt);
+        constexpr int EB = 8;             // consecutive entries per thread and trip
+        uint32_t *bm32 = (uint32_t *)bm;  // little endian: column c is bit (c & 31) of half-word c >> 5
+        for (uint32_t c0 = 0; c0 < tot; c0 += EB * LG_BLOCK) {
+            const uint32_t t0 = c0 + tid * EB;
+            if (t0 < tot) {
+                FlatWalk wk;
+                wk.start<K_CAP>(kS, kP, t0);
+                uint64_t pos[EB];
 #pragma unroll
-            for (int d = 0; d < PF; ++d) {
-                js[d] = 0;
-                if (live) {
-                    js[d] = __ffsll((long long)live) - 1;
-                    live &= live - 1;
-                    n = d + 1;
+                for (int e = 0; e < EB; ++e) {
+                    pos[e] = ~0ull;
+                    if (t0 + e < tot) {
+                        wk.advance(kS, kP, t0 + e);
+                        pos[e] = wk.base + (t0 + e);
+                    }
                 }
-            }
-            uint64_t sj[PF], ej[PF], cc[PF];
+                uint32_t c[EB];
 #pragma unroll
-            for (int d = 0; d < PF; ++d) {
-                sj[d] = readlane_u64(s, js[d]);
-                ej[d] = readlane_u64(e, js[d]);
-                cc[d] = 0;
-                if (d < n && sj[d] + lane < ej[d]) cc[d] = (uint64_t)B.indices[sj[d] + lane];
-            }
+                for (int e = 0; e < EB; ++e) c[e] = pos[e] != ~0ull ? (uint32_t)((uint64_t)B.indices[pos[e]] - wlo) : 0xFFFFFFFFu;
 #pragma unroll
-            for (int d = 0; d < PF; ++d) {
-                if (d < n) {
-                    for (uint64_t b = sj[d] + lane; b < ej[d]; b += WAVE) {
-                        const uint64_t c = (b == sj[d] + lane ? cc[d] : (uint64_t)B.indices[b]) - wlo;
-                        const unsigned long long bit = 1ull << (c & 63);
-                        const unsigned long long old = atomicOr(&bm[c >> 6], bit);
+                for (int e = 0; e < EB; ++e) {
+                    if (c[e] != 0xFFFFFFFFu) {
+                        const uint32_t bit = 1u << (c[e] & 31);
+                        const uint32_t old = atomicOr(&bm32[c[e] >> 5], bit);
                         fresh += (old & bit) ? 0u : 1u;
                     }
                 }
             }
         }
+        __syncthreads();                  // the next group overwrites kS / kP
     }
 }
 
-template <typename IDX, typename PTR>
+template <int WL, typename IDX, typename PTR>
 __global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B,
                                                                   uint64_t b_cols, const uint64_t *__restrict__ large_list,
                                                                   const uint64_t *__restrict__ task_row,
@@ -354,18 +428,24 @@ __global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, P
                                                                   const uint64_t *__restrict__ ntasks,
                                                                   const uint8_t *__restrict__ wlog,
                                                                   uint64_t *__restrict__ count) {
-    __shared__ unsigned long long bm[WORDS];
+    using Cfg = LgCfg<WL>;
+    constexpr int K_CAP = Cfg::K_CAP;
+    __shared__ unsigned long long bm[Cfg::WORDS];
+    __shared__ uint64_t kS[K_CAP];
+    __shared__ uint32_t kP[K_CAP + 1];
+    __shared__ uint64_t wt[16];
     __shared__ uint64_t red[LG_WAVES];
     const uint64_t t = large_list[blockIdx.x];
     const uint64_t r = task_row[t];
     const uint64_t w = t - first_task[r];
     const uint32_t wl = wlog[r];
     const int words = (int)((1ull << wl) / 64);
-    const uint64_t wlo = w << wl, whi = (wlo + (1ull << wl) < b_cols) ? wlo + (1ull << wl) : b_cols;
+    const uint64_t wlo = w << wl, whi = wlo + (1ull << wl);   // not clamped to b_cols: see row_window
     for (int i = threadIdx.x; i < words; i += LG_BLOCK) bm[i] = 0;
     __syncthreads();
     uint32_t fresh = 0;
-    set_window_bits(A, B, (uint64_t)A.indptr[r], (uint64_t)A.indptr[r + 1], wlo, whi, ntasks[r] == 1, bm, fresh);
+    set_window_bits<Cfg::K_CAP>(A, B, (uint64_t)A.indptr[r], (uint64_t)A.indptr[r + 1], wlo, whi, ntasks[r] == 1, bm, kS, kP,
+                                (double *)nullptr, wt, fresh);
     const uint64_t ws = wave_sum_u64(fresh);
     if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = ws;
     __syncthreads();
@@ -376,7 +456,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, P
     }
 }
 
-template <typename IDX, typename PTR>
+template <int WL, typename IDX, typename PTR>
 __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B,
                                                                  uint64_t b_cols, const uint64_t *__restrict__ large_list,
                                                                  const uint64_t *__restrict__ task_row,
@@ -387,28 +467,34 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                                                                  const uint64_t *__restrict__ off,
                                                                  IDX *__restrict__ c_indices, double *__restrict__ c_data,
                                                                  unsigned long long *__restrict__ prof) {
-    __shared__ unsigned long long bm[WORDS];        // 64 KiB
-    __shared__ uint16_t sub[WORDS];                 // 16 KiB: rank of a word inside its superblock
-    __shared__ uint32_t super[NSUPER + 1];          // outputs before each 4096-column superblock
-    __shared__ double acc[ACC_CAP];                 // 32 KiB: accumulators of tasks with few outputs
+    using Cfg = LgCfg<WL>;
+    constexpr int WPT = Cfg::WPT, TPS = Cfg::TPS, NSUPER = Cfg::NSUPER, ACC_CAP = Cfg::ACC_CAP, K_CAP = Cfg::K_CAP;
+    __shared__ unsigned long long bm[Cfg::WORDS];   // the window's structure: one bit per column
+    __shared__ uint16_t sub[Cfg::WORDS];            // outputs before a word inside its superblock
+    __shared__ uint32_t super[NSUPER + 1];          // outputs before each 2048-column superblock
+    __shared__ double acc[ACC_CAP];                 // accumulators of the current pass
+    __shared__ uint32_t tag[ACC_CAP];               // earliest pending entry per accumulator (ordering)
+    __shared__ uint32_t more_flag[3];
+    __shared__ uint64_t kS[K_CAP];
+    __shared__ uint32_t kP[K_CAP + 1];
+    __shared__ double kA[K_CAP];
     __shared__ uint64_t wt[16];
-    const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const uint32_t tid = threadIdx.x;
     const uint64_t t = large_list[blockIdx.x];
     const uint64_t r = task_row[t];
     const uint64_t w = t - first_task[r];
     const uint32_t wl = wlog[r];
     const int words = (int)((1ull << wl) / 64);
-    const uint64_t wlo = w << wl, whi = (wlo + (1ull << wl) < b_cols) ? wlo + (1ull << wl) : b_cols;
+    const uint64_t wlo = w << wl, whi = wlo + (1ull << wl);   // not clamped to b_cols: see row_window
     const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
+    const bool whole_row = ntasks[r] == 1;
     const uint64_t out = off[t];
     const uint32_t cnt = (uint32_t)count[t];
     if (cnt == 0) return;                           // window without outputs (block-uniform)
-    // accumulators: LDS when the task has few outputs, and ALWAYS with the bucket table (a wide
-    // window is then processed in passes of <= ACC_CAP outputs); else the row's slots in L2
-    const bool in_lds = cnt <= (uint32_t)ACC_CAP || B.bucket != nullptr;   // block-uniform
-    uint32_t base_rank = 0;                          // first output of the current pass
     // optional phase profile (debug option spgemm_prof): cycles of thread 0 per phase, summed over tasks
     long long t_prev = prof ? (long long)clock64() : 0;
+    const long long t_begin = t_prev;
+    uint32_t n_rounds = 0, n_chunks = 0;
     auto mark = [&](int phase) {
         if (prof && tid == 0) {
             const long long now = (long long)clock64();
@@ -418,35 +504,31 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     };
 
     for (int i = tid; i < words; i += LG_BLOCK) bm[i] = 0;
-    if (in_lds && !B.bucket)
-        for (uint32_t i = tid; i < cnt; i += LG_BLOCK) acc[i] = 0.0;
     __syncthreads();
     uint32_t fresh = 0;
-    set_window_bits(A, B, as, ae, wlo, whi, ntasks[r] == 1, bm, fresh);
-    __syncthreads();
+    set_window_bits<Cfg::K_CAP>(A, B, as, ae, wlo, whi, whole_row, bm, kS, kP, kA, wt, fresh);
     mark(0);   // clear + bits
 
-    // popcount prefix: thread tid owns words [16 tid, 16 tid + 16)
-    uint32_t local[WORDS_PER_THREAD];
+    // popcount prefix: thread tid owns words [WPT tid, WPT tid + WPT)
+    uint32_t local[WPT];
     uint32_t mine = 0;
 #pragma unroll
-    for (int i = 0; i < WORDS_PER_THREAD; ++i) {
-        const int word = tid * WORDS_PER_THREAD + i;
+    for (int i = 0; i < WPT; ++i) {
+        const int word = tid * WPT + i;
         local[i] = mine;
         mine += word < words ? (uint32_t)__popcll(bm[word]) : 0u;
     }
-    uint64_t tot;
-    const uint32_t tpre = (uint32_t)block_excl_scan_u64(mine, wt, &tot);
-    constexpr int THREADS_PER_SUPER = SUPER_WORDS / WORDS_PER_THREAD;   // 4
-    if (tid % THREADS_PER_SUPER == 0) super[tid / THREADS_PER_SUPER] = tpre;
-    if (tid == 0) super[NSUPER] = (uint32_t)tot;
+    uint32_t tot;
+    const uint32_t tpre = block_excl_scan_u32(mine, (uint32_t *)wt, &tot);
+    if (tid % TPS == 0) super[tid / TPS] = tpre;
+    if (tid == 0) super[NSUPER] = tot;
     __syncthreads();
-    const uint32_t sbase = super[tid / THREADS_PER_SUPER];
-    // indices come out sorted: walk the set bits in order; zero the global accumulators
+    const uint32_t sbase = super[tid / TPS];
+    // indices come out sorted: walk the set bits in order
     uint32_t run = tpre;
 #pragma unroll 1
-    for (int i = 0; i < WORDS_PER_THREAD; ++i) {
-        const int word = tid * WORDS_PER_THREAD + i;
+    for (int i = 0; i < WPT; ++i) {
+        const int word = tid * WPT + i;
         if (word >= words) break;
         sub[word] = (uint16_t)(tpre + local[i] - sbase);
         unsigned long long m = bm[word];
@@ -454,226 +536,154 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
             c_indices[out + run] = (IDX)(wlo + (uint64_t)word * 64 + (uint64_t)b);
-            if (!in_lds) c_data[out + run] = 0.0;
             ++run;
         }
     }
-    __syncthreads();   // sub/super complete; zeroed accumulators have reached L2 (release at workgroup scope)
+    __syncthreads();
     mark(1);   // prefix + emit indices
 
-    // Each wave OWNS a contiguous range of superblocks and walks every k in ascending order for
-    // it: one owner per accumulator, reference order.  The ranges are balanced by PRODUCTS when
-    // the column-bucket table of B is available (one bucket = one superblock, so the products of
-    // superblock b are sum_k (t_k[b+1] - t_k[b]) — no pass over the entries needed), else by
-    // outputs.
+    // ---- values ----------------------------------------------------------------------------------
+    // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) of at most ACC_CAP outputs,
+    // whose accumulators live in LDS.  Inside a pass the expansion restricted to the pass's columns is
+    // walked in the reference's order (k ascending), 4 x 512 entries at a time, all loads independent.
+    // ORDER: C(i,j) must be built by the reference's chain of additions (smmp.rs:174-181), so two
+    // entries of one chunk that hit the same accumulator may not be added in arbitrary order (and
+    // float atomics are out anyway).  Each pending entry posts its position with an LDS atomicMin on the
+    // accumulator's tag; the entry whose position comes back adds its product and clears the tag, the
+    // others try again in the next round.  Rounds needed = the largest multiplicity of an output inside
+    // the chunk: 1 almost always, 2-3 in dense windows.  Deterministic and bit-exact.
+    constexpr int U = 4;
+    const bool one_group = ae - as <= (uint64_t)K_CAP;
     const int nsuper = (words + SUPER_WORDS - 1) / SUPER_WORDS;
-    __shared__ uint32_t pcnt[NSUPER];
-    __shared__ uint32_t ppre[NSUPER + 1];
-    if (B.bucket) {
-        if (tid < NSUPER) pcnt[tid] = 0;
-        __syncthreads();
-        const uint64_t wb0 = wlo >> BUCKET_LOG2;
-        const uint64_t i0 = wb0 + lane, i1 = wb0 + lane + 64, last = B.nb - 1;
-        uint32_t c0 = 0, c1 = 0;
-        for (uint64_t p = as + wave; p < ae; p += LG_WAVES) {
-            const uint32_t *t = B.bucket + (uint64_t)A.indices[p] * B.nb;
-            if ((int)lane < nsuper) c0 += t[i0 + 1 < last ? i0 + 1 : last] - t[i0 < last ? i0 : last];
-            if ((int)lane + 64 < nsuper) c1 += t[i1 + 1 < last ? i1 + 1 : last] - t[i1 < last ? i1 : last];
-        }
-        if (c0) atomicAdd(&pcnt[lane], c0);
-        if (c1) atomicAdd(&pcnt[lane + 64], c1);
-        __syncthreads();
-        uint64_t ptot;
-        const uint64_t ex = block_excl_scan_u64((int)tid < nsuper ? pcnt[tid] : 0u, wt, &ptot);
-        if ((int)tid < nsuper) ppre[tid] = (uint32_t)ex;
-        if ((int)tid == nsuper) ppre[tid] = (uint32_t)ptot;
-        __syncthreads();
-    }
-    mark(2);   // product counts per superblock
-    // number of superblocks sb in [from, to) with bal[sb] - bal[from] < target
-    auto boundary = [&](const uint32_t *bal, uint32_t from, uint32_t to, uint32_t target) -> uint32_t {
-        uint32_t n = 0;
-        const uint32_t b0 = bal[from];
-        for (uint32_t sb = from + lane; sb < to; sb += WAVE) n += (bal[sb] - b0 < target) ? 1u : 0u;
-        return __shfl((uint32_t)wave_sum_u64(n), 0, WAVE);
-    };
-    uint32_t sb_lo = 0, sb_hi = 0;
-    if (!B.bucket) {
-        sb_lo = boundary(super, 0, (uint32_t)nsuper, (uint32_t)(((uint64_t)cnt * wave) / LG_WAVES));
-        sb_hi = boundary(super, 0, (uint32_t)nsuper, (uint32_t)(((uint64_t)cnt * (wave + 1)) / LG_WAVES));
-        if (wave == 0) sb_lo = 0;
-        if (wave == LG_WAVES - 1) sb_hi = (uint32_t)nsuper;
-    }
-    const uint64_t clo = wlo + (uint64_t)sb_lo * (SUPER_WORDS * 64);
-    uint64_t chi = wlo + (uint64_t)sb_hi * (SUPER_WORDS * 64);
-    if (chi > whi) chi = whi;
-
-    uint32_t n_steps = 0, n_entries = 0;            // profiling only
-    // apply one batch of up to 64 sub-ranges [s,e) (lane j holds k_j's), ascending j == ascending k
-    auto apply_batch = [&](uint64_t s, uint64_t e, double av) {
-        // PF steps (k's) are loaded together before any of them is applied: a step's entries
-        // are a dependent global load (~1.4 us under load), and with 8 waves per CU one step at
-        // a time left the CU 85 % idle.  Application order stays ascending k.
-        constexpr int PF = 8;
-        unsigned long long live = __ballot(e > s);
-        if (prof) {
-            n_steps += (uint32_t)__popcll(live);
-            n_entries += (uint32_t)wave_sum_u64(e - s);
-        }
-        while (live) {
-            int js[PF];
-            int n = 0;
-#pragma unroll
-            for (int d = 0; d < PF; ++d) {
-                js[d] = 0;
-                if (live) {
-                    js[d] = __ffsll((long long)live) - 1;
-                    live &= live - 1;
-                    n = d + 1;
-                }
+    uint32_t pb = 0;
+    while (pb < (uint32_t)nsuper) {
+        uint32_t pe = pb + 1;
+        while (pe < (uint32_t)nsuper && super[pe + 1] - super[pb] <= (uint32_t)ACC_CAP) ++pe;
+        const uint32_t base_rank = super[pb];
+        const uint32_t pass_out = super[pe] - base_rank;
+        if (pass_out) {                                  // block-uniform
+            for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) {
+                acc[i] = 0.0;
+                tag[i] = NO_TAG;
             }
-            uint64_t sj[PF], ej[PF];
-            uint64_t cc[PF];
-            double vv[PF];
+            if (tid < 3) more_flag[tid] = 0;
+            uint32_t rd = 0;
+            // the tags must be in place before anyone posts on them: a late NO_TAG landing between two posts on
+            // the same accumulator would let the LATER entry win a round (seen once as a 1-ulp difference in
+            // 33 M checked values when the staging below is skipped and no other barrier intervenes)
+            __syncthreads();
+            const bool single = pb == 0 && pe == (uint32_t)nsuper;
+            const uint64_t plo = wlo + (uint64_t)pb * (SUPER_WORDS * 64);
+            const uint64_t phi = wlo + (uint64_t)pe * (SUPER_WORDS * 64);
+            for (uint64_t kc = as; kc < ae; kc += K_CAP) {
+                const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
+                // a task with one group of k's and one pass finds kS / kP / kA as the bit pass left them
+                const uint32_t gtot = (single && one_group)
+                                          ? kP[n]
+                                          : stage_k_group<K_CAP>(A, B, kc, n, single ? wlo : plo, single ? whi : phi,
+                                                                 single && whole_row, kS, kP, kA, wt);
+                mark(8);
+                for (uint32_t c0 = 0; c0 < gtot; c0 += U * LG_BLOCK) {
+                    // thread tid takes positions c0 + U tid .. + U - 1 (order inside the chunk = U tid + u)
+                    uint32_t slot[U], pos_in_chunk[U];
+                    double pr[U];
+                    bool pend[U];
+                    const uint32_t t0 = c0 + tid * U;
+                    uint64_t pos[U];
+                    double av[U];
+                    if (t0 < gtot) {
+                        FlatWalk wk;
+                        wk.start<K_CAP>(kS, kP, t0);
+                        double a_cur = kA[wk.o];
 #pragma unroll
-            for (int d = 0; d < PF; ++d) {
-                sj[d] = readlane_u64(s, js[d]);
-                ej[d] = readlane_u64(e, js[d]);
-                cc[d] = 0;
-                vv[d] = 0.0;
-                if (d < n && sj[d] + lane < ej[d]) {
-                    cc[d] = (uint64_t)B.indices[sj[d] + lane];
-                    vv[d] = B.data[sj[d] + lane];
-                }
-            }
-#pragma unroll
-            for (int d = 0; d < PF; ++d) {
-                if (d < n) {                                  // wave-uniform
-                    const double avj = readlane_f64(av, js[d]);
-                    for (uint64_t b = sj[d] + lane; b < ej[d]; b += WAVE) {
-                        uint64_t c;
-                        double bv;
-                        if (b == sj[d] + lane) {
-                            c = cc[d];
-                            bv = vv[d];
-                        } else {                              // sub-range longer than one wave: rare
-                            c = (uint64_t)B.indices[b];
-                            bv = B.data[b];
-                        }
-                        c -= wlo;
-                        const double pr = avj * bv;
-                        const uint32_t word = (uint32_t)(c >> 6);
-                        const uint32_t rank = super[word / SUPER_WORDS] + sub[word] +
-                                              (uint32_t)__popcll(bm[word] & ((1ull << (c & 63)) - 1ull));
-                        if (in_lds) {
-                            acc[rank - base_rank] += pr;        // LDS, one owner wave, program order
-                        } else {
-                            double *dst = c_data + out + rank;
-                            // The accumulator lives in this XCD's L2.  LOAD with sc1 (served by L2, around
-                            // the per-CU L1 that other waves' stores never refresh); STORE plain: a plain
-                            // store is written through to L2 and KEEPS the line there, whereas an sc1 /
-                            // atomic store drops it to memory (profiles/r01q_spgemm_pmc.txt).
-                            double v = __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            v += pr;
-                            *(volatile double *)dst = v;
-                        }
-                    }
-                    // the next k may hit the same accumulators: its loads must follow these stores
-                    if (in_lds) __builtin_amdgcn_wave_barrier();
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            }
-        }
-    };
-
-    if (B.bucket) {
-        // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) holding at most
-        // ACC_CAP outputs (one superblock has <= 4096), so the accumulators of a pass always fit in
-        // LDS.  (Before: tasks with more outputs accumulated through L2 with one global round trip
-        // per k — 28 % of config 5's tasks took 46 % of this kernel's time, tests/spgemm_bench.py
-        // with SPGEMM_PROF=1.)  Inside a pass the k metadata is gathered ONCE per workgroup into
-        // LDS: row start, the bucket offsets at the 9 wave boundaries, the A value.
-        __shared__ uint64_t k_row0[K_CAP];
-        __shared__ double k_val[K_CAP];
-        __shared__ uint32_t k_bnd[K_CAP][LG_WAVES + 1];
-        __shared__ uint32_t w_bnd[LG_WAVES + 1];
-        const uint64_t wb0 = wlo >> BUCKET_LOG2, last = B.nb - 1;
-        uint32_t pb = 0;
-        while (pb < (uint32_t)nsuper) {
-            uint32_t pe = pb + 1;
-            while (pe < (uint32_t)nsuper && super[pe + 1] - super[pb] <= (uint32_t)ACC_CAP) ++pe;
-            base_rank = super[pb];
-            const uint32_t pass_out = super[pe] - base_rank;
-            if (pass_out) {                                  // block-uniform
-                for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) acc[i] = 0.0;
-                // wave ownership inside the pass, balanced by products
-                const uint32_t pprod = ppre[pe] - ppre[pb];
-                const uint32_t lo_w = pb + boundary(ppre, pb, pe, (uint32_t)(((uint64_t)pprod * wave) / LG_WAVES));
-                if (lane == 0) w_bnd[wave] = wave == 0 ? pb : lo_w;
-                if (tid == 0) w_bnd[LG_WAVES] = pe;
-                __syncthreads();
-                const bool mine = w_bnd[wave + 1] > w_bnd[wave];
-                for (uint64_t kc = as; kc < ae; kc += K_CAP) {
-                    const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
-                    for (uint32_t i = tid; i < n * (LG_WAVES + 1); i += LG_BLOCK) {
-                        const uint32_t kk = i / (LG_WAVES + 1), g = i % (LG_WAVES + 1);
-                        const uint64_t k = (uint64_t)A.indices[kc + kk];
-                        const uint64_t bi = wb0 + w_bnd[g];
-                        k_bnd[kk][g] = B.bucket[k * B.nb + (bi < last ? bi : last)];
-                        if (g == 0) {
-                            k_row0[kk] = (uint64_t)B.indptr[k];
-                            k_val[kk] = A.data[kc + kk];
-                        }
-                    }
-                    __syncthreads();
-                    mark(8);
-                    if (mine) {
-                        for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
-                            const uint32_t j = j0 + lane;
-                            uint64_t s = 0, e = 0;
-                            double av = 0.0;
-                            if (j < n) {
-                                s = k_row0[j] + k_bnd[j][wave];
-                                e = k_row0[j] + k_bnd[j][wave + 1];
-                                av = k_val[j];
+                        for (int u = 0; u < U; ++u) {
+                            pend[u] = t0 + u < gtot;
+                            pos[u] = 0;
+                            if (pend[u]) {
+                                if (wk.advance(kS, kP, t0 + u)) a_cur = kA[wk.o];
+                                pos[u] = wk.base + (t0 + u);
                             }
-                            apply_batch(s, e, av);
+                            av[u] = a_cur;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            pend[u] = false;
+                            pos[u] = 0;
+                            av[u] = 0.0;
                         }
                     }
-                    __syncthreads();
-                    mark(9);
+                    uint32_t cc[U];
+                    double bv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        cc[u] = pend[u] ? (uint32_t)((uint64_t)B.indices[pos[u]] - wlo) : 0u;
+                        bv[u] = pend[u] ? B.data[pos[u]] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        pos_in_chunk[u] = tid * U + (uint32_t)u;
+                        pr[u] = av[u] * bv[u];
+                        const uint32_t word = cc[u] >> 6;
+                        slot[u] = pend[u] ? super[word / SUPER_WORDS] + sub[word] +
+                                                (uint32_t)__popcll(bm[word] & ((1ull << (cc[u] & 63)) - 1ull)) - base_rank
+                                          : 0u;
+                    }
+                    mark(12);
+                    ++n_chunks;
+                    // ordered rounds; termination through three rotating LDS flags (a workgroup-wide
+                    // vote costs more instructions than the round itself)
+                    for (;; ++rd) {                     // rd keeps counting across chunks: the flag rotation never restarts
+                        ++n_rounds;
+                        bool mine_pending = false;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) mine_pending |= pend[u];
+                        const bool wave_pending = __ballot(mine_pending) != 0ull;     // wave-uniform
+                        if (wave_pending) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u)
+                                if (pend[u]) atomicMin(&tag[slot[u]], pos_in_chunk[u]);
+                        }
+                        if (tid == 0) more_flag[(rd + 1) % 3] = 0;
+                        __syncthreads();
+                        if (wave_pending) {
+                            bool more = false;
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                if (pend[u]) {
+                                    if (tag[slot[u]] == pos_in_chunk[u]) {
+                                        acc[slot[u]] += pr[u];
+                                        tag[slot[u]] = NO_TAG;
+                                        pend[u] = false;
+                                    } else {
+                                        more = true;
+                                    }
+                                }
+                            }
+                            if (more) more_flag[rd % 3] = 1;
+                        }
+                        __syncthreads();
+                        if (!more_flag[rd % 3]) {                                     // block-uniform
+                            ++rd;
+                            break;
+                        }
+                    }
                 }
-                for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
-                __syncthreads();
-                mark(10);
-                if (prof && tid == 0) atomicAdd(&prof[11], 1ull);
+                mark(9);
             }
-            pb = pe;
+            for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
+            __syncthreads();
+            mark(10);
+            if (prof && tid == 0) atomicAdd(&prof[11], 1ull);
         }
-        if (prof && lane == 0) {
-            atomicAdd(&prof[12], (unsigned long long)n_steps);
-            atomicAdd(&prof[13], (unsigned long long)n_entries);
-        }
-    } else if (sb_hi > sb_lo && clo < chi) {
-        for (uint64_t p0 = as; p0 < ae; p0 += WAVE) {
-            const uint64_t p = p0 + lane;
-            const bool valid = p < ae;
-            const uint64_t k = valid ? (uint64_t)A.indices[p] : 0;
-            const double av = valid ? A.data[p] : 0.0;
-            uint64_t s = valid ? (uint64_t)B.indptr[k] : 0, e = valid ? (uint64_t)B.indptr[k + 1] : 0;
-            if (e > s) row_window(B, k, clo, chi, s, e);
-            apply_batch(s, e, av);
-        }
+        pb = pe;
     }
-    if (in_lds && !B.bucket) {
-        __syncthreads();
-        mark(3);   // accumulate (LDS accumulators)
-        for (uint32_t i = tid; i < cnt; i += LG_BLOCK) c_data[out + i] = acc[i];
-        mark(5);   // write back
-    } else if (!in_lds) {
-        mark(4);   // accumulate (L2 accumulators)
+    if (prof && tid == 0) {
+        atomicAdd(&prof[6], 1ull);
+        atomicAdd(&prof[13], (unsigned long long)n_chunks);
+        atomicAdd(&prof[14], (unsigned long long)n_rounds);
+        atomicMax(&prof[15], (unsigned long long)((long long)clock64() - t_begin));
     }
-    if (prof && tid == 0) atomicAdd(&prof[in_lds ? 6 : 7], 1ull);   // task counts
 }
 
 template <typename PTR>
@@ -729,7 +739,7 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
-                           (uint64_t)options().spgemm_heavy, ub.as<uint64_t>(), ntasks.as<uint64_t>(), wlog.as<uint8_t>());
+                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, ub.as<uint64_t>(), ntasks.as<uint64_t>(), wlog.as<uint8_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
     SPRS_TRY(exclusive_scan_u64(ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows, stream));
@@ -767,10 +777,22 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
                            count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
         SPRS_TRY_HIP(hipGetLastError());
     }
+    // ONE launch for all large tasks, in the LDS layout of the widest window (option spgemm_winlog).  Splitting
+    // the tasks into per-layout launches (narrow windows of heavy rows 4 per CU, wide ones 1 per CU) was
+    // measured slower: 335 ms against 179 ms (profiles/r01z_spgemm_v3_lds_class_launches_negative.txt).
     if (n_large) {
-        hipLaunchKernelGGL((large_symbolic_kernel<IDX, PTR>), dim3((unsigned)n_large), dim3(LG_BLOCK), 0, stream, A, B,
-                           b_cols, large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),
-                           ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>());
+        const dim3 g((unsigned)n_large), blk(LG_BLOCK);
+#define SPRS_LG_SYM(WL)                                                                                              \
+    hipLaunchKernelGGL((large_symbolic_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, b_cols,                       \
+                       large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),                \
+                       ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>())
+        switch (options().spgemm_winlog) {
+            case 16: SPRS_LG_SYM(16); break;
+            case 18: SPRS_LG_SYM(18); break;
+            case 19: SPRS_LG_SYM(19); break;
+            default: SPRS_LG_SYM(17); break;
+        }
+#undef SPRS_LG_SYM
         SPRS_TRY_HIP(hipGetLastError());
     }
 
@@ -797,11 +819,21 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true>), small_grid(), dim3(SM_BLOCK), 0, stream, A, B,
                            small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
                            count.as<uint64_t>(), off.as<uint64_t>(), (IDX *)c->indices, c->data);
-    if (n_large)
-        hipLaunchKernelGGL((large_numeric_kernel<IDX, PTR>), dim3((unsigned)n_large), dim3(LG_BLOCK), 0, stream, A, B,
-                           b_cols, large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),
-                           ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>(), off.as<uint64_t>(),
-                           (IDX *)c->indices, c->data, prof.as<unsigned long long>());
+    if (n_large) {
+        const dim3 g((unsigned)n_large), blk(LG_BLOCK);
+#define SPRS_LG_NUM(WL)                                                                                              \
+    hipLaunchKernelGGL((large_numeric_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, b_cols,                        \
+                       large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),                \
+                       ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>(), off.as<uint64_t>(),          \
+                       (IDX *)c->indices, c->data, prof.as<unsigned long long>())
+        switch (options().spgemm_winlog) {
+            case 16: SPRS_LG_NUM(16); break;
+            case 18: SPRS_LG_NUM(18); break;
+            case 19: SPRS_LG_NUM(19); break;
+            default: SPRS_LG_NUM(17); break;
+        }
+#undef SPRS_LG_NUM
+    }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
@@ -812,13 +844,12 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         unsigned long long h[16];
         if (hipMemcpy(h, prof.p, 128, hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr,
-                    "[spgemm_prof] inside accumulate: staging %llu, apply %llu, writeback %llu cycles; passes %llu, "
-                    "k-steps %llu (all waves), entries %llu\n",
-                    h[8], h[9], h[10], h[11], h[12], h[13]);
+                    "[spgemm_prof] inside the value passes: staging %llu, expand %llu, ordered add %llu, writeback %llu cycles; "
+                    "passes %llu, chunks %llu, rounds %llu; longest task %llu cycles\n",
+                    h[8], h[12], h[9], h[10], h[11], h[13], h[14], h[15]);
             fprintf(stderr,
-                    "[spgemm_prof] thread-0 cycles summed over large tasks: bits %llu, prefix+emit %llu, prodcount %llu, "
-                    "accumulate(LDS) %llu, accumulate(L2) %llu, writeback %llu; tasks LDS %llu, L2 %llu\n",
-                    h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+                    "[spgemm_prof] thread-0 cycles summed over large tasks: bits %llu, prefix+emit %llu; tasks %llu\n", h[0],
+                    h[1], h[6]);
         }
     }
     *c_out = c;

@@ -658,6 +658,9 @@ static int32_t get_scratch(SpmvPlan &pl, hipStream_t stream, SpmvScratch **out) 
             const uint64_t pbytes = XCS_SLICES * pl.n_long * sizeof(double);
             const uint64_t poff = (pbytes + 255) & ~255ull;
             SPRS_TRY_HIP(hipMalloc((void **)&sc.partial, poff + sizeof(SlicedArgs)));
+            // a slice without entries launches no tile, so nobody ever writes its partials: they must read as
+            // zero (fresh hipMalloc memory usually does, recycled memory does not)
+            SPRS_TRY_HIP(hipMemset(sc.partial, 0, poff));
             SlicedArgs sa;
             for (int s = 0; s < XCS_SLICES; ++s) {
                 const CsrPiece &sl = pl.slice[s];

@@ -26,6 +26,11 @@ def main():
     if len(sys.argv) > 6:
         import sprs_amd
         sprs_amd.set_option("spgemm_bucket", int(sys.argv[6]))
+    for name in ("winlog", "heavy", "bucket"):          # SPGEMM_WINLOG=17 SPGEMM_HEAVY=262144 ...
+        v = os.environ.get("SPGEMM_" + name.upper())
+        if v:
+            import sprs_amd
+            sprs_amd.set_option("spgemm_" + name, int(v))
     if os.environ.get("SPGEMM_PROF"):
         import sprs_amd
         sprs_amd.set_option("spgemm_prof", 1)
@@ -33,16 +38,23 @@ def main():
     idt = torch.int64 if idx_bytes == 8 else torch.int32
     indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)
     a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    c = smmp.mul_csr_csr(a, a)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # two runs: the first pays the driver's first-touch of the 53 GB result (erratic: 0.03 .. 1 s when a
+    # previous process has just released as much); the second is the steady state a caller sees
+    times = []
+    c = None
+    for _ in range(2):
+        del c
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c = smmp.mul_csr_csr(a, a)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = times[-1]
     nnz_c = c.nnz()
     # products P = sum_i sum_{k in A_i} nnz(A_k)
     rl = (indptr[1:] - indptr[:-1]).to(torch.float64)
     prods = float(rl[indices.long()].sum())
-    out = {"n": n, "nnz_a": int(indices.numel()), "nnz_c": int(nnz_c), "products": prods, "seconds": round(dt, 4),
+    out = {"n": n, "nnz_a": int(indices.numel()), "nnz_c": int(nnz_c), "products": prods, "seconds": round(dt, 4), "seconds_first_call": round(times[0], 4),
            "gflops": round(2 * prods / dt / 1e9, 3), "idx_bytes": idx_bytes,
            "compulsory_GB": round(((2 * indices.numel() + nnz_c) * (8 + idx_bytes) + 3 * (n + 1) * 8) / 1e9, 3)}
     # row-block parity vs the oracle (checker only)

@@ -149,6 +149,75 @@ def test_multi_window_columns(hip):
     check_against_oracle(A2, B2, exact_values=True)
 
 
+@pytest.mark.parametrize("winlog", [16, 17, 18, 19])
+def test_window_sizes_and_dense_outputs(hip, winlog):
+    """Every LDS layout of the large-row kernels (option spgemm_winlog), on inputs that stress the
+    ordered accumulation: > 256 k's per row (several staged groups), windows whose outputs are
+    nearly dense (every chunk of the expansion holds duplicates -> several ordering rounds, several
+    passes), heavy rows narrowed to 2^13-column windows, mixed signs (any reordering of the
+    additions would change the bits)."""
+    import scipy.sparse as sp
+    hip.set_option("spgemm_winlog", winlog)
+    hip.set_option("spgemm_heavy", 4096)
+    try:
+        rng = np.random.default_rng(winlog)
+        cols = 300_000
+        b = sp.random(2000, cols, density=0.004, random_state=7, format="csr")          # ~1200 per row
+        dense_band = sp.random(2000, 6000, density=0.5, random_state=8, format="csr")   # dense outputs in cols < 6000
+        b = (b + sp.hstack([dense_band, sp.csr_matrix((2000, cols - 6000))])).tocsr()
+        a = sp.random(24, 2000, density=0.3, random_state=9, format="csr")              # ~600 k's per row
+        a.data[:] = rng.standard_normal(a.nnz)
+        b.data[:] = rng.standard_normal(b.nnz)
+        a.sort_indices(); b.sort_indices()
+        u = lambda v: v.astype(np.uint64)
+        A = ((24, 2000), u(a.indptr), u(a.indices), a.data)
+        B = ((2000, cols), u(b.indptr), u(b.indices), b.data)
+        shape, ip, ix, dt = check_against_oracle(A, B, exact_values=True)
+        assert np.diff(ip.astype(np.int64)).max() > 100_000
+        for bucket in (0, 1):
+            hip.set_option("spgemm_bucket", bucket)
+            check_against_oracle(A, B, exact_values=True)
+    finally:
+        hip.set_option("spgemm_winlog", 17)
+        hip.set_option("spgemm_heavy", 65536)
+        hip.set_option("spgemm_bucket", 1)
+
+
+def test_result_pool_reuse_and_trim(hip):
+    """Released result blocks are reused by the next product (same bits out), are capped by
+    pool_max_bytes, and go back to the driver on pool_trim / option pool = 0."""
+    from sprs_amd import gen
+    from sprs_amd.device import DeviceCsMat
+    n = 60000
+    indptr, indices, data = gen.rmat_csr(n, 8, seed=11)
+    a = DeviceCsMat.from_host((n, n), indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64),
+                              data.numpy())
+    hip.pool_trim()
+    assert hip.get_option("pool") == 1 and hip.get_option("pool_cached_bytes") == 0
+    c1 = a * a
+    ref = c1.to_host()
+    nbytes = c1.nnz() * 16
+    assert nbytes > (2 << 20)
+    del c1
+    assert hip.get_option("pool_cached_bytes") >= nbytes            # both blocks came back
+    c2 = a * a                                                       # ... and serve the next result
+    assert hip.get_option("pool_cached_bytes") == 0
+    for x, y in zip(ref[1:], c2.to_host()[1:]):
+        assert np.array_equal(x, y)
+    del c2
+    assert hip.pool_trim() >= nbytes and hip.get_option("pool_cached_bytes") == 0
+    hip.set_option("pool_max_bytes", 1 << 20)                        # nothing this big may be kept
+    c3 = a * a
+    del c3
+    assert hip.get_option("pool_cached_bytes") == 0
+    hip.set_option("pool_max_bytes", 128 << 30)
+    hip.set_option("pool", 0)
+    c4 = a * a
+    del c4
+    assert hip.get_option("pool_cached_bytes") == 0
+    hip.set_option("pool", 1)
+
+
 def test_contract_violations(hip, golden):
     from sprs_amd import SprsHipError, _ffi, smmp
     from sprs_amd.device import DeviceCsMat
@@ -194,20 +263,23 @@ def test_deterministic_and_operator(hip):
         assert np.array_equal(x, y)
 
 
-def test_config5_full_size_row_blocks(hip):
+@pytest.mark.parametrize("idx_bytes", [8, 4])
+def test_config5_full_size_row_blocks(hip, idx_bytes):
     """BASELINE config 5 at FULL size: A*A for R-MAT 1M x 1M, ~8 nnz/row -> nnz(C) = 3.3e9 (53 GB on the
-    device).  The host oracle cannot hold C, so three row blocks are recomputed by the oracle
-    (smmp on A[rows,:] x A) and compared entry by entry; plus size-independent structure checks on
-    the device: indptr non-decreasing and consistent with nnz, every row strictly increasing."""
+    device with usize indices).  The host oracle cannot hold C, so three row blocks are recomputed by the
+    oracle (smmp on A[rows,:] x A) and compared entry by entry — structure AND values bit for bit, the
+    additions happen in the reference's order; plus size-independent structure checks on the device:
+    indptr non-decreasing and consistent with nnz, every row strictly increasing."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "spgemm_bench.py"), "1000000", "8", "8", "300"],
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "spgemm_bench.py"), "1000000", "8", str(idx_bytes),
+                        "300"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["nnz_c"] > 3_000_000_000 and d["nnz_a"] > 7_000_000
     assert d["parity"]["structure_bit_exact"] and d["parity"]["max_rel_err"] <= TOL
+    assert d["parity"]["values_bit_exact"], d["parity"]
     assert d["structure_checks"]["rows_strictly_increasing"] and d["structure_checks"]["indptr_monotone"]
