@@ -33,6 +33,7 @@ extern "C" {
     pub fn sprs_hip_memcpy_d2d(dev_dst: *mut c_void, dev_src: *const c_void, bytes: u64, stream: *mut c_void) -> i32;
     pub fn sprs_hip_memset(dev_dst: *mut c_void, byte_value: i32, bytes: u64, stream: *mut c_void) -> i32;
     pub fn sprs_hip_synchronize(stream: *mut c_void) -> i32;
+    pub fn sprs_hip_pool_trim(freed_bytes: *mut u64) -> i32;
     pub fn sprs_hip_csmat_upload(
         out: *mut *mut sprs_hip_csmat, storage: i32, rows: u64, cols: u64,
         indptr: *const c_void, iptr_bytes: i32, indices: *const c_void, idx_bytes: i32,
