@@ -29,6 +29,57 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *wa
     return base + inc - v;
 }
 
+// Workgroup barrier that orders LDS accesses only.  __syncthreads() carries a workgroup-scope release
+// fence, which on gfx950 is an s_waitcnt vmcnt(0): the wave first waits for every global load AND store
+// it has in flight.  Where the threads of a workgroup only hand LDS data to each other, that turns each
+// barrier into a drain of unrelated streaming stores.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// the same scans with LDS-only barriers
+__device__ __forceinline__ uint64_t block_excl_scan_u64_lds(uint64_t v, uint64_t *wave_tot, uint64_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    lds_barrier();
+    uint64_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+        const uint64_t t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    lds_barrier();
+    *total = tot;
+    return base + inc - v;
+}
+
+__device__ __forceinline__ uint32_t block_excl_scan_u32_lds(uint32_t v, uint32_t *wave_tot, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= (uint32_t)off) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    lds_barrier();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    lds_barrier();
+    *total = tot;
+    return base + inc - v;
+}
+
 // 32-bit twin (half the shuffles) for sums known to stay below 2^32
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *wave_tot /*LDS, >= 16*/, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -325,23 +325,35 @@ __device__ __forceinline__ uint32_t stage_k_group(const CsrView<IDX, PTR> &A, co
                                                   uint64_t *kS, uint32_t *kP, double *kA, uint64_t *wt) {
     const uint32_t tid = threadIdx.x;
     uint32_t len = 0;                      // < 2^32: a window holds at most 2^19 columns of a row
+    uint64_t s = 0;
+    double av = 0.0;
     if (tid < n) {
         const uint64_t k = (uint64_t)A.indices[kc + tid];
-        uint64_t s = (uint64_t)B.indptr[k], e = (uint64_t)B.indptr[k + 1];
+        uint64_t e = (uint64_t)B.indptr[k + 1];
+        s = (uint64_t)B.indptr[k];
         // with the bucket table the window bounds do not depend on the row bounds: the two pairs of
         // loads go out together (one memory round trip less on the task's critical path)
         if (!whole_row && (B.bucket || e > s)) row_window(B, k, wlo, whi, s, e);
-        kS[tid] = s;
         len = (uint32_t)(e - s);
-        if (kA) kA[tid] = A.data[kc + tid];
+        if (kA) av = A.data[kc + tid];
     }
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan_u32(len, (uint32_t *)wt, &tot);
-    if (tid < n) kP[tid] = ex;
-    if (tid == 0) kP[n] = tot;
-    for (uint32_t i = n + 1 + tid; i <= (uint32_t)K_CAP; i += LG_BLOCK) kP[i] = 0xFFFFFFFFu;   // sentinels for the search
-    __syncthreads();
-    return tot;
+    // Only the k's that HAVE entries in the window are kept (most do not, in a narrow window): the
+    // walk below then crosses exactly one boundary per step instead of idling through runs of empty k's
+    // (those dependent LDS reads were 70 % of the expansion: profiles/r01z_spgemm_v3_expand_split.txt).
+    // One scan carries both the count of kept k's (high word) and the prefix of the lengths (low word).
+    uint64_t tot;
+    const uint64_t ex = block_excl_scan_u64_lds(((uint64_t)(len ? 1u : 0u) << 32) | len, wt, &tot);
+    const uint32_t kept = (uint32_t)(tot >> 32), total = (uint32_t)tot;
+    if (len) {
+        const uint32_t j = (uint32_t)(ex >> 32);
+        kS[j] = s;
+        kP[j] = (uint32_t)ex;
+        if (kA) kA[j] = av;
+    }
+    if (tid == 0) kP[kept] = total;
+    for (uint32_t i = kept + 1 + tid; i <= (uint32_t)K_CAP; i += LG_BLOCK) kP[i] = 0xFFFFFFFFu;   // sentinels for the search
+    lds_barrier();
+    return total;
 }
 
 // owner of flat position t < total: the last k with kP[k] <= t.  kP[0 .. K_CAP] is non-decreasing
@@ -369,10 +381,8 @@ struct FlatWalk {
     // returns true when the owner changed
     __device__ __forceinline__ bool advance(const uint64_t *kS, const uint32_t *kP, uint32_t t) {
         if (t < nxt) return false;
-        do {
-            ++o;
-            nxt = kP[o + 1];
-        } while (t >= nxt);
+        ++o;                      // kP is strictly increasing (empty k's are not staged): one step
+        nxt = kP[o + 1];
         base = kS[o] - kP[o];
         return true;
     }
@@ -382,11 +392,12 @@ template <int K_CAP, typename IDX, typename PTR>
 __device__ __forceinline__ void set_window_bits(const CsrView<IDX, PTR> &A, const CsrView<IDX, PTR> &B, uint64_t as,
                                                 uint64_t ae, uint64_t wlo, uint64_t whi, bool whole_row,
                                                 unsigned long long *bm, uint64_t *kS, uint32_t *kP, double *kA,
-                                                uint64_t *wt, uint32_t &fresh) {
+                                                uint64_t *wt, uint32_t &fresh, uint32_t &last_total) {
     const uint32_t tid = threadIdx.x;
     for (uint64_t kc = as; kc < ae; kc += K_CAP) {
         const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
         const uint32_t tot = stage_k_group<K_CAP>(A, B, kc, n, wlo, whi, whole_row, kS, kP, kA, wt);
+        last_total = tot;
         constexpr int EB = 8;             // consecutive entries per thread and trip
         uint32_t *bm32 = (uint32_t *)bm;  // little endian: column c is bit (c & 31) of half-word c >> 5
         for (uint32_t c0 = 0; c0 < tot; c0 += EB * LG_BLOCK) {
@@ -416,7 +427,7 @@ __device__ __forceinline__ void set_window_bits(const CsrView<IDX, PTR> &A, cons
                 }
             }
         }
-        __syncthreads();                  // the next group overwrites kS / kP
+        lds_barrier();                  // the next group overwrites kS / kP
     }
 }
 
@@ -442,13 +453,13 @@ __global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, P
     const int words = (int)((1ull << wl) / 64);
     const uint64_t wlo = w << wl, whi = wlo + (1ull << wl);   // not clamped to b_cols: see row_window
     for (int i = threadIdx.x; i < words; i += LG_BLOCK) bm[i] = 0;
-    __syncthreads();
-    uint32_t fresh = 0;
+    lds_barrier();
+    uint32_t fresh = 0, unused_total = 0;
     set_window_bits<Cfg::K_CAP>(A, B, (uint64_t)A.indptr[r], (uint64_t)A.indptr[r + 1], wlo, whi, ntasks[r] == 1, bm, kS, kP,
-                                (double *)nullptr, wt, fresh);
+                                (double *)nullptr, wt, fresh, unused_total);
     const uint64_t ws = wave_sum_u64(fresh);
     if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = ws;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) {
         uint64_t tot = 0;
         for (int i = 0; i < LG_WAVES; ++i) tot += red[i];
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                                                                  IDX *__restrict__ c_indices, double *__restrict__ c_data,
                                                                  unsigned long long *__restrict__ prof) {
     using Cfg = LgCfg<WL>;
-    constexpr int WPT = Cfg::WPT, TPS = Cfg::TPS, NSUPER = Cfg::NSUPER, ACC_CAP = Cfg::ACC_CAP, K_CAP = Cfg::K_CAP;
+    constexpr int WPT = Cfg::WPT, NSUPER = Cfg::NSUPER, ACC_CAP = Cfg::ACC_CAP, K_CAP = Cfg::K_CAP;
     __shared__ unsigned long long bm[Cfg::WORDS];   // the window's structure: one bit per column
     __shared__ uint16_t sub[Cfg::WORDS];            // outputs before a word inside its superblock
     __shared__ uint32_t super[NSUPER + 1];          // outputs before each 2048-column superblock
@@ -495,43 +506,62 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     long long t_prev = prof ? (long long)clock64() : 0;
     const long long t_begin = t_prev;
     uint32_t n_rounds = 0, n_chunks = 0;
+    // (accumulated in LDS and flushed once per task: a global atomic per mark serialises all workgroups
+    // on 16 addresses and every s_waitcnt vmcnt(0) after it then measures THAT, not the phase)
+    __shared__ unsigned long long pacc[16];
+    if (prof && tid < 16) pacc[tid] = 0;
     auto mark = [&](int phase) {
         if (prof && tid == 0) {
             const long long now = (long long)clock64();
-            atomicAdd(&prof[phase], (unsigned long long)(now - t_prev));
+            pacc[phase] += (unsigned long long)(now - t_prev);
             t_prev = now;
         }
     };
 
     for (int i = tid; i < words; i += LG_BLOCK) bm[i] = 0;
-    __syncthreads();
+    lds_barrier();
     uint32_t fresh = 0;
-    set_window_bits<Cfg::K_CAP>(A, B, as, ae, wlo, whi, whole_row, bm, kS, kP, kA, wt, fresh);
+    uint32_t k_total = 0;      // entries of the (last) staged group: reused by a one-group, one-pass task
+    set_window_bits<Cfg::K_CAP>(A, B, as, ae, wlo, whi, whole_row, bm, kS, kP, kA, wt, fresh, k_total);
     mark(0);   // clear + bits
 
-    // popcount prefix: thread tid owns words [WPT tid, WPT tid + WPT)
-    uint32_t local[WPT];
-    uint32_t mine = 0;
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        const int word = tid * WPT + i;
-        local[i] = mine;
-        mine += word < words ? (uint32_t)__popcll(bm[word]) : 0u;
-    }
-    uint32_t tot;
-    const uint32_t tpre = block_excl_scan_u32(mine, (uint32_t *)wt, &tot);
-    if (tid % TPS == 0) super[tid / TPS] = tpre;
-    if (tid == 0) super[NSUPER] = tot;
-    __syncthreads();
-    const uint32_t sbase = super[tid / TPS];
-    // indices come out sorted: walk the set bits in order
-    uint32_t run = tpre;
+    // popcount prefix.  Words are dealt to the threads INTERLEAVED (thread tid takes words tid, tid + 512, ...):
+    // consecutive lanes read consecutive LDS words (the blocked assignment, 16 consecutive words per thread at
+    // 2^19 columns, put all 64 lanes on two bank groups — 32-way conflicts on every read), and the dense low
+    // columns of a power-law window are spread over all threads instead of a few.  A superblock is 32 words =
+    // half a wave: its inner prefix is a 32-lane shuffle scan.  (Measured neutral on config 5 — this phase is
+    // a chain of dependent LDS operations either way, profiles/r01z_spgemm_v4_experiments.txt.)
+    static_assert(SUPER_WORDS == 32, "superblock = half a wave");
 #pragma unroll 1
     for (int i = 0; i < WPT; ++i) {
-        const int word = tid * WPT + i;
+        const int word = i * LG_BLOCK + (int)tid;
+        if (i * LG_BLOCK >= words) break;                       // block-uniform
+        const uint32_t pc = word < words ? (uint32_t)__popcll(bm[word]) : 0u;
+        uint32_t inc = pc;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off, 32);
+            if ((tid & 31u) >= (uint32_t)off) inc += o;
+        }
+        if (word < words) {
+            sub[word] = (uint16_t)(inc - pc);
+            if ((tid & 31u) == 31u) super[word / SUPER_WORDS] = inc;   // superblock total, turned into a prefix below
+        }
+    }
+    lds_barrier();
+    const int nsb = (words + SUPER_WORDS - 1) / SUPER_WORDS;       // <= NSUPER <= 512 = one per thread
+    uint32_t tot;
+    const uint32_t spre = block_excl_scan_u32_lds((int)tid < nsb ? super[tid] : 0u, (uint32_t *)wt, &tot);
+    if ((int)tid < nsb) super[tid] = spre;
+    if (tid == 0) super[nsb] = tot;
+    lds_barrier();
+    // indices come out sorted: walk the set bits of each word in order
+#pragma unroll 1
+    for (int i = 0; i < WPT; ++i) {
+        const int word = i * LG_BLOCK + (int)tid;
         if (word >= words) break;
-        sub[word] = (uint16_t)(tpre + local[i] - sbase);
         unsigned long long m = bm[word];
+        uint32_t run = super[word / SUPER_WORDS] + sub[word];
         while (m) {
             const int b = __ffsll((long long)m) - 1;
             m &= m - 1;
@@ -539,7 +569,6 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
             ++run;
         }
     }
-    __syncthreads();
     mark(1);   // prefix + emit indices
 
     // ---- values ----------------------------------------------------------------------------------
@@ -571,7 +600,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
             // the tags must be in place before anyone posts on them: a late NO_TAG landing between two posts on
             // the same accumulator would let the LATER entry win a round (seen once as a 1-ulp difference in
             // 33 M checked values when the staging below is skipped and no other barrier intervenes)
-            __syncthreads();
+            lds_barrier();
             const bool single = pb == 0 && pe == (uint32_t)nsuper;
             const uint64_t plo = wlo + (uint64_t)pb * (SUPER_WORDS * 64);
             const uint64_t phi = wlo + (uint64_t)pe * (SUPER_WORDS * 64);
@@ -579,7 +608,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                 const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
                 // a task with one group of k's and one pass finds kS / kP / kA as the bit pass left them
                 const uint32_t gtot = (single && one_group)
-                                          ? kP[n]
+                                          ? k_total
                                           : stage_k_group<K_CAP>(A, B, kc, n, single ? wlo : plo, single ? whi : phi,
                                                                  single && whole_row, kS, kP, kA, wt);
                 mark(8);
@@ -613,12 +642,20 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                             av[u] = 0.0;
                         }
                     }
+                    if (prof) {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        mark(2);   // owner search + walk (LDS only)
+                    }
                     uint32_t cc[U];
                     double bv[U];
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         cc[u] = pend[u] ? (uint32_t)((uint64_t)B.indices[pos[u]] - wlo) : 0u;
                         bv[u] = pend[u] ? B.data[pos[u]] : 0.0;
+                    }
+                    if (prof) {
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        mark(4);   // the 2 U loads of B entries
                     }
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
@@ -645,7 +682,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                                 if (pend[u]) atomicMin(&tag[slot[u]], pos_in_chunk[u]);
                         }
                         if (tid == 0) more_flag[(rd + 1) % 3] = 0;
-                        __syncthreads();
+                        lds_barrier();
                         if (wave_pending) {
                             bool more = false;
 #pragma unroll
@@ -662,7 +699,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                             }
                             if (more) more_flag[rd % 3] = 1;
                         }
-                        __syncthreads();
+                        lds_barrier();
                         if (!more_flag[rd % 3]) {                                     // block-uniform
                             ++rd;
                             break;
@@ -672,13 +709,15 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                 mark(9);
             }
             for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
-            __syncthreads();
+            lds_barrier();
             mark(10);
-            if (prof && tid == 0) atomicAdd(&prof[11], 1ull);
+            if (prof && tid == 0) pacc[11] += 1ull;
         }
         pb = pe;
     }
     if (prof && tid == 0) {
+        for (int i = 0; i < 13; ++i)
+            if (i != 6 && pacc[i]) atomicAdd(&prof[i], pacc[i]);
         atomicAdd(&prof[6], 1ull);
         atomicAdd(&prof[13], (unsigned long long)n_chunks);
         atomicAdd(&prof[14], (unsigned long long)n_rounds);
@@ -845,8 +884,8 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         if (hipMemcpy(h, prof.p, 128, hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr,
                     "[spgemm_prof] inside the value passes: staging %llu, expand %llu, ordered add %llu, writeback %llu cycles; "
-                    "passes %llu, chunks %llu, rounds %llu; longest task %llu cycles\n",
-                    h[8], h[12], h[9], h[10], h[11], h[13], h[14], h[15]);
+                    "passes %llu, chunks %llu, rounds %llu; longest task %llu cycles; expand = search %llu + loads %llu + rank\n",
+                    h[8], h[12] + h[2] + h[4], h[9], h[10], h[11], h[13], h[14], h[15], h[2], h[4]);
             fprintf(stderr,
                     "[spgemm_prof] thread-0 cycles summed over large tasks: bits %llu, prefix+emit %llu; tasks %llu\n", h[0],
                     h[1], h[6]);
