@@ -31,7 +31,9 @@ class RowShardedSpMV:
     block = (rows, cols, indptr, indices, data) with a zero-based indptr.
     """
 
-    def __init__(self, shape, indptr, indices, data, local_spmv, group=None, row_weight=8.0):
+    def __init__(self, shape, indptr, indices, data, local_spmv, group=None, row_weight=8.0, exchange="direct"):
+        assert exchange in ("direct", "allgather")
+        self.mode = exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -50,10 +52,36 @@ class RowShardedSpMV:
         self.local_spmv = local_spmv
         self.y = torch.zeros(self.rows, dtype=torch.float64, device=indptr.device)
 
+    def _exchange_allgather(self):
+        """Fallback: one padded all_gather (ring or tree inside the library) + unpack.  Moves
+        world * max_block doubles instead of rows, and a ring is bound by one xGMI link."""
+        pad = max(b - a for a, b in zip(self.cuts, self.cuts[1:]))
+        if not hasattr(self, "_ag"):
+            self._ag = torch.zeros(self.world * pad, dtype=torch.float64, device=self.y.device)
+            self._mine = torch.zeros(pad, dtype=torch.float64, device=self.y.device)
+        self._mine[:self.r1 - self.r0].copy_(self.y[self.r0:self.r1])
+        dist.all_gather_into_tensor(self._ag, self._mine, group=self.group)
+        for peer in range(self.world):
+            if peer != self.rank:
+                a, b = self.cuts[peer], self.cuts[peer + 1]
+                self.y[a:b].copy_(self._ag[peer * pad:peer * pad + (b - a)])
+
     def exchange(self):
         """all-gather-v of y: direct send/recv with every peer, one group."""
         if self.world == 1:
             return
+        if self.mode == "allgather":
+            return self._exchange_allgather()
+        try:
+            self._exchange_direct()
+        except RuntimeError as e:                     # e.g. a backend without grouped P2P on this topology
+            import sys
+            print("sprs_amd.dist: direct exchange failed (%s); falling back to all_gather" % str(e).splitlines()[0],
+                  file=sys.stderr)
+            self.mode = "allgather"
+            self._exchange_allgather()
+
+    def _exchange_direct(self):
         mine = self.y[self.r0:self.r1]
         ops = []
         for peer in range(self.world):

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, steps, ret):
+def _worker(rank, world, port, n, steps, ret, exchange="direct"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, n, steps, ret):
                                        dt.numpy(), x.numpy(), y)
             y_block.copy_(torch.from_numpy(y))
 
-        sh = RowShardedSpMV((n, n), indptr, indices, data, local_spmv)
+        sh = RowShardedSpMV((n, n), indptr, indices, data, local_spmv, exchange=exchange)
         assert sh.world == world and sh.rank == rank
         x = gen.dense_vector(n)
         for _ in range(steps):                       # y becomes the next x, as an iterative solver would
@@ -58,6 +58,14 @@ def _worker(rank, world, port, n, steps, ret):
         ret[rank] = (bool(ok), sh.block_nnz, blocks, sh.cuts)
     finally:
         dist.destroy_process_group()
+
+
+def test_row_sharded_spmv_gloo_allgather_fallback():
+    """the padded all_gather the driver falls back to when the grouped send/recv is refused"""
+    n = 3000
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), n, 2, ret, "allgather"), nprocs=2, join=True)
+    assert len(ret) == 2 and all(ret[r][0] for r in range(2))
 
 
 @pytest.mark.parametrize("world", [2, 3])
