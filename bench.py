@@ -42,12 +42,15 @@ def main():
     ap.add_argument("--workload", default="rmat10m")
     ap.add_argument("--idx-bytes", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--permute-cols", type=int, default=0,
+                    help="experiment: relabel the columns by a random permutation (seed given) before the run")
     ap.add_argument("--kernel", type=int, default=None, help="spmv_kernel option for A/B (1 tiled, 2 wave-per-row)")
     ap.add_argument("--xcs", type=int, default=None, help="XCD-sliced plan: 0 auto, 1 on, 2 off")
     ap.add_argument("--split", type=int, default=None, help="row-length threshold of the sliced part")
     ap.add_argument("--idx32", type=int, default=None, help="plan copies with 32-bit column ids: 1 on (default), 0 off")
     ap.add_argument("--sort", type=int, default=None, help="plan copies with column-sorted tiles: 1 on (default), 0 off")
     ap.add_argument("--tile", type=int, default=None, help="nnz per workgroup tile: 2048 or 4096")
+    ap.add_argument("--relabel", type=int, default=None, help="sliced plan column relabelling: 0 auto, 1 on, 2 off")
     ap.add_argument("--ldspad", type=int, default=None, help="extra dynamic LDS per workgroup (occupancy cap, tuning)")
     ap.add_argument("--xmask", type=int, default=None, help="timing experiment only: gather x[col & mask]")
     args = ap.parse_args()
@@ -75,7 +78,7 @@ def main():
     from sprs_amd import _ffi
     import ctypes as C
     _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
-    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_lds_pad", args.ldspad), ("spmv_xmask", args.xmask)):
+    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_relabel", args.relabel), ("spmv_lds_pad", args.ldspad), ("spmv_xmask", args.xmask)):
         if val is not None:
             sprs_amd.set_option(opt, val)
 
@@ -104,6 +107,36 @@ def main():
         sys.exit("unknown workload " + wl)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
+    if args.permute_cols:
+        # same sparsity statistics, but the hub columns no longer sit at 0, 2^k, 2^j + 2^k: separates what the
+        # power-law costs from what the ADDRESSES of its hot x entries cost (L2 channel hot-spotting)
+        if args.permute_cols > 0:
+            g = torch.Generator(device=dev)
+            g.manual_seed(args.permute_cols)
+            perm = torch.randperm(n, device=dev, generator=g).to(indices.dtype)
+        elif args.permute_cols <= -2:   # -K: the K hottest columns move to the front (natural order inside), rest follows
+            cnt = torch.bincount(indices.long(), minlength=n)
+            thr = torch.sort(cnt, descending=True).values[-args.permute_cols]
+            hot = cnt > thr
+            order_c = torch.cat([torch.nonzero(hot).flatten(), torch.nonzero(~hot).flatten()])
+            perm = torch.empty(n, dtype=indices.dtype, device=dev)
+            perm[order_c] = torch.arange(n, device=dev, dtype=indices.dtype)
+            del cnt, order_c, hot
+        else:   # -1: relabel by decreasing column count (hub columns become 0, 1, 2, ...)
+            cnt = torch.bincount(indices.long(), minlength=n)
+            order_c = torch.argsort(cnt, descending=True, stable=True)
+            perm = torch.empty(n, dtype=indices.dtype, device=dev)
+            perm[order_c] = torch.arange(n, device=dev, dtype=indices.dtype)
+            del cnt, order_c
+        indices = perm[indices.long()]
+        # rows must stay sorted by column (CsMat invariant): sort inside rows via a (row, col) key
+        rows_of = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
+        key = (rows_of << 32) | indices.long()
+        key, order = torch.sort(key)
+        indices = (key & 0xFFFFFFFF).to(idt)
+        data = data[order]
+        del rows_of, key, order, perm
+        name += " [columns permuted]" if args.permute_cols > 0 else " [columns relabelled by decreasing count]"
     nnz_total = indices.numel()
     x = gen.dense_vector(n, seed=3, device=dev)
     stream = torch.cuda.current_stream()
@@ -163,7 +196,7 @@ def main():
     # counter passes of the same command (scripts/gpu_pmc.sh -> profiles/pmc_traffic.json) and is
     # only filled in when workload, index width and options match that run.
     traffic = None
-    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.sort, args.tile, args.ldspad, args.xmask))
+    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.sort, args.tile, args.ldspad, args.xmask, args.relabel)) and not args.permute_cols
     try:
         if world == 1 and defaults:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -11,7 +11,7 @@ import re
 import sys
 
 PER_SPMV = ("spmv_tile_kernel", "spmv_sliced_kernel", "spmv_carry_kernel", "spmv_sliced_carry_kernel",
-            "xcs_reduce_kernel", "spmv_rowwave_kernel")
+            "xcs_reduce_kernel", "spmv_rowwave_kernel", "rl_permute_x_kernel")
 
 
 def main():

@@ -150,12 +150,15 @@ void SpmvPlan::release() {
     }
     drop(long_rows);
     drop(slab);
+    drop(perm);
+    perm = nullptr;
     long_rows = nullptr;
     slab = nullptr;
     for (auto &kv : scratch) {
         drop(kv.second.carry_main);
         drop(kv.second.carry_slices);
         drop(kv.second.partial);
+        drop(kv.second.xp);
     }
     scratch.clear();
     n_long = 0;
@@ -570,6 +573,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         o.spmv_xcs_split = value;
     } else if (!strcmp(name, "spmv_xcs_idx32")) {
         o.spmv_xcs_idx32 = value ? 1 : 0;
+    } else if (!strcmp(name, "spmv_relabel")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_relabel must be 0 (auto), 1 (on) or 2 (off)");
+        o.spmv_relabel = value;
     } else if (!strcmp(name, "spmv_sort_tiles")) {
         o.spmv_sort_tiles = value ? 1 : 0;
     } else if (!strcmp(name, "spmv_tile")) {
@@ -611,6 +617,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_xcs_split")) *value = o.spmv_xcs_split;
     else if (!strcmp(name, "spmv_xcs_idx32")) *value = o.spmv_xcs_idx32;
     else if (!strcmp(name, "spmv_sort_tiles")) *value = o.spmv_sort_tiles;
+    else if (!strcmp(name, "spmv_relabel")) *value = o.spmv_relabel;
     else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
     else if (!strcmp(name, "spgemm_bucket")) *value = o.spgemm_bucket;
     else if (!strcmp(name, "spgemm_prof")) *value = o.spgemm_prof;

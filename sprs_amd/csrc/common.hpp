@@ -43,6 +43,7 @@ struct Options {
     int64_t spmv_xcs_split = 32;   // rows with >= this many entries go to the sliced part
     int64_t spmv_xcs_idx32 = 1;    // plan-owned copies store 32-bit column ids when cols < 2^32
     int64_t spmv_sort_tiles = 0;   // plan copies: entries of a tile sorted by column (measured 10 % SLOWER: profiles/r01v)
+    int64_t spmv_relabel = 0;      // sliced plan: columns relabelled by count class, x permuted per SpMV: 0 auto (on), 1 on, 2 off
     int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
     int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
@@ -73,12 +74,13 @@ struct SpmvScratch {               // per stream: nothing in here is shared betw
     double *carry_main = nullptr;
     double *carry_slices = nullptr;
     double *partial = nullptr;     // XCS_SLICES x n_long partial row sums
+    double *xp = nullptr;          // x in the plan's column labelling (relabelled plans)
 };
 
 struct SpmvPlan {
     bool built = false;
     bool xcs = false;
-    int64_t opt_xcs = -1, opt_split = -1, opt_idx32 = -1, opt_tile = -1, opt_sort = -1;   // option values the plan was built with
+    int64_t opt_xcs = -1, opt_split = -1, opt_idx32 = -1, opt_tile = -1, opt_sort = -1, opt_relabel = -1;   // option values the plan was built with
     uint32_t tile = 0;             // nnz per tile
     int idx_bytes = 8;             // width of the column ids the kernels read (handle's, or 4 for plan copies)
     CsrPiece main;                 // the whole matrix (plain plan) or its short rows (sliced plan)
@@ -86,6 +88,8 @@ struct SpmvPlan {
     uint64_t slice_tile_off[XCS_SLICES + 1] = {0};
     uint64_t n_long = 0;
     uint64_t *long_rows = nullptr; // device: original row of long row j
+    uint32_t *perm = nullptr;      // device, cols entries: plan label of column j (relabelled plans), else null
+    uint64_t cols = 0;
     void *slab = nullptr;          // backing store of all plan-owned arrays
     std::unordered_map<void *, SpmvScratch> scratch;
     void release();

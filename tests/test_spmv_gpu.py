@@ -97,6 +97,41 @@ def test_rmat_vs_oracle(hip, idx, ptr, xcs, idx32, srt):
         hip.set_option("spmv_sort_tiles", 0)
 
 
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_column_relabelling(hip, idx, ptr):
+    """The sliced plan renumbers the columns by popularity class and permutes x per SpMV (spmv.hip rl_*).
+    Which x-slice an entry falls into follows its label, so the 8 partial sums of a row group the same
+    products differently: equal to the oracle within tolerance either way, to each other within rounding,
+    and bit-identical from one SpMV to the next on the same handle (cached plan + scratch); accumulate
+    form and columns nobody references included."""
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    n = 70000
+    indptr, indices, data = gen.rmat_csr(n, 24, seed=17)
+    a_host = ((n, n), indptr.numpy().astype(ptr), indices.numpy().astype(idx), data.numpy())
+    x = gen.dense_vector(n, seed=5).numpy()
+    ref = oracle_spmv(*a_host, x)
+    out = {}
+    try:
+        hip.set_option("spmv_xcs", 1)
+        for relabel in (1, 2):
+            hip.set_option("spmv_relabel", relabel)
+            a = DeviceCsMat.from_host(*a_host)
+            xv = DeviceVec.from_host(x)
+            y1 = (a * xv).to_host()
+            y2 = (a * xv).to_host()                  # second SpMV: cached plan + scratch
+            assert np.array_equal(y1, y2)
+            yacc = DeviceVec.from_host(np.ones(n))
+            prod.mul_acc_mat_vec_csr(a, xv, yacc)
+            assert rel_err(yacc.to_host(), ref + 1.0) <= TOL
+            out[relabel] = y1
+            assert rel_err(y1, ref) <= TOL
+        assert rel_err(out[1], out[2]) <= 1e-13 and not np.array_equal(out[1], np.zeros(n))
+    finally:
+        hip.set_option("spmv_xcs", 0)
+        hip.set_option("spmv_relabel", 0)
+
+
 def test_laplacian_componentwise_bound(hip):
     # config 3 shape at test size; mixed signs -> |dy_i| <= 1e-10 (|A||x|)_i  (SURVEY §8d)
     from oracle import oracle
