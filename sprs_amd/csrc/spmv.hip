@@ -348,7 +348,7 @@ __global__ void xcs_classify_kernel(const PTR *__restrict__ indptr, uint64_t row
 // An L2 line holds 16 consecutive x entries.  In the natural labelling a hub column shares its
 // line with 15 columns of arbitrary (on R-MAT: up to 100x lower) popularity, so most of what the
 // 4 MiB of an XCD's L2 caches is cold.  The plan therefore renumbers the columns by POPULARITY
-// CLASS — floor(log2(count)), most popular first, natural order inside a class (one stable
+// CLASS — half octaves of the count, most popular first, natural order inside a class (one stable
 // counting-sort pass) — so that lines are homogeneous, and gathers x into that order at the start
 // of every SpMV (one pass over x: ~0.05 ms at 10 M columns).  Measured on the R-MAT 10 M matrix
 // with the columns relabelled up front: 1.83 -> 1.68 ms; with the K hottest columns merely moved
@@ -358,18 +358,32 @@ __global__ void xcs_classify_kernel(const PTR *__restrict__ indptr, uint64_t row
 // differences, same run-to-run determinism).
 // ---------------------------------------------------------------------------
 constexpr int RL_CHUNK = 1024;            // columns per wave in the counting sort
-constexpr int RL_DIGITS = 33;             // class 0 (never referenced) .. 32
+constexpr int RL_DIGITS = 64;             // half-octave classes: 2 floor(log2 c) + (next bit of c) + 1; 0 = never referenced
 
 __device__ __forceinline__ uint32_t rl_digit(uint32_t count) {
-    const uint32_t cls = count ? 32u - (uint32_t)__clz(count) : 0u;   // 1 + floor(log2(count)), 0 for unused columns
-    return 32u - cls;                                                  // most popular first
+    uint32_t cls = 0;
+    if (count) {
+        uint32_t e = 31u - (uint32_t)__clz(count);                    // floor(log2(count))
+        if (e > 30u) e = 30u;
+        const uint32_t half = e ? (count >> (e - 1u)) & 1u : 0u;
+        cls = 2u * e + half + 1u;                                      // 1 .. 62
+    }
+    return 63u - cls;                                                  // most popular first
 }
+
+// Exact counts (RL_SAMPLE = 1).  The atomics on the hub columns serialise in L2 — counting the 3.2e8 entries
+// of the R-MAT 10M matrix takes 29 ms, half of the plan build — but estimating the popularity from every 4th
+// entry (8 ms) mis-bins the rarely used columns and costs the SpMV 3 % (1.454 vs 1.415 ms for the sliced
+// kernel, profiles/r01z_spmv_column_labelling.txt): the plan is built once, the SpMV runs many times.
+constexpr uint64_t RL_SAMPLE = 1;
 
 template <typename IDX>
 __global__ __launch_bounds__(256) void rl_count_kernel(const IDX *__restrict__ indices, uint64_t nnz,
                                                        uint32_t *__restrict__ cnt) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) atomicAdd(&cnt[indices[p]], 1u);
+    const uint64_t n = (nnz + RL_SAMPLE - 1) / RL_SAMPLE;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride)
+        atomicAdd(&cnt[indices[q * RL_SAMPLE]], 1u);
 }
 
 // one wave per chunk of RL_CHUNK columns; lane d keeps the number of columns of digit d
