@@ -132,7 +132,10 @@ def main():
         # rows must stay sorted by column (CsMat invariant): sort inside rows via a (row, col) key
         rows_of = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
         key = (rows_of << 32) | indices.long()
-        key, order = torch.sort(key)
+        if os.environ.get("BENCH_NO_RESORT"):   # experiment: keep the entries in their old order (rows no longer sorted)
+            order = torch.arange(key.numel(), device=dev)
+        else:
+            key, order = torch.sort(key)
         indices = (key & 0xFFFFFFFF).to(idt)
         data = data[order]
         del rows_of, key, order, perm
