@@ -101,3 +101,81 @@ class RowShardedSpMV:
         self.local_spmv(self.block, x, self.y[self.r0:self.r1])
         self.exchange()
         return self.y
+
+
+def hip_local_spgemm(a_block, b):
+    """the HIP SpGEMM on torch-resident operands (borrowed, no copy); returns a DeviceCsMat"""
+    from . import smmp
+    from .device import DeviceCsMat
+    da = DeviceCsMat.wrap_torch(a_block[0], a_block[1], a_block[2], a_block[3])
+    db = DeviceCsMat.wrap_torch(b[0], b[1], b[2], b[3])
+    return smmp.mul_csr_csr(da, db)
+
+
+class RowShardedSpGEMM:
+    """C = A * B with A split into row blocks over the process group, B replicated — the rows of C are
+    independent (`smmp::numeric` doc, sprs/src/sparse/smmp.rs:136-140), so there is NO exchange: rank g
+    computes and keeps C[r_g:r_{g+1}, :].  The blocks are balanced by the number of PRODUCTS
+    sum_{k in A_i} nnz(B_k) (what the SpGEMM kernels' time follows), not by nnz(A).
+
+    a / b: (shape, indptr, indices, data) torch tensors on this rank's device (every rank holds or
+    generates the same operands); local_spgemm(a_block, b) -> rank-local result, by default the HIP path
+    on the GPU box.  `gather_indptr()` is the one optional collective: the global row pointer of C (the
+    prefix sum over ranks of the local nnz, as mul_csr_csr_with_workspace concatenates its chunks,
+    smmp.rs:320-331)."""
+
+    def __init__(self, a, b, local_spgemm=None, group=None, virtual=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if virtual is not None:                       # (rank, world) without a process group: one-GPU tests
+            self.rank, self.world = virtual
+        if local_spgemm is None:
+            local_spgemm = hip_local_spgemm
+        (self.rows, self.inner), a_ip, a_ix, a_dt = a
+        (b_rows, self.cols), b_ip, _, _ = b
+        if self.inner != b_rows:
+            raise ValueError("Dimension mismatch")                       # smmp.rs:207
+        # products per row of A, and their prefix: the cost the blocks are balanced on
+        b_len = (b_ip[1:] - b_ip[:-1]).to(torch.float64)
+        per_entry = b_len[a_ix.long()]
+        cost = torch.zeros(self.rows + 1, dtype=torch.float64, device=a_ip.device)
+        csum = torch.cumsum(per_entry, 0)
+        ends = (a_ip[1:] - a_ip[0]).long()
+        cost[1:] = torch.where(ends > 0, csum[(ends - 1).clamp(min=0)], torch.zeros((), dtype=torch.float64,
+                                                                                     device=a_ip.device))
+        cost[1:] = torch.cummax(cost[1:], 0).values                      # empty rows inherit the running total
+        self.cuts = gen.balanced_row_blocks(cost.to(torch.float64), self.world)
+        r0, r1 = self.cuts[self.rank], self.cuts[self.rank + 1]
+        lo, hi = int(a_ip[r0] - a_ip[0]), int(a_ip[r1] - a_ip[0])
+        self.r0, self.r1 = r0, r1
+        self.block_products = float(cost[r1] - cost[r0])
+        self.a_block = ((r1 - r0, self.inner), (a_ip[r0:r1 + 1] - a_ip[r0]).contiguous(), a_ix[lo:hi].clone(),
+                        a_dt[lo:hi].clone())
+        self.b = b
+        self.local_spgemm = local_spgemm
+        self.c_block = None
+
+    def multiply(self):
+        """rank-local C[r0:r1, :]"""
+        self.c_block = self.local_spgemm(self.a_block, self.b)
+        return self.c_block
+
+    def gather_indptr(self, local_indptr):
+        """global indptr of C from the ranks' zero-based local ones (a device/CPU int64 tensor of r1-r0+1)."""
+        nnz_local = torch.tensor([int(local_indptr[-1])], dtype=torch.int64, device=local_indptr.device)
+        if self.world == 1:
+            return local_indptr.clone()
+        all_nnz = [torch.zeros_like(nnz_local) for _ in range(self.world)]
+        dist.all_gather(all_nnz, nnz_local, group=self.group)
+        base = sum(int(v) for v in all_nnz[:self.rank])
+        pieces = [torch.zeros(self.cuts[g + 1] - self.cuts[g] + 1, dtype=torch.int64, device=local_indptr.device)
+                  for g in range(self.world)]
+        # variable lengths: pad to the longest block for the collective
+        pad = max(p.numel() for p in pieces)
+        mine = torch.zeros(pad, dtype=torch.int64, device=local_indptr.device)
+        mine[:local_indptr.numel()] = local_indptr.to(torch.int64) + base
+        got = [torch.zeros(pad, dtype=torch.int64, device=local_indptr.device) for _ in range(self.world)]
+        dist.all_gather(got, mine, group=self.group)
+        out = [got[g][:pieces[g].numel()] for g in range(self.world)]
+        return torch.cat([out[0]] + [o[1:] for o in out[1:]])

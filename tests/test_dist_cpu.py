@@ -81,3 +81,48 @@ def test_row_sharded_spmv_gloo(world):
         assert block_nnz == blocks[rank]
     total = sum(ret[0][2])
     assert max(ret[0][2]) <= total / world * 1.6       # cost-balanced (nnz + 8/row) despite the power law
+
+
+def _spgemm_worker(rank, world, port, n, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        from sprs_amd import gen
+        from sprs_amd.dist import RowShardedSpGEMM
+        indptr, indices, data = gen.rmat_csr(n, 6, seed=9)
+        u = lambda t: t.numpy().astype(np.uint64)
+
+        def local_spgemm(a_block, b):                 # CPU stand-in for the HIP SpGEMM
+            (ar, ac), aip, aix, adt = a_block
+            (br, bc), bip, bix, bdt = b
+            assert int(aip[0]) == 0
+            return oracle.mul_csr_csr((ar, ac), u(aip), u(aix), adt.numpy(), (br, bc), u(bip), u(bix), bdt.numpy(),
+                                      threads=1)
+
+        sh = RowShardedSpGEMM(((n, n), indptr, indices, data), ((n, n), indptr, indices, data), local_spgemm)
+        shape, cip, cix, cdt = sh.multiply()
+        assert shape == (sh.r1 - sh.r0, n)
+        full_ip = sh.gather_indptr(torch.from_numpy(cip.astype(np.int64)))
+        rshape, rip, rix, rdt = oracle.mul_csr_csr((n, n), u(indptr), u(indices), data.numpy(), (n, n), u(indptr),
+                                                   u(indices), data.numpy(), threads=1)
+        lo, hi = int(rip[sh.r0]), int(rip[sh.r1])
+        ok = (np.array_equal(full_ip.numpy().astype(np.uint64), rip) and np.array_equal(cix, rix[lo:hi])
+              and np.array_equal(cdt, rdt[lo:hi]))
+        ret[rank] = (bool(ok), sh.block_products, sh.cuts)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_spgemm_gloo(world):
+    """SpGEMM by A-row blocks, B replicated, no data-path collective: every rank's block of C equals the
+    same rows of the single-process product bit for bit, the gathered indptr equals the global one, and
+    the blocks are balanced by products despite the power law."""
+    ret = mp.Manager().dict()
+    n = 4000
+    mp.spawn(_spgemm_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    assert len(ret) == world and all(ret[r][0] for r in range(world))
+    prods = [ret[r][1] for r in range(world)]
+    assert max(prods) <= sum(prods) / world * 1.5

@@ -218,6 +218,33 @@ def test_result_pool_reuse_and_trim(hip):
     hip.set_option("pool", 1)
 
 
+def test_row_blocks_virtual_ranks(hip):
+    """The multi-GPU SpGEMM driver (sprs_amd/dist.py RowShardedSpGEMM: A by product-balanced row blocks, B
+    replicated, no exchange) with 4 virtual ranks on the one GPU: the blocks of C, one after the other,
+    are the rows of the single-handle product bit for bit."""
+    import torch
+    from sprs_amd import gen
+    from sprs_amd.device import DeviceCsMat
+    from sprs_amd.dist import RowShardedSpGEMM
+    dev = torch.device("cuda", 0)
+    n = 50000
+    indptr, indices, data = gen.rmat_csr(n, 8, seed=31, device=dev)
+    a = ((n, n), indptr, indices, data)
+    whole = (DeviceCsMat.wrap_torch(*a) * DeviceCsMat.wrap_torch(*a)).to_host()
+    cuts_seen, prods = None, []
+    for g in range(4):
+        sh = RowShardedSpGEMM(a, a, virtual=(g, 4))
+        shape, ip, ix, dt = sh.multiply().to_host()
+        lo, hi = int(whole[1][sh.r0]), int(whole[1][sh.r1])
+        assert shape == (sh.r1 - sh.r0, n)
+        assert np.array_equal(ip + np.uint64(lo), whole[1][sh.r0:sh.r1 + 1])
+        assert np.array_equal(ix, whole[2][lo:hi]) and np.array_equal(dt, whole[3][lo:hi])
+        assert cuts_seen in (None, sh.cuts)
+        cuts_seen = sh.cuts
+        prods.append(sh.block_products)
+    assert cuts_seen[0] == 0 and cuts_seen[-1] == n and max(prods) <= sum(prods) / 4 * 1.3
+
+
 def test_contract_violations(hip, golden):
     from sprs_amd import SprsHipError, _ffi, smmp
     from sprs_amd.device import DeviceCsMat
