@@ -152,4 +152,12 @@ inline DeviceVec operator*(const DeviceCsMat &a, const DeviceVec &x) {
 // `&A * &B` (csmat.rs:1866-1888)
 inline DeviceCsMat operator*(const DeviceCsMat &a, const DeviceCsMat &b) { return smmp::mul_csr_csr(a, b); }
 
+// Result blocks released by ~DeviceCsMat stay in the library's pool for the next result (sprs_hip.h);
+// this hands them back to the driver.  Returns the bytes released.
+inline uint64_t pool_trim() {
+    uint64_t freed = 0;
+    check(sprs_hip_pool_trim(&freed));
+    return freed;
+}
+
 }  // namespace sprs_hip
