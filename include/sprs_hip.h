@@ -166,6 +166,35 @@ int32_t sprs_hip_spmm_rowmaj_f64(const sprs_hip_csmat *a, const double *rhs_dev,
                                  uint64_t k, uint64_t ld_rhs, double *out_dev, uint64_t out_rows,
                                  uint64_t ld_out, int32_t accumulate, void *stream);
 
+/* ---- BiCGSTAB: a caller that loops on the SpMV -------------- */
+
+/* Counters and scalars of sprs::linalg::bicgstab::BiCGSTAB after solve()
+ * (iteration_count / soft_restart_count / hard_restart_count / err / rho,
+ * bicgstab.rs:236-262); converged = solve() returned Ok rather than Err. */
+typedef struct sprs_hip_bicgstab_info {
+    uint64_t iteration_count;
+    uint64_t soft_restart_count;
+    uint64_t hard_restart_count;
+    double err;
+    double rho;
+    int32_t converged;
+} sprs_hip_bicgstab_info;
+
+/* Twin of BiCGSTAB::solve(a, x0, b, tol, max_iter) (bicgstab.rs:148-171) with device-resident dense
+ * vectors: solves A x = b from the start vector x0, unpreconditioned, with the reference's soft restart
+ * (|rho| / err^2 < soft_restart_threshold; the reference's default is 0.1, with_restart_threshold) and
+ * hard restart (true residual recomputed before convergence is claimed).  A: square CSR or CSC handle
+ * (a CSC operand is converted once on the device).  x0_dev, b_dev, x_dev: n doubles each; x_dev may not
+ * alias x0_dev / b_dev.  Like the reference, running out of iterations is not an error: the status is
+ * SPRS_HIP_OK, info->converged is 0 and x_dev holds the last iterate.  SPRS_HIP_DIM_MISMATCH unless
+ * A.rows == A.cols == n.  Blocks until done (the restart decisions need the scalars on the host).
+ * Element-wise arithmetic is bit-identical to the reference's; dot products are serial (== reference)
+ * for n <= 2048 — the reference's own 4 x 4 test system reproduces bit for bit — and a fixed two-level
+ * tree above; the SpMVs are sprs_hip_spmv_f64.  Deterministic run to run. */
+int32_t sprs_hip_bicgstab_f64(sprs_hip_csmat *a, const double *x0_dev, const double *b_dev, uint64_t n,
+                              double tol, uint64_t max_iter, double soft_restart_threshold, double *x_dev,
+                              sprs_hip_bicgstab_info *info, void *stream);
+
 /* ---- SpGEMM ------------------------------------------------------------- */
 
 /* Twin of smmp::mul_csr_csr (smmp.rs:196-416): C = A * B, all CSR, same index

@@ -266,3 +266,27 @@ def csmat_mul_csmat(lhs, rhs, threads=0):
     if (ls, rs) == ("CSC", "CSR"):
         return t_view(csr_csr(t_view(other(rhs)), t_view(lhs)))
     return t_view(csr_csr(t_view(rhs), t_view(lhs)))
+
+
+class BicgstabInfo(C.Structure):
+    _fields_ = [("iteration_count", C.c_uint64), ("soft_restart_count", C.c_uint64),
+                ("hard_restart_count", C.c_uint64), ("err", C.c_double), ("rho", C.c_double),
+                ("converged", C.c_int32)]
+
+
+def bicgstab(shape, indptr, indices, data, x0, b, tol, max_iter, soft_restart_threshold=0.1, storage="CSR"):
+    """BiCGSTAB::solve (sprs/src/sparse/linalg/bicgstab.rs:148-171) on dense vectors; a CSC operand is
+    converted first (its product adds ascending k as well).  Returns (x, info dict)."""
+    n = shape[0]
+    assert shape[0] == shape[1] == np.asarray(x0).size == np.asarray(b).size
+    indptr, indices, data = _canon(indptr, indices, data)
+    if storage == "CSC":
+        indptr, indices, data = convert_storage(n, n, indptr, indices, data)
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(n)
+    info = BicgstabInfo()
+    f = getattr(lib(), "oracle_bicgstab_" + _suffix(indices, indptr))
+    _chk(f(C.c_uint64(n), _p(indptr), _p(indices), _p(data), _p(x0), _p(b), C.c_double(tol), C.c_uint64(max_iter),
+           C.c_double(soft_restart_threshold), _p(x), C.byref(info)))
+    return x, {k: getattr(info, k) for k, _ in BicgstabInfo._fields_}

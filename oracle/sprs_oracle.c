@@ -11,6 +11,7 @@
  *
  * Build: see oracle/Makefile (gcc -O3 -ffp-contract=off -fopenmp).
  */
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -477,3 +477,104 @@ int SUF(oracle_check_structure)(uint64_t inner, uint64_t outer, const PTR_T *ind
     }
     return ORACLE_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * BiCGSTAB — restatement of sprs/src/sparse/linalg/bicgstab.rs (solver for A x = b, unpreconditioned).
+ *
+ * The reference keeps every vector as a CsVec and multiplies with `&CsMat * &CsVec`
+ * (csr_mul_csvec, prod.rs:162-184: one sparse dot per row, ascending column; a CSC matrix takes the
+ * SpGEMM route, which also adds ascending k).  For vectors without structural zeros that is, entry for
+ * entry and addition for addition, the dense arithmetic below: dots and norms are serial sums from 0
+ * (vec.rs:846-880, 907-918), axpys are unfused (`x * alpha`, then add: bicgstab.rs:199-210).
+ * `a` is CSR here; a CSC operand is converted by the caller (oracle_convert_storage).
+ * new(): :117-143, solve(): :148-171, soft/hard restart: :175-192, step(): :194-229.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t iteration_count, soft_restart_count, hard_restart_count;
+    double err, rho;
+    int32_t converged;
+} SUF(oracle_bicgstab_info);
+
+static void SUF(bicg_spmv)(uint64_t n, const PTR_T *ip, const IDX_T *ix, const double *dt, const double *x, double *y)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        double sum = 0.0;                                   /* dot_acc: Acc::zero(), then mul_acc ascending */
+        for (uint64_t p = (uint64_t)ip[i]; p < (uint64_t)ip[i + 1]; ++p) {
+            const double prod = dt[p] * x[ix[p]];
+            sum = sum + prod;
+        }
+        y[i] = sum;
+    }
+}
+
+static double SUF(bicg_dot)(uint64_t n, const double *a, const double *b)
+{
+    double sum = 0.0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const double prod = a[i] * b[i];
+        sum = sum + prod;
+    }
+    return sum;
+}
+
+int SUF(oracle_bicgstab)(uint64_t n, const PTR_T *ip, const IDX_T *ix, const double *dt, const double *x0,
+                         const double *b, double tol, uint64_t max_iter, double soft_restart_threshold,
+                         double *x, SUF(oracle_bicgstab_info) *info)
+{
+    double *r = (double *)malloc(8 * n * 7 + 64);
+    if (!r) return ORACLE_BAD_STRUCTURE;
+    double *rhat = r + n, *p = rhat + n, *v = p + n, *s = v + n, *t = s + n, *h = t + n;
+    uint64_t it = 0, soft = 0, hard = 0;
+    /* new() */
+    SUF(bicg_spmv)(n, ip, ix, dt, x0, v);
+    for (uint64_t i = 0; i < n; ++i) { r[i] = b[i] - v[i]; rhat[i] = r[i]; p[i] = r[i]; x[i] = x0[i]; }
+    double err = sqrt(SUF(bicg_dot)(n, r, r));
+    double rho = err * err;
+    int converged = 0;
+    for (uint64_t k = 0; k < max_iter && !converged; ++k) {
+        /* step() */
+        ++it;
+        SUF(bicg_spmv)(n, ip, ix, dt, p, v);
+        const double alpha = rho / SUF(bicg_dot)(n, rhat, v);
+        for (uint64_t i = 0; i < n; ++i) { const double q = p[i] * alpha; h[i] = x[i] + q; }
+        for (uint64_t i = 0; i < n; ++i) { const double q = v[i] * alpha; s[i] = r[i] - q; }
+        SUF(bicg_spmv)(n, ip, ix, dt, s, t);
+        const double omega = SUF(bicg_dot)(n, t, s) / SUF(bicg_dot)(n, t, t);
+        for (uint64_t i = 0; i < n; ++i) { const double q = omega * s[i]; x[i] = h[i] + q; }
+        for (uint64_t i = 0; i < n; ++i) { const double q = t[i] * omega; r[i] = s[i] - q; }
+        err = sqrt(SUF(bicg_dot)(n, r, r));
+        const double rho_prev = rho;
+        rho = SUF(bicg_dot)(n, rhat, r);
+        if (fabs(rho) / (err * err) < soft_restart_threshold) {
+            ++soft;                                           /* soft_restart() */
+            for (uint64_t i = 0; i < n; ++i) { rhat[i] = r[i]; p[i] = r[i]; }
+            rho = err * err;
+        } else {
+            const double beta = (rho / rho_prev) * (alpha / omega);
+            for (uint64_t i = 0; i < n; ++i) {
+                const double q = v[i] * omega;
+                const double d = p[i] - q;
+                const double e = d * beta;
+                p[i] = r[i] + e;
+            }
+        }
+        if (err < tol) {
+            /* hard_restart(): true residual, then soft restart without counting it */
+            ++hard;
+            SUF(bicg_spmv)(n, ip, ix, dt, x, v);
+            for (uint64_t i = 0; i < n; ++i) r[i] = b[i] - v[i];
+            err = sqrt(SUF(bicg_dot)(n, r, r));
+            for (uint64_t i = 0; i < n; ++i) { rhat[i] = r[i]; p[i] = r[i]; }
+            rho = err * err;
+            if (err < tol) converged = 1;
+        }
+    }
+    info->iteration_count = it;
+    info->soft_restart_count = soft;
+    info->hard_restart_count = hard;
+    info->err = err;
+    info->rho = rho;
+    info->converged = converged;
+    free(r);
+    return ORACLE_OK;
+}

@@ -20,6 +20,18 @@ pub struct sprs_hip_csmat {
     _private: [u8; 0],
 }
 
+/// counters of BiCGSTAB::solve (include/sprs_hip.h)
+#[repr(C)]
+#[derive(Debug, Clone, Copy, Default)]
+pub struct sprs_hip_bicgstab_info {
+    pub iteration_count: u64,
+    pub soft_restart_count: u64,
+    pub hard_restart_count: u64,
+    pub err: f64,
+    pub rho: f64,
+    pub converged: i32,
+}
+
 extern "C" {
     pub fn sprs_hip_last_error() -> *const c_char;
     pub fn sprs_hip_last_hip_code() -> i32;
@@ -34,6 +46,9 @@ extern "C" {
     pub fn sprs_hip_memset(dev_dst: *mut c_void, byte_value: i32, bytes: u64, stream: *mut c_void) -> i32;
     pub fn sprs_hip_synchronize(stream: *mut c_void) -> i32;
     pub fn sprs_hip_pool_trim(freed_bytes: *mut u64) -> i32;
+    pub fn sprs_hip_bicgstab_f64(a: *mut sprs_hip_csmat, x0_dev: *const f64, b_dev: *const f64, n: u64, tol: f64,
+                                 max_iter: u64, soft_restart_threshold: f64, x_dev: *mut f64,
+                                 info: *mut sprs_hip_bicgstab_info, stream: *mut c_void) -> i32;
     pub fn sprs_hip_csmat_upload(
         out: *mut *mut sprs_hip_csmat, storage: i32, rows: u64, cols: u64,
         indptr: *const c_void, iptr_bytes: i32, indices: *const c_void, idx_bytes: i32,

@@ -532,6 +532,21 @@ int32_t sprs_hip_spmm_rowmaj_f64(const sprs_hip_csmat *a, const double *rhs_dev,
                            (hipStream_t)stream);
 }
 
+int32_t sprs_hip_bicgstab_f64(sprs_hip_csmat *a, const double *x0_dev, const double *b_dev, uint64_t n, double tol,
+                              uint64_t max_iter, double soft_restart_threshold, double *x_dev,
+                              sprs_hip_bicgstab_info *info, void *stream) {
+    clear_error();
+    if (!a) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    if (a->rows != a->cols || a->rows != n) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if (n && (!x0_dev || !b_dev || !x_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL vector");
+    if (x_dev == x0_dev || x_dev == b_dev) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "x_dev may not alias x0_dev / b_dev");
+    if (n == 0) {
+        if (info) *info = sprs_hip_bicgstab_info{0, 0, 0, 0.0, 0.0, 1};
+        return SPRS_HIP_OK;
+    }
+    return bicgstab_f64(a, x0_dev, b_dev, n, tol, max_iter, soft_restart_threshold, x_dev, info, (hipStream_t)stream);
+}
+
 int32_t sprs_hip_spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
     clear_error();
     if (!a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");

@@ -146,6 +146,9 @@ int32_t spmm_rowmaj_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64
                         uint64_t ld_out, bool accumulate, hipStream_t stream);
 // convert.hip
 int32_t to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out);
+// bicgstab.hip
+int32_t bicgstab_f64(sprs_hip_csmat *a, const double *x0, const double *b, uint64_t n, double tol, uint64_t max_iter,
+                     double soft_restart_threshold, double *x, sprs_hip_bicgstab_info *info, hipStream_t stream);
 int32_t slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end, sprs_hip_csmat **out);
 // abi.hip
 int32_t alloc_csmat(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols, uint64_t nnz,

@@ -226,3 +226,44 @@ def test_random_vs_scipy_cancellation_free():
                                                (200, 250), u(b.indptr), u(b.indices), b.data, threads=t)
         assert np.array_equal(ip, c.indptr) and np.array_equal(ix, c.indices)
         assert np.allclose(dt, c.data, rtol=1e-13, atol=0)
+
+
+def test_bicgstab_reference_example(golden):
+    """sprs/src/sparse/linalg/bicgstab.rs:336-369 (and the doc example :32-66): the solve must return Ok
+    within 50 iterations at tol 1e-60 and A x must equal b to 1e-60 relative — i.e. the restatement has to
+    reach a residual of exactly zero, which pins the order of every addition."""
+    from oracle import oracle
+    fx = golden["bicgstab_example"]
+    ip, ix = np.array(fx["indptr"], dtype=np.uint64), np.array(fx["indices"], dtype=np.uint64)
+    dt = np.array(fx["data"])
+    x, info = oracle.bicgstab(tuple(fx["shape"]), ip, ix, dt, np.ones(4), np.ones(4), fx["tol"], fx["max_iter"],
+                              storage="CSC")
+    assert info["converged"] == 1 and info["iteration_count"] <= fx["max_iter"] and info["err"] < fx["tol"]
+    dense = np.zeros((4, 4))
+    for j in range(4):
+        for p in range(int(ip[j]), int(ip[j + 1])):
+            dense[int(ix[p]), j] = dt[p]
+    assert np.all(np.abs(1.0 - np.ones(4) / (dense @ x)) < fx["tol"])
+    # independent cross-check of the solution itself
+    assert np.allclose(x, np.linalg.solve(dense, np.ones(4)), rtol=1e-14, atol=0)
+    # u32 instantiation gives the same bits
+    x32, info32 = oracle.bicgstab(tuple(fx["shape"]), ip.astype(np.uint32), ix.astype(np.uint32), dt, np.ones(4),
+                                  np.ones(4), fx["tol"], fx["max_iter"], storage="CSC")
+    assert np.array_equal(x, x32) and info == info32
+
+
+def test_bicgstab_iteration_limit_is_not_an_error():
+    """solve() returns Err(solver) with the last iterate when max_iter runs out (bicgstab.rs:168-170)"""
+    import scipy.sparse as sp
+    from oracle import oracle
+    rng = np.random.default_rng(0)
+    n = 300
+    a = sp.random(n, n, density=0.02, random_state=1, format="csr")
+    a = (a + sp.diags(np.abs(a).sum(axis=1).A1 + 1.0)).tocsr()
+    a.sort_indices()
+    b = rng.standard_normal(n)
+    u = lambda v: v.astype(np.uint64)
+    x, info = oracle.bicgstab((n, n), u(a.indptr), u(a.indices), a.data, np.zeros(n), b, 1e-300, 3)
+    assert info["converged"] == 0 and info["iteration_count"] == 3
+    x2, info2 = oracle.bicgstab((n, n), u(a.indptr), u(a.indices), a.data, np.zeros(n), b, 1e-11, 100)
+    assert info2["converged"] == 1 and np.linalg.norm(a @ x2 - b) < 1e-11 and info2["hard_restart_count"] >= 1

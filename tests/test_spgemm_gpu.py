@@ -29,10 +29,10 @@ def gpu_mul(a, b, validate=True):
     return c.to_host()
 
 
-def check_against_oracle(a, b, exact_values=False):
+def check_against_oracle(a, b, exact_values=False, ref=None):
     from oracle import oracle
     shape, ip, ix, dt = gpu_mul(a, b)
-    rshape, rip, rix, rdt = oracle.mul_csr_csr(*a, *b, threads=1)
+    rshape, rip, rix, rdt = ref if ref is not None else oracle.mul_csr_csr(*a, *b, threads=1)
     assert shape == rshape
     assert ip.dtype == rip.dtype and ix.dtype == rix.dtype          # same I / Iptr as the operands (smmp.rs:196-199)
     assert np.array_equal(ip, rip), "indptr differs"
@@ -149,6 +149,30 @@ def test_multi_window_columns(hip):
     check_against_oracle(A2, B2, exact_values=True)
 
 
+_DENSE_CASE = []
+
+
+def _dense_output_case():
+    """built once per session: scipy.sparse.random needs ~20 s for these shapes"""
+    if not _DENSE_CASE:
+        import scipy.sparse as sp
+        rng = np.random.default_rng(16)
+        cols = 300_000
+        b = sp.random(2000, cols, density=0.004, random_state=7, format="csr")          # ~1200 per row
+        dense_band = sp.random(2000, 6000, density=0.5, random_state=8, format="csr")   # dense outputs in cols < 6000
+        b = (b + sp.hstack([dense_band, sp.csr_matrix((2000, cols - 6000))])).tocsr()
+        a = sp.random(24, 2000, density=0.3, random_state=9, format="csr")              # ~600 k's per row
+        a.data[:] = rng.standard_normal(a.nnz)
+        b.data[:] = rng.standard_normal(b.nnz)
+        a.sort_indices(); b.sort_indices()
+        u = lambda v: v.astype(np.uint64)
+        from oracle import oracle
+        A = ((24, 2000), u(a.indptr), u(a.indices), a.data)
+        B = ((2000, cols), u(b.indptr), u(b.indices), b.data)
+        _DENSE_CASE.append((A, B, oracle.mul_csr_csr(*A, *B, threads=1)))
+    return _DENSE_CASE[0]
+
+
 @pytest.mark.parametrize("winlog", [16, 17, 18, 19])
 def test_window_sizes_and_dense_outputs(hip, winlog):
     """Every LDS layout of the large-row kernels (option spgemm_winlog), on inputs that stress the
@@ -160,23 +184,11 @@ def test_window_sizes_and_dense_outputs(hip, winlog):
     hip.set_option("spgemm_winlog", winlog)
     hip.set_option("spgemm_heavy", 4096)
     try:
-        rng = np.random.default_rng(winlog)
-        cols = 300_000
-        b = sp.random(2000, cols, density=0.004, random_state=7, format="csr")          # ~1200 per row
-        dense_band = sp.random(2000, 6000, density=0.5, random_state=8, format="csr")   # dense outputs in cols < 6000
-        b = (b + sp.hstack([dense_band, sp.csr_matrix((2000, cols - 6000))])).tocsr()
-        a = sp.random(24, 2000, density=0.3, random_state=9, format="csr")              # ~600 k's per row
-        a.data[:] = rng.standard_normal(a.nnz)
-        b.data[:] = rng.standard_normal(b.nnz)
-        a.sort_indices(); b.sort_indices()
-        u = lambda v: v.astype(np.uint64)
-        A = ((24, 2000), u(a.indptr), u(a.indices), a.data)
-        B = ((2000, cols), u(b.indptr), u(b.indices), b.data)
-        shape, ip, ix, dt = check_against_oracle(A, B, exact_values=True)
-        assert np.diff(ip.astype(np.int64)).max() > 100_000
-        for bucket in (0, 1):
+        A, B, ref = _dense_output_case()
+        for bucket in (1, 0):
             hip.set_option("spgemm_bucket", bucket)
-            check_against_oracle(A, B, exact_values=True)
+            shape, ip, ix, dt = check_against_oracle(A, B, exact_values=True, ref=ref)
+        assert np.diff(ip.astype(np.int64)).max() > 100_000
     finally:
         hip.set_option("spgemm_winlog", 17)
         hip.set_option("spgemm_heavy", 65536)
