@@ -152,6 +152,35 @@ inline DeviceVec operator*(const DeviceCsMat &a, const DeviceVec &x) {
 // `&A * &B` (csmat.rs:1866-1888)
 inline DeviceCsMat operator*(const DeviceCsMat &a, const DeviceCsMat &b) { return smmp::mul_csr_csr(a, b); }
 
+namespace linalg {
+// linalg::bicgstab::BiCGSTAB (sprs/src/sparse/linalg/bicgstab.rs): `solve` returns the solver object in
+// both the Ok and the Err case of the reference (Err = iteration limit, results still inside); here
+// `converged()` tells them apart.
+class BiCGSTAB {
+public:
+    static BiCGSTAB solve(const DeviceCsMat &a, const DeviceVec &x0, const DeviceVec &b, double tol, uint64_t max_iter,
+                          double soft_restart_threshold = 0.1) {
+        if (x0.dim() != b.dim()) throw Error(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+        BiCGSTAB s(x0.dim());
+        check(sprs_hip_bicgstab_f64(const_cast<sprs_hip_csmat *>(a.handle()), x0.ptr(), b.ptr(), x0.dim(), tol, max_iter,
+                                    soft_restart_threshold, s.x_.ptr(), &s.info_, nullptr));
+        return s;
+    }
+    bool converged() const { return info_.converged != 0; }
+    uint64_t iteration_count() const { return info_.iteration_count; }
+    uint64_t soft_restart_count() const { return info_.soft_restart_count; }
+    uint64_t hard_restart_count() const { return info_.hard_restart_count; }
+    double err() const { return info_.err; }
+    double rho() const { return info_.rho; }
+    const DeviceVec &x() const { return x_; }
+
+private:
+    explicit BiCGSTAB(uint64_t n) : x_(n) {}
+    DeviceVec x_;
+    sprs_hip_bicgstab_info info_{};
+};
+}  // namespace linalg
+
 // Result blocks released by ~DeviceCsMat stay in the library's pool for the next result (sprs_hip.h);
 // this hands them back to the driver.  Returns the bytes released.
 inline uint64_t pool_trim() {

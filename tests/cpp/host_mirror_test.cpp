@@ -67,6 +67,21 @@ int main() {
         REQUIRE((dt == std::vector<double>{32., 15., 16., 35., 25., 16., 40., 56.}));
         REQUIRE(c.rows() == 5 && c.cols() == 5 && c.is_csr());
     }
+    {   // bicgstab.rs:336-369: the reference's test system must be solved exactly (tol 1e-60)
+        DeviceCsMat a(SPRS_HIP_CSC, 4, 4, std::vector<uint64_t>{0, 2, 4, 6, 8},
+                      std::vector<uint64_t>{0, 3, 1, 2, 1, 2, 0, 3},
+                      std::vector<double>{1.0, 2., 21., 6., 6., 2., 2., 8.});
+        DeviceVec ones(std::vector<double>(4, 1.0));
+        auto res = linalg::BiCGSTAB::solve(a, ones, ones, 1e-60, 50);
+        REQUIRE(res.converged() && res.iteration_count() <= 50 && res.err() < 1e-60);
+        auto x = res.x().to_host();
+        const double dense[4][4] = {{1, 0, 0, 2}, {0, 21, 6, 0}, {0, 6, 2, 0}, {2, 0, 0, 8}};
+        for (int i = 0; i < 4; ++i) {
+            double bi = 0;
+            for (int j = 0; j < 4; ++j) bi += dense[i][j] * x[j];
+            REQUIRE(std::fabs(1.0 - 1.0 / bi) < 1e-60);
+        }
+    }
     {   // panics -> exceptions with the reference's text
         DeviceCsMat a = mat1();
         DeviceVec x4(4), y5(5);
