@@ -206,6 +206,18 @@ int32_t sprs_hip_bicgstab_f64(sprs_hip_csmat *a, const double *x0_dev, const dou
  * SPRS_HIP_INDEX_OVERFLOW if nnz(C) does not fit Iptr.  Synchronous. */
 int32_t sprs_hip_spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c);
 
+/* The two halves of smmp::mul_csr_csr as the reference exposes them:
+ * sprs_hip_spgemm_symbolic — twin of smmp::symbolic (smmp.rs:81-131): the STRUCTURE of C = A * B (indptr and
+ *   the sorted indices of every row, structural zeros kept) as a new handle whose values are 0.0;
+ * sprs_hip_spgemm_numeric  — twin of smmp::numeric (smmp.rs:151-189): the VALUES of the product into `c`,
+ *   which must have the product's structure (what _symbolic returned, for these or any operands with the same
+ *   patterns — the re-use the reference's split exists for).  Unlike the reference, a `c` with another
+ *   structure is detected: SPRS_HIP_BAD_STRUCTURE (nnz or indptr differ).  Same contract checks and
+ *   status codes as sprs_hip_spgemm_f64; c's shape / storage / index types are checked like numeric()'s asserts
+ *   (smmp.rs:161-166).  Both block until done. */
+int32_t sprs_hip_spgemm_symbolic(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c_structure);
+int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c);
+
 /* Storage conversion raw::convert_mat_storage / to_other_storage
  * (csmat.rs:1405-1426, 1782-1829): new owning handle with the other storage
  * order.  SPRS_HIP_INDEX_OVERFLOW where the reference panics (csmat.rs:1794). */

@@ -90,6 +90,8 @@ extern "C" {
         out_dev: *mut f64, out_rows: u64, ld_out: u64, accumulate: i32, stream: *mut c_void,
     ) -> i32;
     pub fn sprs_hip_spgemm_f64(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_spgemm_symbolic(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c_structure: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_spgemm_numeric(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_csmat_to_other_storage(m: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_set_option(name: *const c_char, value: i64) -> i32;
     pub fn sprs_hip_get_option(name: *const c_char, value: *mut i64) -> i32;

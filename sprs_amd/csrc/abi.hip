@@ -532,6 +532,37 @@ int32_t sprs_hip_spmm_rowmaj_f64(const sprs_hip_csmat *a, const double *rhs_dev,
                            (hipStream_t)stream);
 }
 
+static int32_t spgemm_contract(const sprs_hip_csmat *a, const sprs_hip_csmat *b) {
+    if (a->cols != b->rows) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");   // smmp.rs:207
+    if (a->storage != SPRS_HIP_CSR || b->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    if (a->iptr_bytes != b->iptr_bytes || a->idx_bytes != b->idx_bytes)
+        SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "operands must share index types (smmp.rs:196-199)");
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_spgemm_symbolic(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
+    clear_error();
+    if (!a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *c = nullptr;
+    SPRS_TRY(spgemm_contract(a, b));
+    return spgemm_symbolic(a, b, c);
+}
+
+int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c) {
+    clear_error();
+    if (!a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    SPRS_TRY(spgemm_contract(a, b));
+    // smmp.rs:161-166: the asserts of numeric() on the shape of c
+    if (c->rows != a->rows || c->cols != b->cols) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if (c->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    if (c->iptr_bytes != a->iptr_bytes || c->idx_bytes != a->idx_bytes)
+        SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "C must share the operands' index types");
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
+    c->mm.release();
+    return spgemm_numeric(a, b, c);
+}
+
 int32_t sprs_hip_bicgstab_f64(sprs_hip_csmat *a, const double *x0_dev, const double *b_dev, uint64_t n, double tol,
                               uint64_t max_iter, double soft_restart_threshold, double *x_dev,
                               sprs_hip_bicgstab_info *info, void *stream) {

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
             const uint64_t o = off[t];
             for (uint32_t i = lane; i < need; i += WAVE) {
                 c_indices[o + i] = (IDX)keys[i];
-                c_data[o + i] = vals[i];
+                if (c_data) c_data[o + i] = vals[i];      // null: structure only (the twin of smmp::symbolic)
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -570,6 +570,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
         }
     }
     mark(1);   // prefix + emit indices
+    if (!c_data) return;   // structure only (the twin of smmp::symbolic): block-uniform
 
     // ---- values ----------------------------------------------------------------------------------
     // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) of at most ACC_CAP outputs,
@@ -733,6 +734,15 @@ __global__ void write_indptr_kernel(const uint64_t *__restrict__ first_task, con
     indptr[r] = (PTR)off[first_task[r]];
 }
 
+// numeric into an existing matrix: its indptr must be the product's
+template <typename PTR>
+__global__ void compare_indptr_kernel(const uint64_t *__restrict__ first_task, const uint64_t *__restrict__ off,
+                                      uint64_t rows, const PTR *__restrict__ indptr, unsigned int *__restrict__ mismatch) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > rows) return;
+    if ((uint64_t)indptr[r] != off[first_task[r]]) atomicOr(mismatch, 1u);
+}
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() {
@@ -744,7 +754,8 @@ struct DevBuf {
 };
 
 template <typename IDX, typename PTR>
-int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c_out) {
+int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c_out, bool structure_only,
+                    sprs_hip_csmat *c_into) {
     hipStream_t stream = nullptr;
     const uint64_t rows = a->rows, b_cols = b->cols;
     CsrView<IDX, PTR> A{(const PTR *)a->indptr, (const IDX *)a->indices, a->data, nullptr, 0};
@@ -844,9 +855,29 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
                   (unsigned long long)c_nnz);   // Iptr::from_usize, smmp.rs:121
 
     sprs_hip_csmat *c = nullptr;
-    SPRS_TRY(alloc_csmat(&c, SPRS_HIP_CSR, rows, b_cols, c_nnz, (int32_t)sizeof(PTR), (int32_t)sizeof(IDX)));
-    hipLaunchKernelGGL((write_indptr_kernel<PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream,
-                       first_task.as<uint64_t>(), off.as<uint64_t>(), rows, (PTR *)c->indptr);
+    if (c_into) {
+        // smmp::numeric (smmp.rs:151-189) fills the values of a matrix that already has the product's
+        // structure (the one smmp::symbolic produced): check it instead of trusting it
+        if (c_into->nnz != c_nnz)
+            SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "numeric: C holds %llu entries, the product has %llu",
+                      (unsigned long long)c_into->nnz, (unsigned long long)c_nnz);
+        DevBuf flag;
+        SPRS_TRY_HIP(flag.alloc(4));
+        SPRS_TRY_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+        hipLaunchKernelGGL((compare_indptr_kernel<PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream,
+                           first_task.as<uint64_t>(), off.as<uint64_t>(), rows, (const PTR *)c_into->indptr,
+                           flag.as<unsigned int>());
+        unsigned int bad = 0;
+        SPRS_TRY_HIP(hipMemcpy(&bad, flag.p, 4, hipMemcpyDeviceToHost));
+        if (bad) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "numeric: the indptr of C is not the product's");
+        c = c_into;
+    } else {
+        SPRS_TRY(alloc_csmat(&c, SPRS_HIP_CSR, rows, b_cols, c_nnz, (int32_t)sizeof(PTR), (int32_t)sizeof(IDX)));
+        hipLaunchKernelGGL((write_indptr_kernel<PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream,
+                           first_task.as<uint64_t>(), off.as<uint64_t>(), rows, (PTR *)c->indptr);
+        if (structure_only) SPRS_TRY_HIP(hipMemsetAsync(c->data, 0, (c_nnz ? c_nnz : 1) * sizeof(double), stream));
+    }
+    double *c_values = structure_only ? nullptr : c->data;
 
     // ---- numeric -------------------------------------------------------------
     DevBuf prof;
@@ -857,14 +888,14 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     if (n_small)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true>), small_grid(), dim3(SM_BLOCK), 0, stream, A, B,
                            small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
-                           count.as<uint64_t>(), off.as<uint64_t>(), (IDX *)c->indices, c->data);
+                           count.as<uint64_t>(), off.as<uint64_t>(), (IDX *)c->indices, c_values);
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
 #define SPRS_LG_NUM(WL)                                                                                              \
     hipLaunchKernelGGL((large_numeric_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, b_cols,                        \
                        large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),                \
                        ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>(), off.as<uint64_t>(),          \
-                       (IDX *)c->indices, c->data, prof.as<unsigned long long>())
+                       (IDX *)c->indices, c_values, prof.as<unsigned long long>())
         switch (options().spgemm_winlog) {
             case 16: SPRS_LG_NUM(16); break;
             case 18: SPRS_LG_NUM(18); break;
@@ -876,7 +907,7 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
-        sprs_hip_csmat_free(c);
+        if (!c_into) sprs_hip_csmat_free(c);
         return fail_hip(e, "spgemm numeric");
     }
     if (prof.p) {
@@ -891,18 +922,33 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
                     h[1], h[6]);
         }
     }
-    *c_out = c;
+    if (c_out) *c_out = c;
     return SPRS_HIP_OK;
 }
 
 }  // namespace
 
-int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
+static int32_t spgemm_dispatch(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c, bool structure_only,
+                               sprs_hip_csmat *c_into) {
     if (b->cols > 0xFFFFFFFEull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "SpGEMM: more than 2^32-2 columns is not supported");
-    if (a->idx_bytes == 8 && a->iptr_bytes == 8) return spgemm_impl<uint64_t, uint64_t>(a, b, c);
-    if (a->idx_bytes == 4 && a->iptr_bytes == 8) return spgemm_impl<uint32_t, uint64_t>(a, b, c);
-    if (a->idx_bytes == 8 && a->iptr_bytes == 4) return spgemm_impl<uint64_t, uint32_t>(a, b, c);
-    return spgemm_impl<uint32_t, uint32_t>(a, b, c);
+    if (a->idx_bytes == 8 && a->iptr_bytes == 8) return spgemm_impl<uint64_t, uint64_t>(a, b, c, structure_only, c_into);
+    if (a->idx_bytes == 4 && a->iptr_bytes == 8) return spgemm_impl<uint32_t, uint64_t>(a, b, c, structure_only, c_into);
+    if (a->idx_bytes == 8 && a->iptr_bytes == 4) return spgemm_impl<uint64_t, uint32_t>(a, b, c, structure_only, c_into);
+    return spgemm_impl<uint32_t, uint32_t>(a, b, c, structure_only, c_into);
+}
+
+int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
+    return spgemm_dispatch(a, b, c, false, nullptr);
+}
+
+// smmp::symbolic (smmp.rs:81-131): structure only; the values of the result are zero
+int32_t spgemm_symbolic(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
+    return spgemm_dispatch(a, b, c, true, nullptr);
+}
+
+// smmp::numeric (smmp.rs:151-189): values into a matrix that has the product's structure
+int32_t spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c) {
+    return spgemm_dispatch(a, b, nullptr, false, c);
 }
 
 }  // namespace sprs_hip

@@ -54,6 +54,47 @@ def test_golden_mul_csr_csr(hip, golden, idx, ptr):
         assert np.array_equal(ip, exp[1]) and np.array_equal(ix, exp[2]) and np.array_equal(dt, exp[3])
 
 
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_symbolic_and_numeric_twins(hip, golden, idx, ptr):
+    """smmp.rs:422-465 `symbolic_and_numeric`: the two halves of the product as separate calls — the
+    structure alone (values 0.0), then the values into that structure; re-use of the structure with other
+    values of the same patterns; and what the reference does not check: a C of another structure is refused."""
+    from oracle import oracle
+    from sprs_amd import _ffi, gen, smmp
+    from sprs_amd.device import DeviceCsMat
+    a, b, exp = (as_csr(golden[k], idx, ptr) for k in ("mat1", "mat2", "mat1_matprod_mat2"))
+    da, db = DeviceCsMat.from_host(*a), DeviceCsMat.from_host(*b)
+    c = smmp.symbolic(da, db)
+    shape, ip, ix, dt = c.to_host()
+    assert shape == exp[0] and np.array_equal(ip, exp[1]) and np.array_equal(ix, exp[2])
+    assert ip.dtype == exp[1].dtype and ix.dtype == exp[2].dtype and not dt.any()
+    smmp.numeric(da, db, c)
+    assert np.array_equal(c.to_host()[3], exp[3])
+    # same patterns, other values: numeric alone refreshes C (the point of the split)
+    da2 = DeviceCsMat.from_host(a[0], a[1], a[2], a[3] * 3.0)
+    smmp.numeric(da2, db, c)
+    assert np.array_equal(c.to_host()[3], exp[3] * 3.0)
+    # a large-row case against the oracle's two halves
+    n = 12000
+    indptr, indices, data = gen.rmat_csr(n, 8, seed=13)
+    m = ((n, n), indptr.numpy().astype(ptr), indices.numpy().astype(idx), data.numpy())
+    dm = DeviceCsMat.from_host(*m)
+    cs = smmp.symbolic(dm, dm)
+    r_ip, r_ix = oracle.symbolic(m[0], m[1], m[2], m[0], m[1], m[2])
+    got = cs.to_host()
+    assert np.array_equal(got[1], r_ip) and np.array_equal(got[2], r_ix)
+    smmp.numeric(dm, dm, cs)
+    assert np.array_equal(cs.to_host()[3], oracle.numeric(*m, *m, r_ip, r_ix))
+    assert np.diff(r_ip.astype(np.int64)).max() > 4096
+    # wrong structure: another matrix of the right shape
+    with pytest.raises(_ffi.SprsHipError) as e:
+        smmp.numeric(dm, dm, DeviceCsMat.from_host(*m))
+    assert e.value.status == _ffi.BAD_STRUCTURE
+    with pytest.raises(_ffi.SprsHipError) as e:
+        smmp.numeric(da, db, cs)                                   # wrong shape
+    assert e.value.status == _ffi.DIM_MISMATCH
+
+
 def test_golden_structure_only(hip, golden):
     # smmp.rs:515-555 (complex; structure) and tests/block_matrix.rs:71-108
     fx = golden["mul_complex_structure"]
