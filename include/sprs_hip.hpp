@@ -143,6 +143,19 @@ inline DeviceCsMat mul_csr_csr(const DeviceCsMat &lhs, const DeviceCsMat &rhs) {
 }  // namespace smmp
 
 // `&A * &x` (csmat.rs:2119-2160): fresh result
+namespace smmp {
+// smmp::symbolic (smmp.rs:81-131): structure of lhs * rhs, values 0.0
+inline DeviceCsMat symbolic(const DeviceCsMat &lhs, const DeviceCsMat &rhs) {
+    sprs_hip_csmat *c = nullptr;
+    check(sprs_hip_spgemm_symbolic(lhs.handle(), rhs.handle(), &c));
+    return DeviceCsMat(c);
+}
+// smmp::numeric (smmp.rs:151-189): values of lhs * rhs into c, which must have the product's structure
+inline void numeric(const DeviceCsMat &lhs, const DeviceCsMat &rhs, DeviceCsMat &c) {
+    check(sprs_hip_spgemm_numeric(lhs.handle(), rhs.handle(), const_cast<sprs_hip_csmat *>(c.handle())));
+}
+}  // namespace smmp
+
 inline DeviceVec operator*(const DeviceCsMat &a, const DeviceVec &x) {
     DeviceVec y(a.rows());
     check(sprs_hip_spmv_f64(a.handle(), x.ptr(), x.dim(), y.ptr(), y.dim(), 0, nullptr));
