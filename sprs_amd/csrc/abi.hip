@@ -640,6 +640,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "pool_max_bytes")) {
         if (value < 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "pool_max_bytes must be >= 0");
         o.pool_max_bytes = value;
+    } else if (!strcmp(name, "spgemm_minwin")) {
+        if (value < 11 || value > 16) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_minwin must be 11..16");
+        o.spgemm_minwin = value;
     } else if (!strcmp(name, "spgemm_heavy")) {
         if (value < 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_heavy must be >= 1024");
         o.spgemm_heavy = value;
@@ -668,6 +671,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_bucket")) *value = o.spgemm_bucket;
     else if (!strcmp(name, "spgemm_prof")) *value = o.spgemm_prof;
     else if (!strcmp(name, "spgemm_heavy")) *value = o.spgemm_heavy;
+    else if (!strcmp(name, "spgemm_minwin")) *value = o.spgemm_minwin;
     else if (!strcmp(name, "pool")) *value = o.pool;
     else if (!strcmp(name, "pool_max_bytes")) *value = o.pool_max_bytes;
     else if (!strcmp(name, "pool_cached_bytes")) *value = (int64_t)pool_cached_bytes();

@@ -48,6 +48,7 @@ struct Options {
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
     int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
     int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)
+    int64_t spgemm_minwin = 13;    // SpGEMM: log2 of the narrowest column window of a heavy row (11..16)
     int64_t spgemm_heavy = 65536;  // SpGEMM: target products per task of a heavy row (narrower column windows)
     int64_t pool = 1;              // keep released result blocks (>= 1 MiB) for the next result instead of hipFree
     int64_t pool_max_bytes = 128ll << 30;   // cap on the bytes the pool may hold

@@ -50,7 +50,6 @@ constexpr int MAX_WIN_LOG2 = 19;          // widest column window of a large-row
 constexpr int LG_BLOCK = 512;             // 8 waves
 constexpr int LG_WAVES = LG_BLOCK / WAVE;
 constexpr int SUPER_WORDS = 32;           // bitmap words per superblock (2048 columns)
-constexpr int MIN_WIN_LOG2 = 13;          // heavy rows: windows down to 8192 columns
 constexpr uint32_t NO_TAG = 0xFFFFFFFFu;
 
 // LDS layout of the large-row kernels for windows of up to 2^WL columns.  The narrower the window
@@ -155,7 +154,7 @@ __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 3
 // ---------------------------------------------------------------------------
 template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
-                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t max_wl,
+                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t max_wl, uint32_t min_wl,
                                                        uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks,
                                                        uint8_t *__restrict__ wlog) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
                 uint64_t width = b_cols / want;                // columns per task
                 wl = width <= 1 ? 0 : 63 - __clzll((long long)width);   // floor(log2)
                 if (wl > max_wl) wl = max_wl;
-                if (wl < (uint32_t)MIN_WIN_LOG2) wl = MIN_WIN_LOG2;
+                if (wl < min_wl) wl = min_wl;
                 if (wl > max_wl) wl = max_wl;
             }
             wlog[r] = (uint8_t)wl;
@@ -789,7 +788,8 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
-                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, ub.as<uint64_t>(), ntasks.as<uint64_t>(), wlog.as<uint8_t>());
+                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint32_t)options().spgemm_minwin,
+                           ub.as<uint64_t>(), ntasks.as<uint64_t>(), wlog.as<uint8_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
     SPRS_TRY(exclusive_scan_u64(ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows, stream));
