@@ -44,6 +44,8 @@ constexpr int WAVE = 64;
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr uint64_t SMALL_MAX = 512;       // products per row handled by the wave/hash path
 constexpr int SMALL_TAB = 1024;           // hash slots per wave (load factor <= 0.5)
+constexpr uint64_t TINY_MAX = 64;         // rows of at most this many products: same kernel with a 128-slot table,
+constexpr int TINY_TAB = 128;             //   so that 32 waves share a CU instead of 12 (these rows are latency bound)
 constexpr int SM_BLOCK = 256;             // 4 waves
 constexpr int SM_WAVES = SM_BLOCK / WAVE;
 constexpr int MAX_WIN_LOG2 = 19;          // widest column window of a large-row task (option spgemm_winlog <= this)
@@ -192,14 +194,17 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
 __global__ void make_tasks_kernel(const uint64_t *__restrict__ ub, const uint64_t *__restrict__ ntasks,
                                   const uint64_t *__restrict__ first_task, uint64_t rows,
                                   uint64_t *__restrict__ task_row, uint64_t *__restrict__ small_list,
-                                  uint64_t *__restrict__ large_list, unsigned long long *__restrict__ counters) {
+                                  uint64_t *__restrict__ large_list, uint64_t list_len,
+                                  unsigned long long *__restrict__ counters) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const uint64_t n = ntasks[r];
     if (!n) return;
     const uint64_t f = first_task[r];
     for (uint64_t j = 0; j < n; ++j) task_row[f + j] = r;
-    if (ub[r] <= SMALL_MAX) {
+    if (ub[r] <= TINY_MAX) {
+        small_list[list_len - 1 - atomicAdd(&counters[2], 1ull)] = f;     // tiny rows: from the end of the same list
+    } else if (ub[r] <= SMALL_MAX) {
         small_list[atomicAdd(&counters[0], 1ull)] = f;
     } else {
         const uint64_t pos = atomicAdd(&counters[1], (unsigned long long)n);
@@ -210,7 +215,7 @@ __global__ void make_tasks_kernel(const uint64_t *__restrict__ ub, const uint64_
 // ---------------------------------------------------------------------------
 // small rows: one wave per task, LDS hash table
 // ---------------------------------------------------------------------------
-template <typename IDX, typename PTR, bool NUMERIC>
+template <typename IDX, typename PTR, bool NUMERIC, int TAB>
 __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B,
                                                               const uint64_t *__restrict__ small_list,
                                                               uint64_t n_small, const uint64_t *__restrict__ task_row,
@@ -218,8 +223,9 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                                                               uint64_t *__restrict__ count,        // symbolic: out
                                                               const uint64_t *__restrict__ off,    // numeric: in
                                                               IDX *__restrict__ c_indices, double *__restrict__ c_data) {
-    __shared__ uint32_t keys_s[SM_WAVES][SMALL_TAB];
-    __shared__ double vals_s[NUMERIC ? SM_WAVES : 1][NUMERIC ? SMALL_TAB : 1];
+    __shared__ uint32_t keys_s[SM_WAVES][TAB];
+    __shared__ double vals_s[NUMERIC ? SM_WAVES : 1][NUMERIC ? TAB : 1];
+    __shared__ uint32_t tag_s[NUMERIC ? SM_WAVES : 1][WAVE];   // order tags of the entry-parallel path
     const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     uint32_t *keys = keys_s[wave];
     double *vals = vals_s[NUMERIC ? wave : 0];
@@ -237,6 +243,74 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
         __builtin_amdgcn_wave_barrier();
         const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
         uint32_t fresh = 0;
+        if (ae - as <= (uint64_t)WAVE) {
+            // ENTRY-PARALLEL path (rows with at most 64 k's — nearly all small rows): lane j holds k_j; the
+            // concatenation of the B rows (k ascending: the reference's order) is walked 64 products at a time,
+            // every load independent.  (One k at a time — below — leaves 59 of 64 lanes idle on a banded matrix
+            // and chains one memory round trip per k: 5-pt Laplacian squared, 51 ms of 71.)
+            const bool has = as + lane < ae;
+            const uint64_t k = has ? (uint64_t)A.indices[as + lane] : 0;
+            const double av = has ? A.data[as + lane] : 0.0;
+            const uint64_t bs = has ? (uint64_t)B.indptr[k] : 0;
+            const uint32_t len = has ? (uint32_t)((uint64_t)B.indptr[k + 1] - bs) : 0u;
+            uint32_t inc = len;                               // inclusive prefix of the lengths over the lanes
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const uint32_t o = __shfl_up(inc, off, WAVE);
+                if (lane >= (uint32_t)off) inc += o;
+            }
+            const uint32_t total = __shfl(inc, WAVE - 1, WAVE);
+            if constexpr (NUMERIC) tag_s[wave][lane] = EMPTY;
+            for (uint32_t base = 0; base < total; base += WAVE) {
+                const uint32_t t = base + lane;
+                const bool valid = t < total;
+                uint32_t own = 0;                             // owner = number of lanes whose prefix is <= t
+#pragma unroll
+                for (int step = WAVE / 2; step > 0; step >>= 1) {
+                    const uint32_t v = __shfl(inc, (int)(own + step - 1), WAVE);
+                    if (v <= t) own += step;
+                }
+                own &= WAVE - 1;
+                const uint32_t inc_o = __shfl(inc, (int)own, WAVE), len_o = __shfl(len, (int)own, WAVE);
+                const uint64_t bs_o = __shfl(bs, (int)own, WAVE);
+                const double av_o = __shfl(av, (int)own, WAVE);
+                const uint64_t pos = bs_o + (uint64_t)(t - (inc_o - len_o));
+                const uint32_t c = valid ? (uint32_t)B.indices[pos] : 0u;
+                double pr = 0.0;
+                if constexpr (NUMERIC) pr = valid ? av_o * B.data[pos] : 0.0;
+                uint32_t h = hash_slot(c, lg);
+                if (valid) {
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&keys[h], EMPTY, c);
+                        if (old == EMPTY) {
+                            ++fresh;
+                            if constexpr (NUMERIC) vals[h] = 0.0;       // tmp starts at N::zero()
+                            break;
+                        }
+                        if (old == c) break;
+                        h = (h + 1) & mask;
+                    }
+                }
+                if constexpr (NUMERIC) {
+                    // Two lanes of this batch may hold the same column (from different k's): their products must be
+                    // added in lane order = k order.  64 direct-mapped order tags: the lowest pending lane of a tag
+                    // adds, the others (same column, or merely the same tag) take another turn.
+                    __builtin_amdgcn_wave_barrier();
+                    bool pend = valid;
+                    uint32_t *tg = &tag_s[wave][h & (WAVE - 1)];
+                    while (__ballot(pend)) {
+                        if (pend) atomicMin(tg, lane);
+                        __builtin_amdgcn_wave_barrier();
+                        if (pend && *(volatile uint32_t *)tg == lane) {
+                            vals[h] += pr;
+                            *(volatile uint32_t *)tg = EMPTY;
+                            pend = false;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        } else
         for (uint64_t p0 = as; p0 < ae; p0 += WAVE) {
             const uint64_t p = p0 + lane;
             const bool valid = p < ae;
@@ -781,8 +855,8 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     SPRS_TRY_HIP(ub.alloc(rows * 8));
     SPRS_TRY_HIP(ntasks.alloc(rows * 8));
     SPRS_TRY_HIP(first_task.alloc((rows + 1) * 8));
-    SPRS_TRY_HIP(counters.alloc(16));
-    SPRS_TRY_HIP(hipMemsetAsync(counters.p, 0, 16, stream));
+    SPRS_TRY_HIP(counters.alloc(32));
+    SPRS_TRY_HIP(hipMemsetAsync(counters.p, 0, 32, stream));
     uint64_t ntask_total = 0;
     if (rows) {
         uint64_t blocks = (rows + 3) / 4;
@@ -801,29 +875,37 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     SPRS_TRY_HIP(large_list.alloc(ntask_total * 8));
     SPRS_TRY_HIP(count.alloc(ntask_total * 8));
     SPRS_TRY_HIP(off.alloc((ntask_total + 1) * 8));
-    uint64_t n_small = 0, n_large = 0;
+    uint64_t n_small = 0, n_large = 0, n_tiny = 0;
     if (ntask_total) {
         hipLaunchKernelGGL(make_tasks_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream,
                            ub.as<uint64_t>(), ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows,
                            task_row.as<uint64_t>(), small_list.as<uint64_t>(), large_list.as<uint64_t>(),
-                           counters.as<unsigned long long>());
+                           ntask_total, counters.as<unsigned long long>());
         SPRS_TRY_HIP(hipGetLastError());
-        uint64_t h[2];
-        SPRS_TRY_HIP(hipMemcpy(h, counters.p, 16, hipMemcpyDeviceToHost));
+        uint64_t h[3];
+        SPRS_TRY_HIP(hipMemcpy(h, counters.p, 24, hipMemcpyDeviceToHost));
         n_small = h[0];
         n_large = h[1];
+        n_tiny = h[2];
     }
-    auto small_grid = [&]() {
-        uint64_t g = (n_small + SM_WAVES - 1) / SM_WAVES;
+    auto small_grid = [&](uint64_t n_tasks) {
+        uint64_t g = (n_tasks + SM_WAVES - 1) / SM_WAVES;
         if (g > 256 * 32) g = 256 * 32;
         return dim3((unsigned)g);
     };
+    const uint64_t *tiny_list = small_list.as<uint64_t>() + (ntask_total - n_tiny);
     if (n_large > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many SpGEMM tasks for one launch");
 
     // ---- symbolic ----------------------------------------------------------
+    if (n_tiny) {
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, stream,
+                           A, B, tiny_list, n_tiny, task_row.as<uint64_t>(), ub.as<uint64_t>(), count.as<uint64_t>(),
+                           (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
     if (n_small) {
-        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false>), small_grid(), dim3(SM_BLOCK), 0, stream, A, B,
-                           small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, stream,
+                           A, B, small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
                            count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
         SPRS_TRY_HIP(hipGetLastError());
     }
@@ -885,9 +967,13 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         SPRS_TRY_HIP(prof.alloc(128));
         SPRS_TRY_HIP(hipMemsetAsync(prof.p, 0, 128, stream));
     }
+    if (n_tiny)
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, stream, A,
+                           B, tiny_list, n_tiny, task_row.as<uint64_t>(), ub.as<uint64_t>(), count.as<uint64_t>(),
+                           off.as<uint64_t>(), (IDX *)c->indices, c_values);
     if (n_small)
-        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true>), small_grid(), dim3(SM_BLOCK), 0, stream, A, B,
-                           small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, stream,
+                           A, B, small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
                            count.as<uint64_t>(), off.as<uint64_t>(), (IDX *)c->indices, c_values);
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
