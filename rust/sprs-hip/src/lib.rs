@@ -144,6 +144,57 @@ pub mod smmp {
         unsafe { check(sys::sprs_hip_spgemm_f64(lhs.h, rhs.h, &mut h)) };
         DeviceCsMat { h }
     }
+
+    /// Twin of `sprs::smmp::symbolic` (smmp.rs:81-131): the structure of `lhs * rhs`, values 0.0.
+    pub fn symbolic(lhs: &DeviceCsMat, rhs: &DeviceCsMat) -> DeviceCsMat {
+        let mut h = std::ptr::null_mut();
+        unsafe { check(sys::sprs_hip_spgemm_symbolic(lhs.h, rhs.h, &mut h)) };
+        DeviceCsMat { h }
+    }
+
+    /// Twin of `sprs::smmp::numeric` (smmp.rs:151-189): the values of `lhs * rhs` into `c`, which must
+    /// have the product's structure (panics with the library's message otherwise).
+    pub fn numeric(lhs: &DeviceCsMat, rhs: &DeviceCsMat, c: &mut DeviceCsMat) {
+        unsafe { check(sys::sprs_hip_spgemm_numeric(lhs.h, rhs.h, c.h)) };
+    }
+}
+
+pub mod linalg {
+    use super::*;
+    /// Twin of `sprs::linalg::bicgstab::BiCGSTAB` (sparse/linalg/bicgstab.rs) with device-resident dense
+    /// vectors.  `solve` returns `Ok(solver)` / `Err(solver)` like the reference (Err = iteration limit).
+    pub struct BiCGSTAB {
+        x: DeviceVec,
+        info: sys::sprs_hip_bicgstab_info,
+    }
+    impl BiCGSTAB {
+        pub fn solve(a: &DeviceCsMat, x0: &DeviceVec, b: &DeviceVec, tol: f64, max_iter: usize)
+            -> Result<Box<BiCGSTAB>, Box<BiCGSTAB>> {
+            assert_eq!(x0.len, b.len, "Dimension mismatch");
+            let x = DeviceVec::zeros(x0.len);
+            let mut info = sys::sprs_hip_bicgstab_info::default();
+            unsafe {
+                check(sys::sprs_hip_bicgstab_f64(a.h, x0.ptr, b.ptr, x0.len as u64, tol, max_iter as u64, 0.1, x.ptr,
+                                                 &mut info, std::ptr::null_mut()));
+            }
+            let s = Box::new(BiCGSTAB { x, info });
+            if s.info.converged != 0 { Ok(s) } else { Err(s) }
+        }
+        pub fn iteration_count(&self) -> usize { self.info.iteration_count as usize }
+        pub fn soft_restart_count(&self) -> usize { self.info.soft_restart_count as usize }
+        pub fn hard_restart_count(&self) -> usize { self.info.hard_restart_count as usize }
+        pub fn err(&self) -> f64 { self.info.err }
+        pub fn rho(&self) -> f64 { self.info.rho }
+        pub fn x(&self) -> &DeviceVec { &self.x }
+    }
+}
+
+/// Result blocks released by `Drop for DeviceCsMat` stay pooled inside the library; this returns them to
+/// the driver (bytes released).
+pub fn pool_trim() -> u64 {
+    let mut freed = 0u64;
+    unsafe { check(sys::sprs_hip_pool_trim(&mut freed)) };
+    freed
 }
 
 /// `&A * &x`  (csmat.rs:2119-2160): fresh result, no accumulation.

@@ -27,6 +27,15 @@ def test_header_symbols_exported_and_bound():
     assert set(_ffi.SIGNATURES) <= set(names), "binding declares symbols the header does not"
 
 
+def test_rust_sys_crate_declares_the_same_symbols():
+    """rust/sprs-hip-sys (source only: no Rust toolchain in this image) must not drift from the header"""
+    rs = open(os.path.join(ROOT, "rust", "sprs-hip-sys", "src", "lib.rs")).read()
+    assert sorted(set(re.findall(r"pub fn (sprs_hip_[a-z0-9_]+)", rs))) == declared_symbols()
+    wrapper = open(os.path.join(ROOT, "rust", "sprs-hip", "src", "lib.rs")).read()
+    for used in set(re.findall(r"sys::(sprs_hip_[a-z0-9_]+)", wrapper)):
+        assert used in rs, used
+
+
 def test_status_codes_match_header():
     from sprs_amd import _ffi
     src = open(os.path.join(ROOT, "include", "sprs_hip.h")).read()
