@@ -12,27 +12,27 @@
 //
 // Work decomposition: a TASK is (row i, column window w).
 //   * rows whose product count  ub_i = sum_{k in A_i} nnz(B_k)  is <= 512 are one
-//     task handled by ONE WAVE with an LDS hash table (keys + f64 accumulators),
-//     then a bitonic sort of the table in LDS;
-//   * larger rows get one task per column window — 2^19 columns, narrowed down to 2^13 for
-//     heavy rows so that a hub row becomes many tasks — handled by a 512-thread workgroup
-//     with an LDS BITMAP of the window (64 KiB at most): setting bits is the
-//     symbolic pass, a popcount prefix over the bitmap turns a column into its
-//     rank inside the (sorted!) output row, so indices come out sorted for free.
-//     Values are accumulated in LDS, in passes of <= 6144 outputs (superblock ranges of
-//     the window); within a pass every wave owns a product-balanced range of 4096-column
-//     superblocks and applies the k's in ascending order (8 k's prefetched at a time).
-//   * a column-bucket table of B (entries of every row before each 4096-column boundary,
-//     built per call, 4 B per row per 4096 columns) replaces the binary searches that
-//     locate a row inside a window / superblock range, and yields the per-superblock
-//     product counts used for the balancing.
+//     task handled by ONE WAVE with an LDS hash table (keys + f64 accumulators): the
+//     products of the row are walked 64 at a time in the reference's order, keys inserted in
+//     parallel, products added through order tags; then a bitonic sort of the table in LDS.
+//     Rows of <= 64 products use 128-slot tables (32 waves per CU).
+//   * larger rows get one task per column window — 2^17 columns by default, narrowed down to
+//     2^13 for heavy rows so that a hub row becomes many tasks — handled by a 512-thread
+//     workgroup with an LDS BITMAP of the window: setting bits is the symbolic pass, a popcount
+//     prefix over the bitmap turns a column into its rank inside the (sorted!) output row, so
+//     indices come out sorted for free.  Values are accumulated in LDS, in passes of a few
+//     thousand outputs (superblock ranges of the window); within a pass the expansion is walked
+//     entry-parallel, 2048 products per chunk, and products that meet in one accumulator are
+//     added in position order through LDS order tags (see large_numeric_kernel).
+//   * a column-bucket table of B (entries of every row before each 2048-column boundary,
+//     built per call, 4 B per row per 2048 columns) replaces the binary searches that
+//     locate a row inside a window / superblock range.
 // Per-task counts are scanned (hand-written two-level prefix sum, scan.hip) into output
 // offsets; C.indptr falls out of the same scan.  Integer/LDS/HBM-bound: no MFMA.
-// History of what was measured (profiles/): per-row windows + LDS accumulators 1.96 s ->
-// 0.50 s on config 5; bucket table, product balancing, LDS staging of the k metadata,
-// LDS-only passes and 8-deep prefetch together -> 0.465 s; a flattened (load-balanced)
-// entry walk was slower and was dropped.  SPGEMM_PROF (option spgemm_prof) prints the
-// phase profile of the large-row numeric kernel.
+// History of what was measured (profiles/): per-row windows + LDS accumulators
+// 1.96 s -> 0.50 s on config 5; bucket table, LDS staging, prefetch -> 0.454 s (waves owning
+// column ranges, one k at a time); entry-parallel expansion with order tags -> 0.22 s.
+// SPGEMM_PROF (option spgemm_prof) prints the phase profile of the large-row numeric kernel.
 #include "common.hpp"
 #include "scan.hpp"
 
@@ -57,12 +57,12 @@ constexpr uint32_t NO_TAG = 0xFFFFFFFFu;
 // LDS layout of the large-row kernels for windows of up to 2^WL columns.  The narrower the window
 // the more workgroups share a CU (each phase of a task ends in a barrier, so a lone workgroup
 // leaves the CU idle while its loads are in flight): 2^19 -> 1 per CU, 2^18 -> 2, 2^17 -> 3, 2^16 -> 4.
+// Measured on config 5: 257 / 243 / 185 / 300 ms for the numeric kernel -> the default is 2^17.
 template <int WL>
 struct LgCfg {
     static constexpr int WORDS = 1 << (WL - 6);                 // 64-bit bitmap words
     static constexpr int WPT = WORDS / LG_BLOCK;                // words per thread in the popcount prefix
     static constexpr int NSUPER = WORDS / SUPER_WORDS;
-    static constexpr int TPS = SUPER_WORDS / WPT;               // threads per superblock
     // accumulators (+ order tags) of one pass; a superblock alone (<= 2048 outputs) must fit
     static constexpr int ACC_CAP = WL >= 19 ? 5632 : WL == 18 ? 2304 : WL == 17 ? 2048 : 2048;
     static constexpr int K_CAP = WL >= 18 ? 512 : 256;          // k's staged in LDS per group (<= one per thread)
@@ -387,7 +387,8 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
 // groups of K_CAP (their sub-range of B inside the window and the exclusive prefix of the
 // sub-range lengths, in LDS); the concatenation of those sub-ranges — the expansion of the task
 // in the reference's own order, k ascending, columns ascending inside a k — is then walked by all
-// 512 threads, thread t taking flat positions t, t + 512, ...: every load is independent.
+// 512 threads, each taking a run of CONSECUTIVE flat positions (one owner search per run, then a
+// step per boundary crossed): every load is independent.
 // (The first design let each wave walk "its" columns one k at a time: 332 M steps of 16 entries,
 // ~2 000 cycles of dependent LDS latency each, 56 % of the kernel — profiles/r01y.)
 // ---------------------------------------------------------------------------
