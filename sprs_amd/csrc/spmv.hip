@@ -28,7 +28,9 @@
 //     serves 1/8 of x: eight times the effective cache.  Slice results are per-row
 //     partials, summed in slice order by a last small kernel (deterministic).
 //     The split is a pure re-layout in HBM (the handle keeps its CSR arrays);
-//     correctness never depends on where a workgroup runs.
+//     correctness never depends on where a workgroup runs.  The copies carry column ids
+//     RELABELLED by popularity class, and x is gathered into that order at the start of every
+//     SpMV, so that the 16 x entries of an L2 line are equally popular (see the rl_* kernels).
 //
 //  3. Products use a separately rounded multiply and add (-ffp-contract=off), as sprs'
 //     MulAcc does (sprs/src/mul_acc.rs:28-30); only the summation order inside a row
