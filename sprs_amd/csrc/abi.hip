@@ -111,7 +111,10 @@ hipError_t pool_alloc(void **out, uint64_t bytes, uint64_t *cap, int device) {
 
 void pool_free(void *ptr, uint64_t cap, int device) {
     if (!ptr) return;
-    if (options().pool && cap >= POOL_MIN) {
+    int current = -1;
+    // a block of ANOTHER device than the calling thread's current one goes straight back to the driver:
+    // the synchronisation below would wait on the wrong device
+    if (options().pool && cap >= POOL_MIN && hipGetDevice(&current) == hipSuccess && current == device) {
         Pool &p = pool();
         // the block may still be read by kernels in flight: same guarantee as hipFree
         if (hipDeviceSynchronize() == hipSuccess) {
