@@ -199,10 +199,13 @@ def _dense_output_case():
         import scipy.sparse as sp
         rng = np.random.default_rng(16)
         cols = 300_000
-        b = sp.random(2000, cols, density=0.004, random_state=7, format="csr")          # ~1200 per row
-        dense_band = sp.random(2000, 6000, density=0.5, random_state=8, format="csr")   # dense outputs in cols < 6000
-        b = (b + sp.hstack([dense_band, sp.csr_matrix((2000, cols - 6000))])).tocsr()
-        a = sp.random(24, 2000, density=0.3, random_state=9, format="csr")              # ~600 k's per row
+        # (numpy + coo instead of scipy.sparse.random, which needs ~20 s for these shapes)
+        per_row = 1200
+        r = np.repeat(np.arange(2000), per_row)
+        b = sp.coo_matrix((np.ones(r.size), (r, rng.integers(0, cols, r.size))), shape=(2000, cols)).tocsr()
+        band = sp.csr_matrix((rng.random((2000, 6000)) < 0.5).astype(np.float64))       # dense outputs in cols < 6000
+        b = (b + sp.hstack([band, sp.csr_matrix((2000, cols - 6000))])).tocsr()
+        a = sp.csr_matrix((rng.random((24, 2000)) < 0.3).astype(np.float64))            # ~600 k's per row
         a.data[:] = rng.standard_normal(a.nnz)
         b.data[:] = rng.standard_normal(b.nnz)
         a.sort_indices(); b.sort_indices()
