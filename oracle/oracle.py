@@ -290,3 +290,32 @@ def bicgstab(shape, indptr, indices, data, x0, b, tol, max_iter, soft_restart_th
     _chk(f(C.c_uint64(n), _p(indptr), _p(indices), _p(data), _p(x0), _p(b), C.c_double(tol), C.c_uint64(max_iter),
            C.c_double(soft_restart_threshold), _p(x), C.byref(info)))
     return x, {k: getattr(info, k) for k, _ in BicgstabInfo._fields_}
+
+
+def triplets_to_cs(shape, row_inds, col_inds, data, storage="CSR", idx_dtype=np.uint64):
+    """TriMatIter::into_cs (sprs/src/sparse/triplet_iter.rs:127-224): sort the triplets by (outer, inner),
+    fold equal (row, col) neighbours with `slot = slot + next` (left to right, :168-171), fill indptr.
+    The reference's sort is UNSTABLE, so the order inside a group of duplicates — hence the rounding of a sum
+    of three or more — is unspecified there; this restatement takes the stable order (triplet order), which
+    is what the device path produces.  Explicit zeros and sums that cancel stay stored.
+    Returns (indptr u64, indices idx_dtype, data)."""
+    rows, cols = shape
+    r = np.asarray(row_inds, dtype=np.int64)
+    c = np.asarray(col_inds, dtype=np.int64)
+    v = np.asarray(data, dtype=np.float64)
+    outer, inner, n_outer = (r, c, rows) if storage == "CSR" else (c, r, cols)
+    order = np.lexsort((inner, outer))                       # stable: ties keep triplet order
+    outer, inner, v = outer[order], inner[order], v[order]
+    out_outer, out_inner, out_v = [], [], []
+    for k in range(v.size):                                   # the reference's loop, slot by slot
+        if k and outer[k] == outer[k - 1] and inner[k] == inner[k - 1]:
+            out_v[-1] = out_v[-1] + v[k]
+        else:
+            out_outer.append(outer[k])
+            out_inner.append(inner[k])
+            out_v.append(v[k])
+    indptr = np.zeros(n_outer + 1, dtype=np.uint64)
+    np.add.at(indptr, np.asarray(out_outer, dtype=np.int64) + 1, 1)
+    indptr = np.cumsum(indptr).astype(np.uint64)
+    return indptr, np.asarray(out_inner, dtype=idx_dtype), np.asarray(out_v, dtype=np.float64)
+
