@@ -165,6 +165,40 @@ inline DeviceVec operator*(const DeviceCsMat &a, const DeviceVec &x) {
 // `&A * &B` (csmat.rs:1866-1888)
 inline DeviceCsMat operator*(const DeviceCsMat &a, const DeviceCsMat &b) { return smmp::mul_csr_csr(a, b); }
 
+// TriMatI<f64, usize> (sparse/triplet.rs:26-48) with the device assembly of `to_csr` (triplet.rs:270-276 ->
+// triplet_iter.rs:127-224: rows sorted, duplicates summed).  No dedicated kernel: with n triplets the matrix
+// is the product R * E of R (rows x n, one 1 per column at the triplet's row) and E (n x cols, one value per
+// row at the triplet's column); the SpGEMM adds over k = triplet index ascending.
+class TriMat {
+public:
+    TriMat(uint64_t rows, uint64_t cols) : rows_(rows), cols_(cols) {}
+    void add_triplet(uint64_t row, uint64_t col, double val) {
+        if (row >= rows_ || col >= cols_) throw Error(SPRS_HIP_INVALID_ARG, "index out of bounds");
+        r_.push_back(row);
+        c_.push_back(col);
+        v_.push_back(val);
+    }
+    uint64_t nnz() const { return v_.size(); }
+    DeviceCsMat to_csr() const {
+        const uint64_t n = v_.size();
+        if (n == 0) return DeviceCsMat(SPRS_HIP_CSR, rows_, cols_, std::vector<uint64_t>(rows_ + 1, 0),
+                                       std::vector<uint64_t>(), std::vector<double>(), false);
+        std::vector<uint64_t> ptr(n + 1);
+        for (uint64_t i = 0; i <= n; ++i) ptr[i] = i;
+        DeviceCsMat sel_csc(SPRS_HIP_CSC, rows_, n, ptr, r_, std::vector<double>(n, 1.0));
+        sprs_hip_csmat *sel = nullptr;
+        check(sprs_hip_csmat_to_other_storage(sel_csc.handle(), &sel));
+        DeviceCsMat sel_csr(sel);
+        DeviceCsMat ent(SPRS_HIP_CSR, n, cols_, ptr, c_, v_);
+        return smmp::mul_csr_csr(sel_csr, ent);
+    }
+
+private:
+    uint64_t rows_, cols_;
+    std::vector<uint64_t> r_, c_;
+    std::vector<double> v_;
+};
+
 namespace linalg {
 // linalg::bicgstab::BiCGSTAB (sprs/src/sparse/linalg/bicgstab.rs): `solve` returns the solver object in
 // both the Ok and the Err case of the reference (Err = iteration limit, results still inside); here
