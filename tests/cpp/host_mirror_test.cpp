@@ -82,6 +82,19 @@ int main() {
             REQUIRE(std::fabs(1.0 - 1.0 / bi) < 1e-60);
         }
     }
+    {   // TriMat::to_csr: rows sorted, duplicates summed in triplet order, explicit zero kept (triplet_iter.rs:127-224)
+        TriMat t(4, 4);
+        const uint64_t r[6] = {2, 0, 2, 0, 2, 1}, c[6] = {1, 3, 1, 0, 1, 2};
+        const double v[6] = {1e16, 5.0, 1.0, 0.0, -1e16, 7.0};
+        for (int i = 0; i < 6; ++i) t.add_triplet(r[i], c[i], v[i]);
+        DeviceCsMat m = t.to_csr();
+        std::vector<uint64_t> ip, ix;
+        std::vector<double> dt;
+        m.to_host(ip, ix, dt);
+        REQUIRE((ip == std::vector<uint64_t>{0, 2, 3, 4, 4}));
+        REQUIRE((ix == std::vector<uint64_t>{0, 3, 2, 1}));
+        REQUIRE((dt == std::vector<double>{0.0, 5.0, 7.0, (1e16 + 1.0) + -1e16}));
+    }
     {   // panics -> exceptions with the reference's text
         DeviceCsMat a = mat1();
         DeviceVec x4(4), y5(5);
