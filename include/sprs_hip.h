@@ -127,6 +127,11 @@ int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint
  * modifying the arrays of a WRAPPED handle in place (sprs_hip_csmat_wrap_device), call this to drop
  * the cached plans; they are rebuilt by the next multiply. */
 int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m);
+/* What the SpMV plan cached in the handle looks like (after the first multiply; kind 0 before):
+ * kind 1 = nnz tiles over the handle's own arrays, 2 = XCD-sliced copy (spmv.hip), 3 = banded copy
+ * with the hot columns served from LDS (spmv_band.hip); plan_bytes = HBM the plan holds besides the
+ * handle's arrays.  No counterpart in the reference (its CsMat has no derived state). */
+int32_t sprs_hip_csmat_spmv_plan_info(const sprs_hip_csmat *m, int32_t *kind, uint64_t *plan_bytes);
 /* transpose_view (csmat.rs:982-991): free, shares the buffers, flips storage + shape */
 int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **out);
 int32_t sprs_hip_csmat_free(sprs_hip_csmat *m);

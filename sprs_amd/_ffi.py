@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsprs_hip.so")
+# SPRS_HIP_LIBRARY: explicit path of the shared library to bind (deployments that keep it elsewhere; the
+# kernel-logic tests point it at the emulator build of the same sources, tests/emu).  No fallback either way.
+LIB_PATH = os.environ.get("SPRS_HIP_LIBRARY") or os.path.join(_HERE, "libsprs_hip.so")
 
 OK, DIM_MISMATCH, STORAGE_MISMATCH, INDEX_OVERFLOW, BAD_STRUCTURE, INVALID_ARG, \
     OUT_OF_MEMORY, HIP_ERROR, NO_DEVICE = range(9)
@@ -50,6 +52,7 @@ SIGNATURES = {
     "sprs_hip_csmat_download_outer": (i32, [vp, u64, u64, vp, vp, vp, P(u64)]),
     "sprs_hip_csmat_slice_outer": (i32, [vp, u64, u64, P(vp)]),
     "sprs_hip_csmat_refresh": (i32, [vp]),
+    "sprs_hip_csmat_spmv_plan_info": (i32, [vp, P(i32), P(u64)]),
     "sprs_hip_csmat_transpose_view": (i32, [vp, P(vp)]),
     "sprs_hip_csmat_free": (i32, [vp]),
     "sprs_hip_spmv_f64": (i32, [vp, vp, u64, vp, u64, i32, vp]),

@@ -133,6 +133,8 @@ void SpmvPlan::release() {
     auto drop = [](void *p) {
         if (p) (void)hipFree(p);
     };
+    band_free(band);
+    band = nullptr;
     drop(main.tile_row);
     drop(main.pos);
     if (main.owns) {
@@ -449,6 +451,32 @@ int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m) {
     return SPRS_HIP_OK;
 }
 
+int32_t sprs_hip_csmat_spmv_plan_info(const sprs_hip_csmat *m, int32_t *kind, uint64_t *plan_bytes) {
+    clear_error();
+    if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    auto *mm = const_cast<sprs_hip_csmat *>(m);
+    std::lock_guard<std::mutex> lock(mm->mu);
+    const SpmvPlan &pl = m->plan;
+    int32_t k = 0;
+    uint64_t bytes = 0;
+    if (pl.built) {
+        if (pl.band) {
+            k = 3;
+            bytes = band_plan_bytes(pl.band);
+        } else if (pl.xcs) {
+            k = 2;
+            bytes = pl.main.nnz * (8 + (uint64_t)pl.idx_bytes);
+            for (const auto &sl : pl.slice) bytes += sl.nnz * (8 + (uint64_t)pl.idx_bytes) + (sl.rows + 1) * 8;
+        } else {
+            k = 1;
+            bytes = (pl.main.ntiles + 1) * 8;
+        }
+    }
+    if (kind) *kind = k;
+    if (plan_bytes) *plan_bytes = bytes;
+    return SPRS_HIP_OK;
+}
+
 int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
     clear_error();
     if (!m || !out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
@@ -654,6 +682,18 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         o.spmv_lds_pad = value;
     } else if (!strcmp(name, "spmv_xmask")) {
         o.spmv_xmask = value;
+    } else if (!strcmp(name, "spmv_band")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band must be 0 (auto), 1 (on) or 2 (off)");
+        o.spmv_band = value;
+    } else if (!strcmp(name, "spmv_band_hot")) {
+        if (value < 0 || value > 96) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_hot must be in 0..96");
+        o.spmv_band_hot = value;
+    } else if (!strcmp(name, "spmv_band_phases")) {
+        if (value < 0 || value > 4) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_phases must be in 0..4");
+        o.spmv_band_phases = value;
+    } else if (!strcmp(name, "spmv_band_group")) {
+        if (value < 0 || value > 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_group must be in 0..1024");
+        o.spmv_band_group = value;
     } else {
         SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     }
@@ -681,6 +721,10 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_winlog")) *value = o.spgemm_winlog;
     else if (!strcmp(name, "spmv_lds_pad")) *value = o.spmv_lds_pad;
     else if (!strcmp(name, "spmv_xmask")) *value = o.spmv_xmask;
+    else if (!strcmp(name, "spmv_band")) *value = o.spmv_band;
+    else if (!strcmp(name, "spmv_band_hot")) *value = o.spmv_band_hot;
+    else if (!strcmp(name, "spmv_band_phases")) *value = o.spmv_band_phases;
+    else if (!strcmp(name, "spmv_band_group")) *value = o.spmv_band_group;
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }

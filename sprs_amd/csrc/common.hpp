@@ -52,6 +52,10 @@ struct Options {
     int64_t spgemm_heavy = 65536;  // SpGEMM: target products per task of a heavy row (narrower column windows)
     int64_t pool = 1;              // keep released result blocks (>= 1 MiB) for the next result instead of hipFree
     int64_t pool_max_bytes = 128ll << 30;   // cap on the bytes the pool may hold
+    int64_t spmv_band = 0;         // banded plan (hot columns from LDS, spmv_band.hip) instead of the XCD-sliced one: 0 auto (on), 1 on, 2 off
+    int64_t spmv_band_hot = 0;     // hot slices of 8192 labels each (0 = default 24)
+    int64_t spmv_band_phases = 0;  // label ranges of the cold rest (0 = default 1), 8 hash pieces each
+    int64_t spmv_band_group = 0;   // tiles per workgroup of the hot kernel (0 = default 4)
     int64_t spmv_lds_pad = 0;      // extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning)
     int64_t spmv_xmask = -1;       // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
 };
@@ -78,9 +82,13 @@ struct SpmvScratch {               // per stream: nothing in here is shared betw
     double *xp = nullptr;          // x in the plan's column labelling (relabelled plans)
 };
 
+struct BandPlan;                   // spmv_band.hip
+
 struct SpmvPlan {
     bool built = false;
     bool xcs = false;
+    BandPlan *band = nullptr;      // banded plan: when set, nothing else below is used
+    int64_t opt_band = -1, opt_band_hot = -1, opt_band_phases = -1, opt_band_group = -1;
     int64_t opt_xcs = -1, opt_split = -1, opt_idx32 = -1, opt_tile = -1, opt_sort = -1, opt_relabel = -1;   // option values the plan was built with
     uint32_t tile = 0;             // nnz per tile
     int idx_bytes = 8;             // width of the column ids the kernels read (handle's, or 4 for plan copies)
@@ -138,6 +146,11 @@ void pool_free(void *p, uint64_t cap, int device);
 uint64_t pool_trim();
 uint64_t pool_cached_bytes();
 
+// spmv_band.hip
+int32_t band_build(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out);   // *out stays null when the plan does not apply
+int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, bool accumulate, hipStream_t stream);
+void band_free(BandPlan *bp);
+uint64_t band_plan_bytes(const BandPlan *bp);
 // spmv.hip
 int32_t spmv_f64(sprs_hip_csmat *a, const double *x, double *y, bool accumulate, hipStream_t stream);
 // spgemm.hip

@@ -33,7 +33,11 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *wa
 // fence, which on gfx950 is an s_waitcnt vmcnt(0): the wave first waits for every global load AND store
 // it has in flight.  Where the threads of a workgroup only hand LDS data to each other, that turns each
 // barrier into a drain of unrelated streaming stores.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef SPRS_LDS_BARRIER   // (the CPU kernel emulator under tests/emu supplies its own two)
+#define SPRS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define SPRS_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
+__device__ __forceinline__ void lds_barrier() { SPRS_LDS_BARRIER(); }
 
 // the same scans with LDS-only barriers
 __device__ __forceinline__ uint64_t block_excl_scan_u64_lds(uint64_t v, uint64_t *wave_tot, uint64_t *total) {

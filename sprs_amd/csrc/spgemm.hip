@@ -718,7 +718,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                         }
                     }
                     if (prof) {
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        SPRS_WAIT_ALL();
                         mark(2);   // owner search + walk (LDS only)
                     }
                     uint32_t cc[U];
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                         bv[u] = pend[u] ? B.data[pos[u]] : 0.0;
                     }
                     if (prof) {
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        SPRS_WAIT_ALL();
                         mark(4);   // the 2 U loads of B entries
                     }
 #pragma unroll

@@ -166,6 +166,12 @@ class DeviceCsMat:
         """Drop the cached multiply plans after the wrapped device arrays were modified in place."""
         check(lib.sprs_hip_csmat_refresh(self._h))
 
+    def spmv_plan_info(self):
+        """-> (kind, plan_bytes): 0 none yet, 1 nnz tiles, 2 XCD-sliced copy, 3 banded copy (hot columns from LDS)."""
+        kind, nbytes = C.c_int32(), C.c_uint64()
+        check(lib.sprs_hip_csmat_spmv_plan_info(self._h, C.byref(kind), C.byref(nbytes)))
+        return kind.value, nbytes.value
+
     def transpose_view(self):
         """csmat.rs:982-991: free, shares buffers."""
         h = C.c_void_p()

@@ -1,0 +1,138 @@
+"""GPU parity tests of the BANDED SpMV plan (sprs_amd/csrc/spmv_band.hip: hot columns served from LDS,
+16-bit local column ids, compact row lists per piece) against the CPU oracle — the same bar as
+test_spmv_gpu.py: <= 1e-10 relative (north star), empty rows exact.  Reference semantics:
+prod::mul_acc_mat_vec_csr, sprs/src/sparse/prod.rs:103-127.
+
+The shapes below are chosen to hit the plan's corner cases at sizes the oracle handles in seconds:
+rows spanning several hot tiles (carries), tiles with more row segments than one staging round holds,
+hot slices without entries, a cold rest in several label ranges, every index-width combination."""
+import numpy as np
+import pytest
+
+from conftest import IDX_COMBOS
+from helpers import ragged_csr, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import sprs_amd
+    if sprs_amd.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need the MI355X (no CPU fallback exists)")
+    return sprs_amd
+
+
+class band_options:
+    def __init__(self, hip, hot, phases, group=0, split=32):
+        self.hip, self.vals = hip, dict(spmv_band=1, spmv_band_hot=hot, spmv_band_phases=phases,
+                                        spmv_band_group=group, spmv_xcs_split=split)
+
+    def __enter__(self):
+        for k, v in self.vals.items():
+            self.hip.set_option(k, v)
+
+    def __exit__(self, *exc):
+        for k in self.vals:
+            self.hip.set_option(k, 32 if k == "spmv_xcs_split" else 0)
+
+
+def oracle_spmv(shape, ip, ix, dt, x, y=None):
+    from oracle import oracle
+    out = np.zeros(shape[0]) if y is None else y.copy()
+    oracle.mul_acc_mat_vec_csr(shape, ip.astype(np.uint64), ix.astype(np.uint64), dt, x, out)   # same arithmetic at any width
+    return out
+
+
+def check_band(hip, shape, ip, ix, dt, seed=0, expect_kind=3):
+    from sprs_amd import prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    rng = np.random.default_rng(seed)
+    x = rng.random(shape[1]) + 0.5
+    a = DeviceCsMat.from_host(shape, ip, ix, dt)
+    xv = DeviceVec.from_host(x)
+    y = (a * xv).to_host()
+    assert a.spmv_plan_info()[0] == expect_kind
+    ref = oracle_spmv(shape, ip, ix, dt, x)
+    assert rel_err(y, ref) <= TOL
+    empty = np.diff(ip.astype(np.int64)) == 0
+    assert np.all(y[empty] == 0.0)
+    assert np.array_equal(y, (a * xv).to_host())            # cached plan + scratch: bit-identical
+    y0 = rng.random(shape[0]) + 0.5
+    yv = DeviceVec.from_host(y0)
+    prod.mul_acc_mat_vec_csr(a, xv, yv)                     # accumulate form (prod.rs:120-126)
+    y2 = yv.to_host()
+    assert rel_err(y2, oracle_spmv(shape, ip, ix, dt, x, y=y0)) <= TOL
+    assert np.array_equal(y2[empty], y0[empty])             # empty rows untouched, bit for bit
+    return y
+
+
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS + [(np.uint64, np.uint32)])
+@pytest.mark.parametrize("hot,phases", [(2, 1), (5, 3)])
+def test_rmat_vs_oracle(hip, idx, ptr, hot, phases):
+    from sprs_amd import gen
+    n = 50000
+    indptr, indices, data = gen.rmat_csr(n, 16)
+    ip, ix, dt = indptr.numpy().astype(ptr), indices.numpy().astype(idx), data.numpy()
+    with band_options(hip, hot, phases):
+        check_band(hip, (n, n), ip, ix, dt)
+
+
+def test_hub_rows_and_many_segments(hip):
+    """3 dense rows (20 000 entries each: every hot slice sees rows longer than two tiles -> carries) and 7 000
+    rows of 33 entries (a hot tile holds thousands of row segments: more than one staging round), short and
+    empty rows in between."""
+    lens = [0, 20000, 3, 0] + [33] * 3500 + [20000] + [1, 0, 31, 32] * 50 + [33] * 3500 + [20000, 0, 0, 7]
+    shape, ip, ix, dt = ragged_csr(lens, 20000, seed=3)
+    for group in (1, 4):
+        with band_options(hip, 2, 2, group=group):
+            check_band(hip, shape, ip, ix, dt, seed=group)
+
+
+def test_split_and_empty_pieces(hip):
+    """all long rows live in a narrow column range: most hot slices and hash pieces have no entries; a second
+    matrix has no short rows at all, a third no long rows (the banded plan does not apply: plain tiles)"""
+    rng = np.random.default_rng(11)
+    n, cols = 3000, 60000
+    lens = rng.integers(40, 90, size=n)
+    ip = np.zeros(n + 1, dtype=np.uint64)
+    ip[1:] = np.cumsum(lens)
+    ix = np.concatenate([np.sort(rng.choice(700, size=l, replace=False)) + 17000 for l in lens]).astype(np.uint64)
+    dt = rng.random(ix.size) + 0.5
+    with band_options(hip, 6, 2):
+        check_band(hip, (n, cols), ip, ix, dt)
+    with band_options(hip, 3, 1, split=2):
+        shape, ip2, ix2, dt2 = ragged_csr([5, 9, 2, 64, 300] * 400, 30000, seed=5)
+        check_band(hip, shape, ip2, ix2, dt2)
+    with band_options(hip, 3, 1, split=1000):
+        shape, ip3, ix3, dt3 = ragged_csr([5, 9, 0, 64, 300] * 100, 9000, seed=6)
+        check_band(hip, shape, ip3, ix3, dt3, expect_kind=1)
+
+
+def test_band_equals_sliced_and_plain_within_rounding(hip):
+    """the three plans group the products of a row differently: equal to the oracle within tolerance, to each
+    other within rounding"""
+    from sprs_amd import gen
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    n = 40000
+    indptr, indices, data = gen.rmat_csr(n, 24, seed=9)
+    ip, ix, dt = indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy()
+    x = gen.dense_vector(n, seed=2).numpy()
+    out = {}
+    try:
+        for name, opts in (("band", dict(spmv_band=1, spmv_band_hot=3)), ("sliced", dict(spmv_band=2, spmv_xcs=1)),
+                           ("plain", dict(spmv_band=2, spmv_xcs=2))):
+            for k, v in opts.items():
+                hip.set_option(k, v)
+            a = DeviceCsMat.from_host((n, n), ip, ix, dt)
+            out[name] = (a * DeviceVec.from_host(x)).to_host()
+            assert a.spmv_plan_info()[0] == {"band": 3, "sliced": 2, "plain": 1}[name]
+    finally:
+        for k in ("spmv_band", "spmv_band_hot", "spmv_xcs"):
+            hip.set_option(k, 0)
+    ref = oracle_spmv((n, n), ip, ix, dt, x)
+    for name, y in out.items():
+        assert rel_err(y, ref) <= TOL, name
+    assert rel_err(out["band"], out["plain"]) <= 1e-13 and rel_err(out["band"], out["sliced"]) <= 1e-13
