@@ -689,8 +689,10 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         if (value < 0 || value > 96) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_hot must be in 0..96");
         o.spmv_band_hot = value;
     } else if (!strcmp(name, "spmv_band_phases")) {
-        if (value < 0 || value > 4) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_phases must be in 0..4");
+        if (value < 0 || value > 8) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_phases must be in 0..8");
         o.spmv_band_phases = value;
+    } else if (!strcmp(name, "spmv_band_split_launch")) {
+        o.spmv_band_split_launch = value ? 1 : 0;
     } else if (!strcmp(name, "spmv_band_group")) {
         if (value < 0 || value > 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_group must be in 0..1024");
         o.spmv_band_group = value;
@@ -725,6 +727,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_band_hot")) *value = o.spmv_band_hot;
     else if (!strcmp(name, "spmv_band_phases")) *value = o.spmv_band_phases;
     else if (!strcmp(name, "spmv_band_group")) *value = o.spmv_band_group;
+    else if (!strcmp(name, "spmv_band_split_launch")) *value = o.spmv_band_split_launch;
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }

@@ -27,6 +27,7 @@
 //   adds the slabs of a long row in piece order.  No float atomics: bit-reproducible run to run.
 #include "spmv_shared.hpp"
 
+#include <cstdlib>
 #include <vector>
 
 namespace sprs_hip {
@@ -40,12 +41,11 @@ constexpr int CB_LOG2 = 13;
 constexpr int CB = 1 << CB_LOG2;     // labels per hot slice = doubles of the x tile in LDS (64 KiB)
 constexpr int HT = 8192;             // entries per hot tile
 constexpr int HNT = 1024;            // threads of a hot workgroup (16 waves, one workgroup per CU)
-constexpr int HPASS = HT / (HNT * 2);
 constexpr int CT = 4096;             // entries per cold / short tile
 constexpr int CNT = 256;             // threads of a cold workgroup (3 per CU)
 constexpr int CPASS = CT / (CNT * 2);
 constexpr int MAX_HOT = 96;
-constexpr int MAX_PHASES = 4;
+constexpr int MAX_PHASES = 8;
 constexpr int MAX_PIECES = MAX_HOT + 8 * MAX_PHASES + 1;
 
 // One CSR piece of the plan, as the kernels see it.
@@ -118,60 +118,56 @@ __device__ __forceinline__ void segment_sums(const double *prod, SegLds<T, SEGC>
 }
 
 // ---------------------------------------------------------------------------------------------
-// hot slices: x tile in LDS, 16-bit column ids.  A workgroup takes G consecutive tiles of ONE slice.
-// Values of tile g sit at vals[g * HT + i]; the column ids are stored in the order the threads read
-// them: thread t's eight ids (entries p * 2048 + 2 t + e, p = 0..3, e = 0..1) at cid[g * HT + 8 t + 2 p + e],
-// one 16-byte load.  Both arrays are padded to whole tiles with zeros, so a tile is always loaded in
-// full; the padding belongs to no row.
-// With 64 + 64 KiB of LDS there is ONE workgroup per CU and nobody else to hide its latencies, so the
-// loop is software-pipelined: everything tile t+1 needs from memory — its stream, its row boundaries and
-// output indices (up to HSEG segments), the next tile_row — is requested right after the products of
-// tile t are in LDS and lands while the segments of tile t are summed; the barriers in between wait for
-// LDS only.
+// hot slices: x tile in LDS, 16-bit column ids, row sums in registers.
+//
+// A workgroup (16 waves) loads the 8192 x entries of ONE slice into LDS once and then takes G consecutive
+// blocks of 8192 entries of that slice.  Inside a block every WAVE owns a WAVE TILE of 512 entries and
+// runs on its own: no workgroup barrier after the x tile is in place.
+// Layout of wave tile w (the plan owns it, so it is whatever the kernel reads best):
+//   * lane l works on the 8 CONSECUTIVE entries 8 l .. 8 l + 7 of the tile;
+//   * column ids in natural order: cid[512 w + i], one 16-byte load per lane; 13 bits of local column,
+//     bit 15 = "this entry is the first of its row in this slice" (the row structure travels with the stream:
+//     the kernel reads no row offsets at all);
+//   * values transposed so that the four coalesced 16-byte loads of a lane return exactly its entries:
+//     entry 8 l + 2 p + e is stored at vals[512 w + 128 p + 2 l + e];
+//   * both arrays are padded with zeros to whole blocks; the padding belongs to no row.
+// Row sums: every lane folds its 8 products serially (runs that start AND end inside the lane are written
+// at once), then one segmented scan over the 64 lanes (shuffles) completes the runs that cross lanes; the
+// run open at the start of the tile goes to carry[w] (band_carry_kernel adds it to the row that owns it), the
+// run open at its end is the partial sum of the last row starting in the tile.  Where a sum goes comes from
+// rowidx[tile_row[w] + ordinal of the row inside the tile], prefetched a tile ahead and parked in LDS.
+// History (profiles/r02a, r02b): one 8192-entry tile per workgroup iteration with products staged in LDS and
+// three workgroup barriers: 2.9 TB/s (one workgroup per CU, nothing overlaps); the same per wave: 3.1 TB/s
+// (bound by the serial LDS read-add loops of the segment sums).
 // ---------------------------------------------------------------------------------------------
-constexpr int HSEG = 2 * HNT - 1;    // segments staged per round: boundaries 0..HSEG = two per thread
+constexpr int WT = 512;                       // entries per wave tile
+constexpr int WPB = HT / WT;                  // wave tiles per block = waves per workgroup
+constexpr int WPASS = WT / (WAVE * 2);        // 16-byte value loads per lane and tile
+constexpr int EPL = WT / WAVE;                // entries per lane
+constexpr int NPRE = 4;                       // output indices prefetched per lane (rows 64 q + lane of the tile)
+constexpr uint32_t ROW_START = 0x8000u;       // flag bit in a hot column id
+static_assert(WPB * WAVE == HNT && WPASS == 4 && EPL == 8, "hot kernel geometry");
 
-struct HotPrefetch {
-    dbl2 av[HPASS];
-    u32x4 cw;
-    uint32_t pb[2], po[2];           // ptr / rowidx of segments tid and tid + HNT of the tile (first round)
-    uint32_t R1;                     // tile_row[t + 1]
-};
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave complete in order; this keeps the COMPILER from moving them across the hand-over
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __global__ __launch_bounds__(HNT) void band_hot_kernel(const BandPiece *__restrict__ pieces,
                                                        const uint32_t *__restrict__ wg_off, uint32_t nh, uint32_t G,
                                                        const double *__restrict__ vals, const uint16_t *__restrict__ cid,
                                                        const double *__restrict__ xp) {
     __shared__ __attribute__((aligned(16))) double xs[CB];
-    __shared__ __attribute__((aligned(16))) double prod[HT];
-    __shared__ SegLds<HT, HSEG> L;
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t ridx_s[WPB][NPRE * WAVE];
+    const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t k = 0;
     while (k + 1 < nh && blockIdx.x >= wg_off[k + 1]) ++k;       // block-uniform
     const BandPiece d = pieces[k];
-    const uint32_t t0 = (blockIdx.x - wg_off[k]) * G;
-    const uint32_t t1 = t0 + G < d.ntiles ? t0 + G : d.ntiles;
-    if (t0 >= t1) return;
-
-    HotPrefetch nx;
-    // everything tile t needs, given R0 = tile_row[t]
-    auto request = [&](uint32_t t, uint32_t R0) {
-        const uint64_t g = d.ent0 + (uint64_t)t * HT;
-#pragma unroll
-        for (int p = 0; p < HPASS; ++p) nx.av[p] = __builtin_nontemporal_load((const dbl2 *)(vals + g + p * (HNT * 2) + tid * 2));
-        nx.cw = __builtin_nontemporal_load((const u32x4 *)(cid + g + tid * 8));
-        nx.R1 = d.tile_row[t + 1];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            // segment j = tid + q HNT (j >= 1) is compact row R0 + j - 1; rows past the piece's last are never used
-            uint32_t r = R0 + tid + q * HNT;
-            r = r ? r - 1 : 0;
-            nx.pb[q] = d.ptr[r < d.nr ? r : d.nr];              // ptr has nr + 1 entries (the last boundary of a tile may be ptr[nr])
-            nx.po[q] = d.rowidx[r < d.nr ? r : d.nr - 1];
-        }
-    };
-    uint32_t R0 = d.tile_row[t0];
-    request(t0, R0);
+    const uint32_t nwt = d.ntiles;                               // wave tiles of the slice
+    const uint32_t b0 = (blockIdx.x - wg_off[k]) * G;            // first block of this workgroup
     // x tile of the slice -> LDS (xp is padded to a whole number of tiles)
     {
         const dbl2 *src = (const dbl2 *)(xp + d.x0);
@@ -181,50 +177,107 @@ __global__ __launch_bounds__(HNT) void band_hot_kernel(const BandPiece *__restri
 #pragma unroll
         for (int q = 0; q < CB / (2 * HNT); ++q) *(dbl2 *)&xs[2 * (q * HNT + tid)] = v[q];
     }
-    tile_barrier<true>();   // xs complete
-    for (uint32_t t = t0; t < t1; ++t) {
+    uint32_t *ridx = ridx_s[wave];
+
+    // pipeline registers: the next tile of this wave (stream + output indices in flight), tile_row of the one after
+    dbl2 av[WPASS];
+    u32x4 cw;
+    uint32_t po[NPRE];
+    uint32_t R0n = 0, R0nn = 0;
+    auto tile_of = [&](uint32_t it) { return (b0 + it) * (uint32_t)WPB + wave; };
+    auto request_row = [&](uint32_t w) { return d.tile_row[w < nwt ? w : nwt - 1]; };   // past the slice: harmless reload
+    auto request_tile = [&](uint32_t w, uint32_t r0) {
+        const uint64_t g = d.ent0 + (uint64_t)(w < nwt ? w : nwt - 1) * WT;
 #pragma unroll
-        for (int p = 0; p < HPASS; ++p) {
-            const uint32_t w = nx.cw[p];
-            dbl2 pr;
-            pr[0] = nx.av[p][0] * xs[w & (CB - 1)];
-            pr[1] = nx.av[p][1] * xs[(w >> 16) & (CB - 1)];
-            *(dbl2 *)&prod[p * (HNT * 2) + tid * 2] = pr;
+        for (int p = 0; p < WPASS; ++p) av[p] = __builtin_nontemporal_load((const dbl2 *)(vals + g + p * (WAVE * 2) + lane * 2));
+        cw = __builtin_nontemporal_load((const u32x4 *)(cid + g + lane * EPL));
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const uint32_t r = r0 + q * WAVE + lane;             // the row that starts at the tile's flag number 64 q + lane
+            po[q] = d.rowidx[r < d.nr ? r : d.nr - 1];
         }
-        const uint32_t R1 = nx.R1;
-        const uint32_t pb0 = nx.pb[0], pb1 = nx.pb[1], po0 = nx.po[0], po1 = nx.po[1];
-        if (t + 1 < t1) request(t + 1, R1);      // in flight while this tile's segments are summed
-        const uint64_t base = (uint64_t)t * HT;
-        const uint32_t cnt = d.nnz - base < (uint64_t)HT ? (uint32_t)(d.nnz - base) : (uint32_t)HT;
-        const uint64_t lim = base + cnt;
-        const uint32_t Rt = R0;
-        segment_sums<HNT, HT, HSEG, true>(
-            prod, L, R1 - Rt + 1,
-            [&](uint32_t j0, uint32_t n) {
-                if (j0 == 0) {
-                    // boundaries 0 .. n (n <= HSEG = 2 HNT - 1): the two values requested a tile ago
-                    if (tid <= n) {
-                        L.segb[tid] = tid == 0 ? 0u : (uint32_t)(((uint64_t)pb0 < lim ? (uint64_t)pb0 : lim) - base);
-                        L.segr[tid] = po0;
-                    }
-                    if (tid + HNT <= n) {
-                        L.segb[tid + HNT] = (uint32_t)(((uint64_t)pb1 < lim ? (uint64_t)pb1 : lim) - base);
-                        L.segr[tid + HNT] = po1;
-                    }
-                } else {
-                    for (uint32_t u = tid; u <= n; u += HNT) {
-                        const uint32_t r = Rt + j0 + u - 1;      // j0 >= HSEG > 0
-                        const uint64_t v = (uint64_t)d.ptr[r < d.nr ? r : d.nr];
-                        L.segb[u] = (uint32_t)((v < lim ? v : lim) - base);
-                        L.segr[u] = r < d.nr ? d.rowidx[r] : 0u;
-                    }
-                }
-            },
-            [&](uint32_t j, uint32_t o, double s) {
-                if (j == 0) d.carry[t] = s;
-                else d.out[o] = s;
-            });
-        R0 = R1;
+    };
+    if (tile_of(0) < nwt) {                                      // (nwt > 0 for every launched workgroup)
+        R0n = request_row(tile_of(0));
+        request_tile(tile_of(0), R0n);
+        R0nn = request_row(tile_of(1));
+    }
+    __syncthreads();   // xs complete; the only workgroup barrier
+    for (uint32_t it = 0; it < G; ++it) {
+        const uint32_t w = tile_of(it);
+        if (w >= nwt) break;                                     // wave-uniform
+        const uint64_t base = (uint64_t)w * WT;
+        const uint32_t cnt = d.nnz - base < (uint64_t)WT ? (uint32_t)(d.nnz - base) : (uint32_t)WT;
+        // ---- products of the lane's 8 consecutive entries, row-start flags ---------------------------
+        double pr[EPL];
+        uint32_t fb = 0;
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p) {
+            const uint32_t c2 = cw[p];
+            const uint32_t i0 = lane * EPL + 2 * p;
+            pr[2 * p] = i0 < cnt ? av[p][0] * xs[c2 & (CB - 1)] : 0.0;
+            pr[2 * p + 1] = i0 + 1 < cnt ? av[p][1] * xs[(c2 >> 16) & (CB - 1)] : 0.0;
+            fb |= ((c2 >> 15) & 1u) << (2 * p);
+            fb |= ((c2 >> 31) & 1u) << (2 * p + 1);
+        }
+        const uint32_t R0 = R0n;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) ridx[q * WAVE + lane] = po[q];
+        // ---- requests for the next tile of this wave ----------------------------------------------------
+        R0n = R0nn;
+        if (it + 1 < G && tile_of(it + 1) < nwt) {
+            request_tile(tile_of(it + 1), R0n);
+            R0nn = request_row(tile_of(it + 2));
+        }
+        wave_lds_fence();                                        // ridx[] of this wave is in place
+        // ---- rows starting in lower lanes: the ordinal of this lane's first row inside the tile ----------
+        uint32_t prefix = 0, nf = 0;
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) {
+            const unsigned long long m = __ballot((fb >> q) & 1u);
+            prefix += (uint32_t)__popcll(m & below);
+            nf += (uint32_t)__popcll(m);
+        }
+        auto out_index = [&](uint32_t j) -> uint32_t {           // where the sum of the tile's j-th starting row goes
+            return j < (uint32_t)(NPRE * WAVE) ? ridx[j] : d.rowidx[R0 + j];
+        };
+        // ---- serial fold of the lane's entries -------------------------------------------------------------
+        double run = 0.0, head = 0.0;
+        uint32_t seen = 0;                                       // rows started in this lane so far
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) {
+            if ((fb >> q) & 1u) {
+                if (seen == 0) head = run;                       // the run that was open when the lane began ends here
+                else d.out[out_index(prefix + seen - 1)] = run;  // a row that lies inside the lane
+                run = 0.0;
+                ++seen;
+            }
+            run += pr[q];
+        }
+        // ---- segmented scan over the lanes: S = sum of the run that is open at the END of the lane -------------
+        double S = run;
+        uint32_t F = seen ? 1u : 0u;
+#pragma unroll
+        for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
+            const double vs = __shfl_up(S, dlt, WAVE);
+            const uint32_t fs = __shfl_up(F, dlt, WAVE);
+            if (lane >= (uint32_t)dlt) {
+                if (!F) S = vs + S;
+                F |= fs;
+            }
+        }
+        double before = __shfl_up(S, 1, WAVE);                   // open run at the end of the previous lane
+        if (lane == 0) before = 0.0;
+        if (seen) {
+            const double v = before + head;                      // the run that ends at this lane's first row start
+            if (prefix == 0) d.carry[w] = v;                     // ... began before the tile
+            else d.out[out_index(prefix - 1)] = v;
+        }
+        if (lane == WAVE - 1) {                                  // the run still open at the end of the tile
+            if (nf == 0) d.carry[w] = S;                         // no row starts in the tile: all of it is head
+            else d.out[out_index(nf - 1)] = S;                   // partial sum of the last row starting here
+        }
+        wave_lds_fence();                                        // done with ridx[] before the next tile overwrites it
     }
 }
 
@@ -235,14 +288,16 @@ template <bool ACC>
 __global__ __launch_bounds__(CNT) void band_cold_kernel(const BandPiece *__restrict__ pieces,
                                                         const ColdGroup *__restrict__ groups, uint32_t ngroups,
                                                         const double *__restrict__ vals, const uint32_t *__restrict__ cid,
-                                                        const double *__restrict__ xp, double *__restrict__ y) {
+                                                        const double *__restrict__ xp, double *__restrict__ y,
+                                                        uint32_t block0) {
     __shared__ __attribute__((aligned(16))) double prod[CT];
     __shared__ SegLds<CT, SEG_CHUNK> L;
     const uint32_t tid = threadIdx.x;
+    const uint32_t bid = blockIdx.x + block0;
     uint32_t g = 0;
-    while (g + 1 < ngroups && blockIdx.x >= groups[g + 1].first_block) ++g;     // block-uniform
+    while (g + 1 < ngroups && bid >= groups[g + 1].first_block) ++g;     // block-uniform
     const ColdGroup cg = groups[g];
-    const uint32_t lb = blockIdx.x - cg.first_block;
+    const uint32_t lb = bid - cg.first_block;
     const uint32_t pi = cg.first_piece + (cg.npieces == 1 ? 0u : (lb & 7u));
     const uint32_t t = cg.npieces == 1 ? lb : (lb >> 3);
     const BandPiece d = pieces[pi];
@@ -311,7 +366,7 @@ __global__ __launch_bounds__(CNT) void band_cold_kernel(const BandPiece *__restr
 // a row that spans several tiles of a piece gets the heads of the later tiles added in tile order
 __global__ void band_carry_kernel(const BandPiece *__restrict__ pieces, uint32_t hot_pieces, double *__restrict__ y) {
     const BandPiece d = pieces[blockIdx.y];
-    const uint32_t T = blockIdx.y < hot_pieces ? (uint32_t)HT : (uint32_t)CT;
+    const uint32_t T = blockIdx.y < hot_pieces ? (uint32_t)WT : (uint32_t)CT;
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c + 1 >= d.ntiles) return;
     const uint32_t R0 = d.tile_row[c], R1 = d.tile_row[c + 1];
@@ -485,11 +540,11 @@ __global__ __launch_bounds__(256) void bp_scatter_kernel(const PTR *__restrict__
                 const PieceBuild b = pb[k];
                 const uint64_t e_rel = pos[(uint64_t)k * n_long + j] - b.start + before + rank;   // entry number inside the piece
                 if (b.hot) {
-                    const uint64_t tile = e_rel / HT;
-                    const uint32_t i = (uint32_t)(e_rel % HT);
-                    const uint32_t pp = i / (HNT * 2), tt = (i % (HNT * 2)) / 2, ee = i & 1u;
-                    vals_hot[b.ent0 + e_rel] = v;
-                    cid_hot[b.ent0 + tile * HT + tt * 8 + pp * 2 + ee] = (uint16_t)(label - b.x0);
+                    const uint64_t tile = e_rel / WT;              // wave tile; entry i = 8 l + 2 p + e of it belongs to lane l
+                    const uint32_t i = (uint32_t)(e_rel % WT);
+                    const uint32_t ll = i / EPL, pp = (i % EPL) / 2, ee = i & 1u;
+                    vals_hot[b.ent0 + tile * WT + pp * (WAVE * 2) + ll * 2 + ee] = v;
+                    cid_hot[b.ent0 + e_rel] = (uint16_t)((label - b.x0) | (before + rank == 0 ? ROW_START : 0u));
                 } else {
                     vals_cold[b.ent0 + e_rel] = v;
                     cid_cold[b.ent0 + e_rel] = label;
@@ -563,7 +618,7 @@ struct BandPlan {
     uint32_t *ptr_all = nullptr, *rowidx_all = nullptr, *tile_row_all = nullptr;
     uint32_t *hot_wg_off = nullptr;
     ColdGroup *groups = nullptr;
-    uint32_t ngroups = 0, hot_wgs = 0, cold_blocks = 0, max_tiles = 0;
+    uint32_t ngroups = 0, hot_wgs = 0, cold_blocks = 0, max_tiles = 0, short_first_block = 0;
     uint64_t total_tiles = 0;
     std::vector<BandPiece> host_pieces;            // carry / out filled per scratch
     std::vector<uint64_t> carry_off;
@@ -722,10 +777,11 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         d.x0 = b.x0;
         d.to_y = 0;
         if (b.hot) {
-            d.ntiles = (uint32_t)((b.nnz + HT - 1) / HT);
+            const uint64_t nblocks = (b.nnz + HT - 1) / HT;       // the arrays are padded to whole blocks of HT entries
+            d.ntiles = (uint32_t)((b.nnz + WT - 1) / WT);         // wave tiles
             b.ent0 = hot_tiles * HT;
-            hot_tiles += d.ntiles;
-            hot_wg_off[k + 1] = hot_wg_off[k] + (d.ntiles + bp->G - 1) / bp->G;
+            hot_tiles += nblocks;
+            hot_wg_off[k + 1] = hot_wg_off[k] + (uint32_t)((nblocks + bp->G - 1) / bp->G);
         } else {
             d.ntiles = (uint32_t)((b.nnz + CT - 1) / CT);
             b.ent0 = cold_ent;
@@ -796,7 +852,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         d.ptr = bp->ptr_all + po;
         d.rowidx = bp->rowidx_all + ro;
         d.tile_row = bp->tile_row_all + bp->carry_off[k];
-        jobs[k] = TileRowJob{d.ptr, bp->tile_row_all + bp->carry_off[k], d.nr, d.ntiles, k < nh ? (uint32_t)HT : (uint32_t)CT};
+        jobs[k] = TileRowJob{d.ptr, bp->tile_row_all + bp->carry_off[k], d.nr, d.ntiles, k < nh ? (uint32_t)WT : (uint32_t)CT};
     }
     TmpBuf jobs_d;
     SPRS_TRY_HIP(jobs_d.alloc(jobs.size() * sizeof(TileRowJob)));
@@ -818,6 +874,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         blocks += mt * 8;
     }
     if (bp->host_pieces[NP].ntiles) {
+        bp->short_first_block = blocks;
         groups.push_back(ColdGroup{blocks, NP, 1});
         blocks += bp->host_pieces[NP].ntiles;
     }
@@ -828,6 +885,23 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         SPRS_TRY_HIP(hipMemcpyAsync(bp->groups, groups.data(), groups.size() * sizeof(ColdGroup), hipMemcpyHostToDevice, stream));
     }
     SPRS_TRY_HIP(hipStreamSynchronize(stream));   // plan complete, temporaries may go
+    if (getenv("SPRS_HIP_DEBUG")) {
+        uint64_t hot_nnz = 0, cold_nnz = 0, hot_pairs = 0, cold_pairs = 0;
+        for (uint32_t k = 0; k < NP; ++k) {
+            (k < nh ? hot_nnz : cold_nnz) += bp->host_pieces[k].nnz;
+            (k < nh ? hot_pairs : cold_pairs) += bp->host_pieces[k].nr;
+        }
+        fprintf(stderr, "[sprs_hip band] rows %llu nnz %llu | long rows %llu, short non-empty rows %llu with %llu entries | hot: %u slices, %llu entries, "
+                        "%llu (row,slice) pairs | cold: %u pieces, %llu entries, %llu pairs | plan %.1f MB\n",
+                (unsigned long long)rows, (unsigned long long)nnz, (unsigned long long)n_long, (unsigned long long)n_short_rows,
+                (unsigned long long)nnz_short, (unsigned)nh, (unsigned long long)hot_nnz, (unsigned long long)hot_pairs,
+                (unsigned)(8 * phases), (unsigned long long)cold_nnz, (unsigned long long)cold_pairs, bp->bytes / 1e6);
+        fprintf(stderr, "[sprs_hip band] entries per hot slice:");
+        for (uint32_t k = 0; k < nh; ++k) fprintf(stderr, " %llu", (unsigned long long)bp->host_pieces[k].nnz);
+        fprintf(stderr, "\n[sprs_hip band] entries per cold piece:");
+        for (uint32_t k = nh; k < NP; ++k) fprintf(stderr, " %llu", (unsigned long long)bp->host_pieces[k].nnz);
+        fprintf(stderr, "\n");
+    }
     guard.p = nullptr;
     *out = bp;
     return SPRS_HIP_OK;
@@ -891,15 +965,23 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         SPRS_TRY_HIP(hipGetLastError());
     }
     if (bp->cold_blocks) {
-        if (acc)
-            hipLaunchKernelGGL(band_cold_kernel<true>, dim3(bp->cold_blocks), dim3(CNT), 0, stream, (const BandPiece *)sc->pieces,
-                               (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,
-                               (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y);
-        else
-            hipLaunchKernelGGL(band_cold_kernel<false>, dim3(bp->cold_blocks), dim3(CNT), 0, stream, (const BandPiece *)sc->pieces,
-                               (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,
-                               (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y);
-        SPRS_TRY_HIP(hipGetLastError());
+        // one launch for the cold pieces and the short rows; option spmv_band_split_launch: two launches (profiling)
+        uint32_t cut = bp->cold_blocks;
+        if (options().spmv_band_split_launch && bp->short_first_block && bp->short_first_block < bp->cold_blocks)
+            cut = bp->short_first_block;
+        for (uint32_t part = 0; part < 2; ++part) {
+            const uint32_t b0 = part ? cut : 0u, nb = part ? bp->cold_blocks - cut : cut;
+            if (!nb) continue;
+            if (acc)
+                hipLaunchKernelGGL(band_cold_kernel<true>, dim3(nb), dim3(CNT), 0, stream, (const BandPiece *)sc->pieces,
+                                   (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,
+                                   (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, b0);
+            else
+                hipLaunchKernelGGL(band_cold_kernel<false>, dim3(nb), dim3(CNT), 0, stream, (const BandPiece *)sc->pieces,
+                                   (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,
+                                   (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, b0);
+            SPRS_TRY_HIP(hipGetLastError());
+        }
     }
     if (bp->max_tiles > 1) {
         hipLaunchKernelGGL(band_carry_kernel, dim3((bp->max_tiles + 255) / 256, bp->npieces + 1), dim3(256), 0, stream,
