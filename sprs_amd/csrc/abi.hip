@@ -686,11 +686,20 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band must be 0 (auto), 1 (on) or 2 (off)");
         o.spmv_band = value;
     } else if (!strcmp(name, "spmv_band_hot")) {
-        if (value < 0 || value > 96) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_hot must be in 0..96");
+        if (value < 0 || value > 384) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_hot must be in 0..384");
         o.spmv_band_hot = value;
     } else if (!strcmp(name, "spmv_band_phases")) {
         if (value < 0 || value > 8) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_phases must be in 0..8");
         o.spmv_band_phases = value;
+    } else if (!strcmp(name, "spmv_band_hot_threads")) {
+        if (value != 0 && value != 512 && value != 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_hot_threads must be 0, 512 or 1024");
+        o.spmv_band_hot_threads = value;
+    } else if (!strcmp(name, "spmv_band_gather")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_gather must be 0, 1 or 2");
+        o.spmv_band_gather = value;
+    } else if (!strcmp(name, "spmv_band_overlap")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_overlap must be 0, 1 or 2");
+        o.spmv_band_overlap = value;
     } else if (!strcmp(name, "spmv_band_split_launch")) {
         o.spmv_band_split_launch = value ? 1 : 0;
     } else if (!strcmp(name, "spmv_band_group")) {
@@ -728,6 +737,9 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_band_phases")) *value = o.spmv_band_phases;
     else if (!strcmp(name, "spmv_band_group")) *value = o.spmv_band_group;
     else if (!strcmp(name, "spmv_band_split_launch")) *value = o.spmv_band_split_launch;
+    else if (!strcmp(name, "spmv_band_overlap")) *value = o.spmv_band_overlap;
+    else if (!strcmp(name, "spmv_band_hot_threads")) *value = o.spmv_band_hot_threads;
+    else if (!strcmp(name, "spmv_band_gather")) *value = o.spmv_band_gather;
     else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
     return SPRS_HIP_OK;
 }

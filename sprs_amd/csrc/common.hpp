@@ -53,10 +53,13 @@ struct Options {
     int64_t pool = 1;              // keep released result blocks (>= 1 MiB) for the next result instead of hipFree
     int64_t pool_max_bytes = 128ll << 30;   // cap on the bytes the pool may hold
     int64_t spmv_band = 0;         // banded plan (hot columns from LDS, spmv_band.hip) instead of the XCD-sliced one: 0 auto (on), 1 on, 2 off
-    int64_t spmv_band_hot = 0;     // hot slices of 8192 labels each (0 = default 24)
+    int64_t spmv_band_hot = 0;     // hot slices of 8192 labels each (0 = default 128)
     int64_t spmv_band_phases = 0;  // label ranges of the cold rest (0 = default 1), 8 hash pieces each
     int64_t spmv_band_split_launch = 0;   // profiling: short rows and cold pieces in two launches instead of one
-    int64_t spmv_band_group = 0;   // tiles per workgroup of the hot kernel (0 = default 4)
+    int64_t spmv_band_hot_threads = 0;    // threads per workgroup of the hot kernel: 1024 (default) or 512
+    int64_t spmv_band_gather = 0;         // how the cold kernel reads x: 0 plain, 1 non-temporal, 2 device scope (L1 bypass)
+    int64_t spmv_band_overlap = 0;        // 1: cold pieces + short rows on a second stream beside the hot kernel (measured: no gain)
+    int64_t spmv_band_group = 0;   // blocks of 8192 entries per workgroup of the hot kernel (0 = default 16)
     int64_t spmv_lds_pad = 0;      // extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning)
     int64_t spmv_xmask = -1;       // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
 };

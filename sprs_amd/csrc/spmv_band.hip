@@ -22,9 +22,12 @@
 //     so that the boundary walk no longer visits empty rows.
 //   Every piece is processed nnz-tile by nnz-tile (coalesced, balanced whatever the row lengths),
 //   products staged in LDS, row segments summed by one lane / one wave each, multi-tile rows fixed up
-//   through carries — the machinery of spmv.hip.  A piece writes one partial sum per (row, piece) into
-//   its slab; rows without entries in the piece keep the zero the slab was created with.  A last kernel
-//   adds the slabs of a long row in piece order.  No float atomics: bit-reproducible run to run.
+//   through carries — the machinery of spmv.hip.  A piece writes one partial sum per (row, piece) pair
+//   it has, COMPACTLY, in the order of its own row list (neighbouring lanes write neighbouring words: the
+//   first version scattered them into dense per-piece slabs, one 8-byte store per cache line, and those
+//   stores cost as much as the gathers they had replaced).  A last kernel adds the partials of a long row
+//   in piece order, finding them through per-(64 rows, piece) presence masks and base offsets.
+//   No float atomics: bit-reproducible run to run.
 #include "spmv_shared.hpp"
 
 #include <cstdlib>
@@ -40,21 +43,18 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int CB_LOG2 = 13;
 constexpr int CB = 1 << CB_LOG2;     // labels per hot slice = doubles of the x tile in LDS (64 KiB)
 constexpr int HT = 8192;             // entries per hot tile
-constexpr int HNT = 1024;            // threads of a hot workgroup (16 waves, one workgroup per CU)
-constexpr int CT = 4096;             // entries per cold / short tile
-constexpr int CNT = 256;             // threads of a cold workgroup (3 per CU)
-constexpr int CPASS = CT / (CNT * 2);
-constexpr int MAX_HOT = 96;
+constexpr int CNT = 256;             // threads of a cold / short workgroup: 4 independent waves, one wave tile each
+constexpr int MAX_HOT = 384;
 constexpr int MAX_PHASES = 8;
 constexpr int MAX_PIECES = MAX_HOT + 8 * MAX_PHASES + 1;
 
 // One CSR piece of the plan, as the kernels see it.
 struct BandPiece {
     const uint32_t *ptr;        // nr + 1 entry offsets, relative to the piece
-    const uint32_t *rowidx;     // nr: where the sum of compact row r goes in `out`
+    const uint32_t *rowidx;     // nr: long-row number (short piece: row of y) of compact row r
     const uint32_t *tile_row;   // ntiles + 1: first compact row starting at / after tile c
     double *carry;              // ntiles
-    double *out;                // slab of partial sums (n_long doubles); the short piece writes y instead
+    double *out;                // nr partial sums, one per compact row, in row-list order; the short piece writes y[rowidx[r]] instead
     uint64_t ent0;              // first entry of the piece in the value / column-id arrays of its class
     uint64_t nnz;
     uint32_t nr, ntiles;
@@ -65,57 +65,6 @@ struct BandPiece {
 struct ColdGroup {              // a run of blocks of the cold launch
     uint32_t first_block, first_piece, npieces;   // npieces 8: block b -> piece b % 8 (XCD b % 8), tile b / 8; 1: tile b
 };
-
-template <int T, int SEGC>
-struct SegLds {
-    uint32_t segb[SEGC + 1];        // tile-local boundaries of the staged segments
-    uint32_t segr[SEGC + 1];        // where the sum of a staged segment goes (index into the piece's output)
-    uint32_t longlist[T / LONG_SEG + 1];
-    uint32_t nlong;
-};
-
-template <bool LDS_ONLY>
-__device__ __forceinline__ void tile_barrier() {
-    if constexpr (LDS_ONLY) lds_barrier();   // does not wait for global loads in flight (the prefetch of the next tile)
-    else __syncthreads();
-}
-
-// Row-segment sums of one tile whose products are in prod[0 .. cnt): segment 0 = head (the tail of a row
-// that started in an earlier tile), segment j >= 1 = compact row R0 + j - 1.  Segments are staged SEGC at a
-// time: stage(j0, n) fills L.segb[0 .. n] (boundaries) and L.segr[0 .. n) (output index of segment j0 + t);
-// emit(j, out_index, sum) is called once per segment.
-template <int NT, int T, int SEGC, bool LDS_ONLY, typename Stage, typename Emit>
-__device__ __forceinline__ void segment_sums(const double *prod, SegLds<T, SEGC> &L, uint32_t S, Stage stage, Emit emit) {
-    const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
-    if (tid == 0) L.nlong = 0;
-    for (uint32_t j0 = 0; j0 < S; j0 += SEGC) {
-        const uint32_t n = S - j0 < (uint32_t)SEGC ? S - j0 : (uint32_t)SEGC;
-        stage(j0, n);
-        tile_barrier<LDS_ONLY>();   // prod[], segb[], segr[], nlong visible
-        for (uint32_t t = tid; t < n; t += NT) {
-            const uint32_t sa = L.segb[t], sb = L.segb[t + 1];
-            if (sb - sa >= LONG_SEG) {
-                L.longlist[atomicAdd(&L.nlong, 1u)] = t;
-            } else {
-                double s = 0.0;
-                for (uint32_t k = sa; k < sb; ++k) s += prod[k];
-                emit(j0 + t, L.segr[t], s);
-            }
-        }
-        tile_barrier<LDS_ONLY>();   // longlist complete
-        const uint32_t nl = L.nlong;
-        for (uint32_t q = wave; q < nl; q += NT / WAVE) {
-            const uint32_t t = L.longlist[q];
-            const uint32_t sa = L.segb[t], sb = L.segb[t + 1];
-            double s = 0.0;
-            for (uint32_t k = sa + lane; k < sb; k += WAVE) s += prod[k];
-            s = wave_sum(s);
-            if (lane == 0) emit(j0 + t, L.segr[t], s);
-        }
-        tile_barrier<LDS_ONLY>();   // everyone done with segb / longlist / prod
-        if (tid == 0) L.nlong = 0;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // hot slices: x tile in LDS, 16-bit column ids, row sums in registers.
@@ -141,12 +90,10 @@ __device__ __forceinline__ void segment_sums(const double *prod, SegLds<T, SEGC>
 // (bound by the serial LDS read-add loops of the segment sums).
 // ---------------------------------------------------------------------------------------------
 constexpr int WT = 512;                       // entries per wave tile
-constexpr int WPB = HT / WT;                  // wave tiles per block = waves per workgroup
 constexpr int WPASS = WT / (WAVE * 2);        // 16-byte value loads per lane and tile
 constexpr int EPL = WT / WAVE;                // entries per lane
-constexpr int NPRE = 4;                       // output indices prefetched per lane (rows 64 q + lane of the tile)
 constexpr uint32_t ROW_START = 0x8000u;       // flag bit in a hot column id
-static_assert(WPB * WAVE == HNT && WPASS == 4 && EPL == 8, "hot kernel geometry");
+static_assert(WPASS == 4 && EPL == 8 && HT % WT == 0, "hot kernel geometry");
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave complete in order; this keeps the COMPILER from moving them across the hand-over
@@ -155,12 +102,16 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(HNT) void band_hot_kernel(const BandPiece *__restrict__ pieces,
+// NTH threads = NTH / 64 waves per workgroup; a workgroup advances NTH / 64 wave tiles ("a block") per iteration.
+// 1024 threads: one workgroup per CU; 512: two, so that the x-tile load of one overlaps the streaming of the other.
+template <int NTH>
+__global__ __launch_bounds__(NTH) void band_hot_kernel(const BandPiece *__restrict__ pieces,
                                                        const uint32_t *__restrict__ wg_off, uint32_t nh, uint32_t G,
                                                        const double *__restrict__ vals, const uint16_t *__restrict__ cid,
                                                        const double *__restrict__ xp) {
     __shared__ __attribute__((aligned(16))) double xs[CB];
-    __shared__ uint32_t ridx_s[WPB][NPRE * WAVE];
+    constexpr int WPB = NTH / WAVE;               // wave tiles per block = waves per workgroup
+    __shared__ __attribute__((aligned(16))) double stage_s[WPB][WT];   // sums of the rows starting in the wave's tile
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t k = 0;
@@ -171,35 +122,29 @@ __global__ __launch_bounds__(HNT) void band_hot_kernel(const BandPiece *__restri
     // x tile of the slice -> LDS (xp is padded to a whole number of tiles)
     {
         const dbl2 *src = (const dbl2 *)(xp + d.x0);
-        dbl2 v[CB / (2 * HNT)];
+        dbl2 v[CB / (2 * NTH)];
 #pragma unroll
-        for (int q = 0; q < CB / (2 * HNT); ++q) v[q] = src[q * HNT + tid];
+        for (int q = 0; q < CB / (2 * NTH); ++q) v[q] = src[q * NTH + tid];
 #pragma unroll
-        for (int q = 0; q < CB / (2 * HNT); ++q) *(dbl2 *)&xs[2 * (q * HNT + tid)] = v[q];
+        for (int q = 0; q < CB / (2 * NTH); ++q) *(dbl2 *)&xs[2 * (q * NTH + tid)] = v[q];
     }
-    uint32_t *ridx = ridx_s[wave];
+    double *stage = stage_s[wave];
 
-    // pipeline registers: the next tile of this wave (stream + output indices in flight), tile_row of the one after
+    // pipeline registers: the next tile of this wave (stream in flight), tile_row of the one after
     dbl2 av[WPASS];
     u32x4 cw;
-    uint32_t po[NPRE];
     uint32_t R0n = 0, R0nn = 0;
     auto tile_of = [&](uint32_t it) { return (b0 + it) * (uint32_t)WPB + wave; };
     auto request_row = [&](uint32_t w) { return d.tile_row[w < nwt ? w : nwt - 1]; };   // past the slice: harmless reload
-    auto request_tile = [&](uint32_t w, uint32_t r0) {
+    auto request_tile = [&](uint32_t w) {
         const uint64_t g = d.ent0 + (uint64_t)(w < nwt ? w : nwt - 1) * WT;
 #pragma unroll
         for (int p = 0; p < WPASS; ++p) av[p] = __builtin_nontemporal_load((const dbl2 *)(vals + g + p * (WAVE * 2) + lane * 2));
         cw = __builtin_nontemporal_load((const u32x4 *)(cid + g + lane * EPL));
-#pragma unroll
-        for (int q = 0; q < NPRE; ++q) {
-            const uint32_t r = r0 + q * WAVE + lane;             // the row that starts at the tile's flag number 64 q + lane
-            po[q] = d.rowidx[r < d.nr ? r : d.nr - 1];
-        }
     };
     if (tile_of(0) < nwt) {                                      // (nwt > 0 for every launched workgroup)
         R0n = request_row(tile_of(0));
-        request_tile(tile_of(0), R0n);
+        request_tile(tile_of(0));
         R0nn = request_row(tile_of(1));
     }
     __syncthreads();   // xs complete; the only workgroup barrier
@@ -220,16 +165,13 @@ __global__ __launch_bounds__(HNT) void band_hot_kernel(const BandPiece *__restri
             fb |= ((c2 >> 15) & 1u) << (2 * p);
             fb |= ((c2 >> 31) & 1u) << (2 * p + 1);
         }
-        const uint32_t R0 = R0n;
-#pragma unroll
-        for (int q = 0; q < NPRE; ++q) ridx[q * WAVE + lane] = po[q];
+        const uint32_t R0 = R0n;                                 // first compact row starting in this tile
         // ---- requests for the next tile of this wave ----------------------------------------------------
         R0n = R0nn;
         if (it + 1 < G && tile_of(it + 1) < nwt) {
-            request_tile(tile_of(it + 1), R0n);
+            request_tile(tile_of(it + 1));
             R0nn = request_row(tile_of(it + 2));
         }
-        wave_lds_fence();                                        // ridx[] of this wave is in place
         // ---- rows starting in lower lanes: the ordinal of this lane's first row inside the tile ----------
         uint32_t prefix = 0, nf = 0;
 #pragma unroll
@@ -238,9 +180,6 @@ __global__ __launch_bounds__(HNT) void band_hot_kernel(const BandPiece *__restri
             prefix += (uint32_t)__popcll(m & below);
             nf += (uint32_t)__popcll(m);
         }
-        auto out_index = [&](uint32_t j) -> uint32_t {           // where the sum of the tile's j-th starting row goes
-            return j < (uint32_t)(NPRE * WAVE) ? ridx[j] : d.rowidx[R0 + j];
-        };
         // ---- serial fold of the lane's entries -------------------------------------------------------------
         double run = 0.0, head = 0.0;
         uint32_t seen = 0;                                       // rows started in this lane so far
@@ -248,7 +187,7 @@ __global__ __launch_bounds__(HNT) void band_hot_kernel(const BandPiece *__restri
         for (int q = 0; q < EPL; ++q) {
             if ((fb >> q) & 1u) {
                 if (seen == 0) head = run;                       // the run that was open when the lane began ends here
-                else d.out[out_index(prefix + seen - 1)] = run;  // a row that lies inside the lane
+                else stage[prefix + seen - 1] = run;             // a row that lies inside the lane
                 run = 0.0;
                 ++seen;
             }
@@ -271,121 +210,205 @@ __global__ __launch_bounds__(HNT) void band_hot_kernel(const BandPiece *__restri
         if (seen) {
             const double v = before + head;                      // the run that ends at this lane's first row start
             if (prefix == 0) d.carry[w] = v;                     // ... began before the tile
-            else d.out[out_index(prefix - 1)] = v;
+            else stage[prefix - 1] = v;
         }
         if (lane == WAVE - 1) {                                  // the run still open at the end of the tile
             if (nf == 0) d.carry[w] = S;                         // no row starts in the tile: all of it is head
-            else d.out[out_index(nf - 1)] = S;                   // partial sum of the last row starting here
+            else stage[nf - 1] = S;                              // partial sum of the last row starting here
         }
-        wave_lds_fence();                                        // done with ridx[] before the next tile overwrites it
+        wave_lds_fence();                                        // stage[0 .. nf) complete
+        for (uint32_t j = lane; j < nf; j += WAVE) d.out[R0 + j] = stage[j];   // coalesced: compact rows R0 .. R0 + nf - 1
+        wave_lds_fence();                                        // read before the next tile overwrites it
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// cold pieces and the short rows: x gathered through L1 / L2 from xp, 32-bit labels
+// cold pieces and the short rows: x gathered through L1 / L2 from xp, 32-bit labels.
+//
+// Same wave-tile scheme as the hot kernel (512 entries per wave, 8 consecutive entries per lane, row sums
+// in registers, row starts flagged in the ids: bit 31), without an x tile: four independent waves per
+// workgroup, 4 KiB of LDS each (output staging), so that six workgroups share a CU and thousands of gathers
+// are in flight per CU.  (First version: 4096-entry tiles with the products staged in LDS and workgroup
+// barriers, three workgroups per CU: 135 G gathers/s whatever the piece — with ~190 gathers in flight per CU
+// at a few hundred ns each that is a latency bound, not a cache-throughput one; profiles/r02c-e.)
+// Layout of wave tile w: values as in the hot slices (entry 8 l + 2 p + e at vals[512 w + 128 p + 2 l + e]);
+// labels likewise transposed for two coalesced 16-byte loads: entry 8 l + 4 p + e at cid[512 w + 256 p + 4 l + e].
+// Pieces start at multiples of 512 entries and are padded with zeros.
 // ---------------------------------------------------------------------------------------------
-template <bool ACC>
+constexpr uint32_t ROW_START32 = 0x80000000u;
+
+// how the cold kernel reads x: 0 plain, 1 non-temporal, 2 device-scope (served by L2, no L1 allocation)
+template <int POLICY>
+__device__ __forceinline__ double gather_x(const double *__restrict__ xp, uint32_t i) {
+    if constexpr (POLICY == 1) return __builtin_nontemporal_load(xp + i);
+    else if constexpr (POLICY == 2) return __hip_atomic_load(xp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return xp[i];
+}
+
+template <bool ACC, int POLICY>
 __global__ __launch_bounds__(CNT) void band_cold_kernel(const BandPiece *__restrict__ pieces,
                                                         const ColdGroup *__restrict__ groups, uint32_t ngroups,
                                                         const double *__restrict__ vals, const uint32_t *__restrict__ cid,
                                                         const double *__restrict__ xp, double *__restrict__ y,
                                                         uint32_t block0) {
-    __shared__ __attribute__((aligned(16))) double prod[CT];
-    __shared__ SegLds<CT, SEG_CHUNK> L;
-    const uint32_t tid = threadIdx.x;
+    constexpr int WPB = CNT / WAVE;
+    __shared__ __attribute__((aligned(16))) double stage_s[WPB][WT];
+    const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t bid = blockIdx.x + block0;
     uint32_t g = 0;
     while (g + 1 < ngroups && bid >= groups[g + 1].first_block) ++g;     // block-uniform
     const ColdGroup cg = groups[g];
     const uint32_t lb = bid - cg.first_block;
     const uint32_t pi = cg.first_piece + (cg.npieces == 1 ? 0u : (lb & 7u));
-    const uint32_t t = cg.npieces == 1 ? lb : (lb >> 3);
+    const uint32_t w = (cg.npieces == 1 ? lb : (lb >> 3)) * WPB + wave;  // wave tile of the piece
     const BandPiece d = pieces[pi];
-    if (t >= d.ntiles) return;
-    const uint64_t base = (uint64_t)t * CT;
-    const uint32_t cnt = d.nnz - base < (uint64_t)CT ? (uint32_t)(d.nnz - base) : (uint32_t)CT;
-    const uint64_t lim = base + cnt;
-    const double *dp = vals + d.ent0 + base;
-    const uint32_t *ip = cid + d.ent0 + base;
-    if (cnt == (uint32_t)CT) {
-        u32x2 ix[CPASS];
-        dbl2 av[CPASS];
+    if (w >= d.ntiles) return;                                           // wave-uniform; no workgroup barrier below
+    double *stage = stage_s[wave];
+    const uint64_t base = (uint64_t)w * WT;
+    const uint32_t cnt = d.nnz - base < (uint64_t)WT ? (uint32_t)(d.nnz - base) : (uint32_t)WT;
+    const uint64_t gpos = d.ent0 + base;
+    dbl2 av[WPASS];
+    u32x4 lw[2];
 #pragma unroll
-        for (int p = 0; p < CPASS; ++p) {
-            const uint32_t i = p * (CNT * 2) + tid * 2;
-            ix[p] = __builtin_nontemporal_load((const u32x2 *)(ip + i));
-            av[p] = __builtin_nontemporal_load((const dbl2 *)(dp + i));
+    for (int p = 0; p < 2; ++p) lw[p] = __builtin_nontemporal_load((const u32x4 *)(cid + gpos + p * (WAVE * 4) + lane * 4));
+#pragma unroll
+    for (int p = 0; p < WPASS; ++p) av[p] = __builtin_nontemporal_load((const dbl2 *)(vals + gpos + p * (WAVE * 2) + lane * 2));
+    const uint32_t R0 = d.tile_row[w];
+    double xv[EPL];
+    uint32_t fb = 0;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        const uint32_t c = lw[q / 4][q % 4];
+        xv[q] = gather_x<POLICY>(xp, c & ~ROW_START32);                  // padding: label 0, value 0, never summed into a row
+        fb |= (c >> 31) << q;
+    }
+    double pr[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) pr[q] = lane * EPL + q < cnt ? av[q / 2][q % 2] * xv[q] : 0.0;
+    // ---- rows starting in lower lanes ------------------------------------------------------------------
+    uint32_t prefix = 0, nf = 0;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        const unsigned long long m = __ballot((fb >> q) & 1u);
+        prefix += (uint32_t)__popcll(m & below);
+        nf += (uint32_t)__popcll(m);
+    }
+    // ---- serial fold, segmented scan over the lanes (see band_hot_kernel) -----------------------------------
+    double run = 0.0, head = 0.0;
+    uint32_t seen = 0;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        if ((fb >> q) & 1u) {
+            if (seen == 0) head = run;
+            else stage[prefix + seen - 1] = run;
+            run = 0.0;
+            ++seen;
         }
-        double xv[CPASS][2];
+        run += pr[q];
+    }
+    double S = run;
+    uint32_t F = seen ? 1u : 0u;
 #pragma unroll
-        for (int p = 0; p < CPASS; ++p) {
-            xv[p][0] = xp[ix[p][0]];
-            xv[p][1] = xp[ix[p][1]];
-        }
-#pragma unroll
-        for (int p = 0; p < CPASS; ++p) {
-            dbl2 pr;
-            pr[0] = av[p][0] * xv[p][0];
-            pr[1] = av[p][1] * xv[p][1];
-            *(dbl2 *)&prod[p * (CNT * 2) + tid * 2] = pr;
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < CPASS; ++p) {
-            const uint32_t i = p * (CNT * 2) + tid * 2;
-            prod[i] = i < cnt ? dp[i] * xp[ip[i]] : 0.0;
-            prod[i + 1] = i + 1 < cnt ? dp[i + 1] * xp[ip[i + 1]] : 0.0;
+    for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
+        const double vs = __shfl_up(S, dlt, WAVE);
+        const uint32_t fs = __shfl_up(F, dlt, WAVE);
+        if (lane >= (uint32_t)dlt) {
+            if (!F) S = vs + S;
+            F |= fs;
         }
     }
-    const uint32_t R0 = d.tile_row[t], R1 = d.tile_row[t + 1];
-    double *out = d.to_y ? y : d.out;
-    const bool acc = ACC && d.to_y;
-    segment_sums<CNT, CT, SEG_CHUNK, false>(
-        prod, L, R1 - R0 + 1,
-        [&](uint32_t j0, uint32_t n) {
-            for (uint32_t u = tid; u <= n; u += CNT) {
-                const uint32_t j = j0 + u;
-                uint32_t b = 0, o = 0;
-                if (j != 0) {
-                    const uint32_t r = R0 + j - 1;
-                    const uint64_t v = (uint64_t)d.ptr[r];       // r <= nr: ptr has nr + 1 entries
-                    b = (uint32_t)((v < lim ? v : lim) - base);
-                    if (r < d.nr) o = d.rowidx[r];
-                }
-                L.segb[u] = b;
-                L.segr[u] = o;
-            }
-        },
-        [&](uint32_t j, uint32_t o, double s) {
-            if (j == 0) d.carry[t] = s;
-            else if (acc) out[o] = out[o] + s;     // every compact row has entries: empty rows are never touched (prod.rs:120-126)
-            else out[o] = s;
-        });
+    double before = __shfl_up(S, 1, WAVE);
+    if (lane == 0) before = 0.0;
+    if (seen) {
+        const double v = before + head;
+        if (prefix == 0) d.carry[w] = v;
+        else stage[prefix - 1] = v;
+    }
+    if (lane == WAVE - 1) {
+        if (nf == 0) d.carry[w] = S;
+        else stage[nf - 1] = S;
+    }
+    wave_lds_fence();                                                    // stage[0 .. nf) complete
+    if (d.to_y) {
+        for (uint32_t j = lane; j < nf; j += WAVE) {
+            const uint32_t r = d.rowidx[R0 + j];
+            if constexpr (ACC) y[r] = y[r] + stage[j];                   // every compact row has entries: empty rows are never touched (prod.rs:120-126)
+            else y[r] = stage[j];
+        }
+    } else {
+        for (uint32_t j = lane; j < nf; j += WAVE) d.out[R0 + j] = stage[j];
+    }
 }
 
-// a row that spans several tiles of a piece gets the heads of the later tiles added in tile order
-__global__ void band_carry_kernel(const BandPiece *__restrict__ pieces, uint32_t hot_pieces, double *__restrict__ y) {
-    const BandPiece d = pieces[blockIdx.y];
-    const uint32_t T = blockIdx.y < hot_pieces ? (uint32_t)WT : (uint32_t)CT;
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c + 1 >= d.ntiles) return;
-    const uint32_t R0 = d.tile_row[c], R1 = d.tile_row[c + 1];
-    if (R1 == R0) return;                                              // no row starts in tile c
-    if ((uint64_t)d.ptr[R1] <= (uint64_t)(c + 1) * T) return;          // its last row ends inside tile c
+// A row that spans several tiles of a piece gets the heads (carries) of the later tiles added, in tile order.
+// Which rows those are is fixed by the plan: one SPILL record per such row, found once when the plan is built
+// (scanning every tile of every piece in every SpMV took 33 us; profiles/r02c).
+struct Spill {
+    uint64_t out;               // index into the partial sums, or into y for the short piece
+    uint32_t first, n;          // carry slots first .. first + n - 1
+    uint32_t to_y, pad;
+};
+
+__global__ __launch_bounds__(256) void band_carry_kernel(const Spill *__restrict__ spills, uint32_t nspills,
+                                                         const double *__restrict__ carry, double *__restrict__ partial,
+                                                         double *__restrict__ y) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nspills) return;
+    const Spill sp = spills[r];
     double acc = 0.0;
-    for (uint32_t e = c + 1; e < d.ntiles && d.tile_row[e] == R1; ++e) acc += d.carry[e];
-    double *out = d.to_y ? y : d.out;
-    out[d.rowidx[R1 - 1]] += acc;
+    for (uint32_t i = 0; i < sp.n; ++i) acc += carry[sp.first + i];
+    double *out = sp.to_y ? y : partial;
+    out[sp.out] += acc;
 }
 
-// y[long_rows[j]] (+)= sum over the pieces, in piece order
+__global__ __launch_bounds__(256) void band_permute_kernel(const double *__restrict__ x, const uint32_t *__restrict__ perm,
+                                                           uint64_t cols, double *__restrict__ xp, double *__restrict__ y_zero,
+                                                           uint64_t rows) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < cols) xp[perm[j]] = x[j];
+    if (y_zero && j < rows) y_zero[j] = 0.0;
+}
+
+// y[long_rows[j]] (+)= sum of the row's partials, in piece order.  One wave per 64 consecutive long rows: for
+// piece k, wmask tells which of the 64 rows have a partial there and wbase where the first of them sits; the
+// present rows' partials follow each other in memory, so the loads of a wave are contiguous.
 template <bool ACC>
-__global__ void band_reduce_kernel(const double *__restrict__ partial, const uint32_t *__restrict__ long_rows,
-                                   double *__restrict__ y, uint32_t n_long, uint32_t npieces) {
+__global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restrict__ partial,
+                                                          const unsigned long long *__restrict__ wmask,
+                                                          const uint32_t *__restrict__ wbase,
+                                                          const uint32_t *__restrict__ long_rows, double *__restrict__ y,
+                                                          uint32_t n_long, uint32_t npieces) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint64_t wb = j / WAVE;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (wb * WAVE >= n_long) return;                            // wave-uniform: no table entries past the last row block
+    double s = 0.0;
+    for (uint32_t k0 = 0; k0 < npieces; k0 += WAVE) {
+        // the table rows of 64 pieces in one coalesced load: lane l holds piece k0 + l
+        const bool in = k0 + lane < npieces;
+        const unsigned long long mk = in ? wmask[wb * npieces + k0 + lane] : 0ull;
+        const uint32_t bs = in ? wbase[wb * npieces + k0 + lane] : 0u;
+        const uint32_t nk = npieces - k0 < (uint32_t)WAVE ? npieces - k0 : (uint32_t)WAVE;
+        constexpr int U = 32;                                   // partials in flight per lane (the loop is latency bound)
+        for (uint32_t kk = 0; kk < nk; kk += U) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int src = (int)(kk + u < nk ? kk + u : nk - 1);                          // wave-uniform
+                // (src is wave-uniform: scalar broadcasts, no LDS traffic)
+                const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mk >> 32), src) << 32) |
+                                             (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, src);
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bs, src);
+                const bool have = kk + u < nk && ((m >> lane) & 1ull);
+                v[u] = have ? partial[b + (uint32_t)__popcll(m & below)] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) s += v[u];              // piece order (absent pieces add +0.0)
+        }
+    }
     if (j >= n_long) return;
-    double s = partial[j];
-    for (uint32_t k = 1; k < npieces; ++k) s += partial[(uint64_t)k * n_long + j];
     const uint32_t r = long_rows[j];
     if constexpr (ACC) y[r] = y[r] + s;
     else y[r] = s;
@@ -432,7 +455,7 @@ __global__ void bp_fill_short_kernel(const PTR *__restrict__ indptr, const IDX *
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > rows) return;
     if (r == rows) {
-        s_ptr[short_pos[rows]] = (uint32_t)short_ptr[rows];
+        if (!s_cid) s_ptr[short_pos[rows]] = (uint32_t)short_ptr[rows];
         return;
     }
     const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
@@ -443,11 +466,17 @@ __global__ void bp_fill_short_kernel(const PTR *__restrict__ indptr, const IDX *
     }
     const uint64_t i = short_pos[r];
     uint64_t d = short_ptr[r];
-    s_rowidx[i] = (uint32_t)r;
-    s_ptr[i] = (uint32_t)d;
-    for (uint64_t p = s; p < e; ++p, ++d) {
-        s_cid[d] = perm[indices[p]];
-        s_val[d] = data[p];
+    if (!s_cid) {                 // first call: the row lists
+        s_rowidx[i] = (uint32_t)r;
+        s_ptr[i] = (uint32_t)d;
+        return;
+    }
+    for (uint64_t p = s; p < e; ++p, ++d) {       // second call: the entries, in the wave-tile layout of band_cold_kernel
+        const uint64_t tile = d / WT;
+        const uint32_t t = (uint32_t)(d % WT);
+        const uint32_t ll = t / EPL, q = t % EPL;
+        s_cid[tile * WT + (q / 4) * (WAVE * 4) + ll * 4 + (q & 3u)] = perm[indices[p]] | (p == s ? ROW_START32 : 0u);
+        s_val[tile * WT + (q / 2) * (WAVE * 2) + ll * 2 + (q & 1u)] = data[p];
     }
 }
 
@@ -546,8 +575,11 @@ __global__ __launch_bounds__(256) void bp_scatter_kernel(const PTR *__restrict__
                     vals_hot[b.ent0 + tile * WT + pp * (WAVE * 2) + ll * 2 + ee] = v;
                     cid_hot[b.ent0 + e_rel] = (uint16_t)((label - b.x0) | (before + rank == 0 ? ROW_START : 0u));
                 } else {
-                    vals_cold[b.ent0 + e_rel] = v;
-                    cid_cold[b.ent0 + e_rel] = label;
+                    const uint64_t tile = e_rel / WT;
+                    const uint32_t i = (uint32_t)(e_rel % WT);
+                    const uint32_t ll = i / EPL, q = i % EPL;
+                    vals_cold[b.ent0 + tile * WT + (q / 2) * (WAVE * 2) + ll * 2 + (q & 1u)] = v;
+                    cid_cold[b.ent0 + tile * WT + (q / 4) * (WAVE * 4) + ll * 4 + (q & 3u)] = label | (before + rank == 0 ? ROW_START32 : 0u);
                 }
             }
         }
@@ -570,6 +602,25 @@ __global__ void bp_rows_kernel(const uint64_t *__restrict__ cnt, const uint64_t 
         const uint64_t q = pair[idx] - b.pair0;
         rowidx_all[b.row_off + q] = (uint32_t)j;
         ptr_all[b.ptr_off + q] = (uint32_t)(pos[idx] - b.start);
+    }
+}
+
+// presence mask and first partial of every (block of 64 long rows, piece)
+__global__ __launch_bounds__(256) void bp_wave_tables_kernel(const uint64_t *__restrict__ cnt, const uint64_t *__restrict__ pair,
+                                                             uint64_t n_long, uint32_t npieces, uint64_t nwb,
+                                                             const PieceBuild *__restrict__ pb,
+                                                             unsigned long long *__restrict__ wmask, uint32_t *__restrict__ wbase) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint64_t wid = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;     // = wb * npieces + k
+    if (wid >= nwb * npieces) return;                                                  // wave-uniform
+    const uint64_t wb = wid / npieces;
+    const uint32_t k = (uint32_t)(wid - wb * npieces);
+    const uint64_t j = wb * WAVE + lane;
+    const bool have = j < n_long && cnt[(uint64_t)k * n_long + j] != 0;
+    const unsigned long long m = __ballot(have);
+    if (lane == 0) {
+        wmask[wid] = m;
+        wbase[wid] = pb[k].row_off + (uint32_t)(pair[(uint64_t)k * n_long + wb * WAVE] - pb[k].pair0);
     }
 }
 
@@ -597,6 +648,26 @@ __global__ void bp_tile_rows_kernel(const TileRowJob *__restrict__ jobs) {
     jb.tile_row[c] = lo;
 }
 
+struct SpillJob {
+    const uint32_t *ptr, *rowidx, *tile_row;
+    uint64_t out0;               // first partial sum of the piece; 0 for the short piece
+    uint32_t ntiles, T, carry0, to_y;
+};
+
+// tile c of a piece spills when its last starting row runs on into tile c + 1
+__global__ void bp_spill_kernel(const SpillJob *__restrict__ jobs, Spill *__restrict__ spills, unsigned int *__restrict__ count) {
+    const SpillJob jb = jobs[blockIdx.y];
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c + 1 >= jb.ntiles) return;
+    const uint32_t R0 = jb.tile_row[c], R1 = jb.tile_row[c + 1];
+    if (R1 == R0) return;                                              // no row starts in tile c
+    if ((uint64_t)jb.ptr[R1] <= (uint64_t)(c + 1) * jb.T) return;      // its last row ends inside tile c
+    uint32_t n = 0;
+    for (uint32_t e = c + 1; e < jb.ntiles && jb.tile_row[e] == R1; ++e) ++n;
+    const unsigned int slot = atomicAdd(count, 1u);
+    spills[slot] = Spill{jb.to_y ? (uint64_t)jb.rowidx[R1 - 1] : jb.out0 + (R1 - 1), jb.carry0 + c + 1, n, jb.to_y, 0u};
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -605,11 +676,15 @@ __global__ void bp_tile_rows_kernel(const TileRowJob *__restrict__ jobs) {
 struct BandScratch {        // per stream
     double *partial = nullptr, *carry = nullptr, *xp = nullptr;
     BandPiece *pieces = nullptr;
+    // the gather-bound kernels (cold pieces, short rows: L2 -> L1 fills) run beside the HBM-bound hot kernel on a second stream
+    hipStream_t aux = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 
 struct BandPlan {
     uint32_t nh = 0, phases = 1, npieces = 0;      // npieces = nh + 8 phases (the short piece comes after them)
     uint32_t n_long = 0, n_short_rows = 0, G = 4;
+    uint32_t hot_threads = 1024, hot_block = 8192; // threads of a hot workgroup; entries it advances per iteration
     uint64_t cols = 0, cols_pad = 0;
     uint32_t *perm = nullptr, *long_rows = nullptr;
     double *vals_hot = nullptr, *vals_cold = nullptr;
@@ -618,10 +693,15 @@ struct BandPlan {
     uint32_t *ptr_all = nullptr, *rowidx_all = nullptr, *tile_row_all = nullptr;
     uint32_t *hot_wg_off = nullptr;
     ColdGroup *groups = nullptr;
+    unsigned long long *wmask = nullptr;           // per (64 long rows, piece): which rows have a partial
+    uint32_t *wbase = nullptr;                     //                            and where the first one is
+    uint64_t total_pairs = 0;
+    void *spills = nullptr;                        // Spill records (device)
+    uint32_t nspills = 0;
     uint32_t ngroups = 0, hot_wgs = 0, cold_blocks = 0, max_tiles = 0, short_first_block = 0;
     uint64_t total_tiles = 0;
     std::vector<BandPiece> host_pieces;            // carry / out filled per scratch
-    std::vector<uint64_t> carry_off;
+    std::vector<uint64_t> carry_off, pair_off;
     std::unordered_map<void *, BandScratch> scratch;
     uint64_t bytes = 0;                            // HBM held by the plan (without scratch)
 };
@@ -642,11 +722,17 @@ void band_free(BandPlan *bp) {
     drop(bp->tile_row_all);
     drop(bp->hot_wg_off);
     drop(bp->groups);
+    drop(bp->spills);
+    drop(bp->wmask);
+    drop(bp->wbase);
     for (auto &kv : bp->scratch) {
         drop(kv.second.partial);
         drop(kv.second.carry);
         drop(kv.second.xp);
         drop(kv.second.pieces);
+        if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
+        if (kv.second.join) (void)hipEventDestroy(kv.second.join);
+        if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
     }
     delete bp;
 }
@@ -665,7 +751,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     const PTR *ip = (const PTR *)a->indptr;
     const IDX *ix = (const IDX *)a->indices;
     *out = nullptr;
-    if (rows >= 0xFFFFFFFFull || cols >= 0xFFFFFFFFull || !nnz) return SPRS_HIP_OK;
+    if (rows >= 0xFFFFFFFFull || cols >= 0x7FFFFFFFull || !nnz) return SPRS_HIP_OK;   // bit 31 of a label flags a row start
     const uint64_t split = (uint64_t)o.spmv_xcs_split;
 
     // ---- row classes --------------------------------------------------------------------
@@ -697,8 +783,10 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     bp->cols_pad = (cols + CB - 1) / CB * CB + CB;
     bp->n_long = (uint32_t)n_long;
     bp->n_short_rows = (uint32_t)n_short_rows;
-    bp->G = (uint32_t)(o.spmv_band_group > 0 ? o.spmv_band_group : 4);
-    uint64_t nh = o.spmv_band_hot > 0 ? (uint64_t)o.spmv_band_hot : 24;
+    bp->hot_threads = o.spmv_band_hot_threads == 512 ? 512u : 1024u;
+    bp->hot_block = bp->hot_threads / WAVE * WT;
+    bp->G = (uint32_t)(o.spmv_band_group > 0 ? o.spmv_band_group : (bp->hot_threads == 1024 ? 16 : 32));   // 16 blocks = 131 072 entries per x-tile load
+    uint64_t nh = o.spmv_band_hot > 0 ? (uint64_t)o.spmv_band_hot : 128;   // measured on R-MAT 10M: 48 .. 192 within 3 % (profiles/r02g, r02h)
     if (nh > (cols + CB - 1) / CB) nh = (cols + CB - 1) / CB;
     if (nh > (uint64_t)MAX_HOT) nh = MAX_HOT;
     uint64_t phases = o.spmv_band_phases > 0 ? (uint64_t)o.spmv_band_phases : 1;
@@ -732,14 +820,12 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     // long_rows is needed by the count kernel: fill it (and the short piece) first.  The short piece's arrays are
     // allocated below once the cold sizes are known, so the fill runs in two steps: rows first.
     // (bp_fill_short_kernel writes both; its s_* targets are allocated right here with the short sizes.)
-    TmpBuf s_rowidx_t, s_ptr_t, s_cid_t, s_val_t;
+    TmpBuf s_rowidx_t, s_ptr_t;
     SPRS_TRY_HIP(s_rowidx_t.alloc((n_short_rows + 1) * 4));
     SPRS_TRY_HIP(s_ptr_t.alloc((n_short_rows + 1) * 4));
-    SPRS_TRY_HIP(s_cid_t.alloc((nnz_short + 4) * 4));
-    SPRS_TRY_HIP(s_val_t.alloc((nnz_short + 2) * 8));
     hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
                        a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)s_rowidx_t.p,
-                       (uint32_t *)s_ptr_t.p, (uint32_t *)s_cid_t.p, (double *)s_val_t.p, bp->long_rows, split);
+                       (uint32_t *)s_ptr_t.p, (uint32_t *)nullptr, (double *)nullptr, bp->long_rows, split);
     SPRS_TRY_HIP(hipGetLastError());
     uint64_t wblocks = (n_long + 3) / 4;
     if (wblocks > 256 * 64) wblocks = 256 * 64;
@@ -758,7 +844,8 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     std::vector<PieceBuild> pb(NP);
     bp->host_pieces.assign(NP + 1, BandPiece());
     bp->carry_off.assign(NP + 2, 0);
-    uint64_t hot_tiles = 0, cold_ent = (nnz_short + 3) & ~3ull, ptr_off = 0, row_off = 0, tile_off = 0;
+    bp->pair_off.assign(NP + 1, 0);
+    uint64_t hot_tiles = 0, cold_ent = (nnz_short + WT - 1) / WT * WT, ptr_off = 0, row_off = 0, tile_off = 0;   // the short piece comes first
     std::vector<uint32_t> hot_wg_off(nh + 1, 0);
     uint32_t max_tiles = 0;
     for (uint32_t k = 0; k < NP; ++k) {
@@ -771,6 +858,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         b.x0 = k < nh ? k * CB : 0u;
         b.ptr_off = (uint32_t)ptr_off;
         b.row_off = (uint32_t)row_off;
+        bp->pair_off[k] = row_off;
         BandPiece &d = bp->host_pieces[k];
         d.nnz = b.nnz;
         d.nr = (uint32_t)nr;
@@ -781,11 +869,12 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
             d.ntiles = (uint32_t)((b.nnz + WT - 1) / WT);         // wave tiles
             b.ent0 = hot_tiles * HT;
             hot_tiles += nblocks;
-            hot_wg_off[k + 1] = hot_wg_off[k] + (uint32_t)((nblocks + bp->G - 1) / bp->G);
+            const uint64_t wg_blocks = (b.nnz + bp->hot_block - 1) / bp->hot_block;   // blocks of one workgroup iteration
+            hot_wg_off[k + 1] = hot_wg_off[k] + (uint32_t)((wg_blocks + bp->G - 1) / bp->G);
         } else {
-            d.ntiles = (uint32_t)((b.nnz + CT - 1) / CT);
+            d.ntiles = (uint32_t)((b.nnz + WT - 1) / WT);         // wave tiles; the piece is padded to whole tiles
             b.ent0 = cold_ent;
-            cold_ent = (cold_ent + b.nnz + 3) & ~3ull;
+            cold_ent += (uint64_t)d.ntiles * WT;
         }
         d.ent0 = b.ent0;
         bp->carry_off[k] = tile_off;     // carry slots and tile_row share the running tile count (+1 per piece for tile_row)
@@ -798,7 +887,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         BandPiece &d = bp->host_pieces[NP];
         d.nnz = nnz_short;
         d.nr = (uint32_t)n_short_rows;
-        d.ntiles = (uint32_t)((nnz_short + CT - 1) / CT);
+        d.ntiles = (uint32_t)((nnz_short + WT - 1) / WT);
         d.ent0 = 0;
         d.x0 = 0;
         d.to_y = 1;
@@ -818,18 +907,20 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     SPRS_TRY_HIP(hipMalloc((void **)&bp->cid_hot, (hot_entries + 8) * 2));
     SPRS_TRY_HIP(hipMemsetAsync(bp->vals_hot, 0, (hot_entries + 2) * 8, stream));
     SPRS_TRY_HIP(hipMemsetAsync(bp->cid_hot, 0, (hot_entries + 8) * 2, stream));
-    SPRS_TRY_HIP(hipMalloc((void **)&bp->vals_cold, (cold_ent + CT) * 8));     // a last partial tile is read element-wise, never past nnz
-    SPRS_TRY_HIP(hipMalloc((void **)&bp->cid_cold, (cold_ent + CT) * 4));
+    SPRS_TRY_HIP(hipMalloc((void **)&bp->vals_cold, (cold_ent + WT) * 8));
+    SPRS_TRY_HIP(hipMalloc((void **)&bp->cid_cold, (cold_ent + WT) * 4));
+    SPRS_TRY_HIP(hipMemsetAsync(bp->vals_cold, 0, (cold_ent + WT) * 8, stream));   // the padding of every piece reads as (label 0, value 0)
+    SPRS_TRY_HIP(hipMemsetAsync(bp->cid_cold, 0, (cold_ent + WT) * 4, stream));
     SPRS_TRY_HIP(hipMalloc((void **)&bp->ptr_all, (ptr_off + n_short_rows + 2) * 4));
     SPRS_TRY_HIP(hipMalloc((void **)&bp->rowidx_all, (row_off + n_short_rows + 1) * 4));
     SPRS_TRY_HIP(hipMalloc((void **)&bp->tile_row_all, (tile_off + 1) * 4));
-    bp->bytes = (hot_entries + 2) * 10 + (cold_ent + CT) * 12 + (ptr_off + row_off + 2 * n_short_rows + tile_off) * 4 +
+    bp->bytes = (hot_entries + 2) * 10 + (cold_ent + WT) * 12 + (ptr_off + row_off + 2 * n_short_rows + tile_off) * 4 +
                 cols * 4 + n_long * 4;
-    // short piece: move the temporaries into place (device-to-device)
-    if (nnz_short) {
-        SPRS_TRY_HIP(hipMemcpyAsync(bp->vals_cold, s_val_t.p, nnz_short * 8, hipMemcpyDeviceToDevice, stream));
-        SPRS_TRY_HIP(hipMemcpyAsync(bp->cid_cold, s_cid_t.p, nnz_short * 4, hipMemcpyDeviceToDevice, stream));
-    }
+    // short piece: its entries go straight into place (piece 0 of the cold arrays), its row lists are copied
+    hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
+                       a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)nullptr,
+                       (uint32_t *)nullptr, bp->cid_cold, bp->vals_cold, bp->long_rows, split);
+    SPRS_TRY_HIP(hipGetLastError());
     SPRS_TRY_HIP(hipMemcpyAsync(bp->ptr_all + ptr_off, s_ptr_t.p, (n_short_rows + 1) * 4, hipMemcpyDeviceToDevice, stream));
     if (n_short_rows)
         SPRS_TRY_HIP(hipMemcpyAsync(bp->rowidx_all + row_off, s_rowidx_t.p, n_short_rows * 4, hipMemcpyDeviceToDevice, stream));
@@ -844,6 +935,17 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
                        pair.u64(), n_long, NP, (const PieceBuild *)pb_d.p, bp->ptr_all, bp->rowidx_all);
     SPRS_TRY_HIP(hipGetLastError());
 
+    {   // ---- tables of the final reduction ---------------------------------------------------------------
+        const uint64_t nwb = (n_long + WAVE - 1) / WAVE;
+        bp->total_pairs = row_off;
+        SPRS_TRY_HIP(hipMalloc((void **)&bp->wmask, nwb * NP * 8));
+        SPRS_TRY_HIP(hipMalloc((void **)&bp->wbase, nwb * NP * 4));
+        const uint64_t waves = nwb * NP;
+        hipLaunchKernelGGL(bp_wave_tables_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, cnt.u64(), pair.u64(),
+                           n_long, NP, nwb, (const PieceBuild *)pb_d.p, bp->wmask, bp->wbase);
+        SPRS_TRY_HIP(hipGetLastError());
+        bp->bytes += nwb * NP * 12;
+    }
     // ---- device pointers of the pieces, tile -> first row tables ------------------------------------
     std::vector<TileRowJob> jobs(NP + 1);
     for (uint32_t k = 0; k <= NP; ++k) {
@@ -852,7 +954,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         d.ptr = bp->ptr_all + po;
         d.rowidx = bp->rowidx_all + ro;
         d.tile_row = bp->tile_row_all + bp->carry_off[k];
-        jobs[k] = TileRowJob{d.ptr, bp->tile_row_all + bp->carry_off[k], d.nr, d.ntiles, k < nh ? (uint32_t)WT : (uint32_t)CT};
+        jobs[k] = TileRowJob{d.ptr, bp->tile_row_all + bp->carry_off[k], d.nr, d.ntiles, (uint32_t)WT};
     }
     TmpBuf jobs_d;
     SPRS_TRY_HIP(jobs_d.alloc(jobs.size() * sizeof(TileRowJob)));
@@ -861,6 +963,34 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
                        (const TileRowJob *)jobs_d.p);
     SPRS_TRY_HIP(hipGetLastError());
 
+    // ---- rows that span tiles: one record each ----------------------------------------------------------
+    {
+        std::vector<SpillJob> sj(NP + 1);
+        for (uint32_t k = 0; k <= NP; ++k) {
+            const BandPiece &d = bp->host_pieces[k];
+            sj[k] = SpillJob{d.ptr, d.rowidx, d.tile_row, k < NP ? (uint64_t)pb[k].row_off : 0ull, d.ntiles,
+                             (uint32_t)WT, (uint32_t)bp->carry_off[k], k == NP ? 1u : 0u};
+        }
+        TmpBuf sj_d, cnt_d;
+        SPRS_TRY_HIP(sj_d.alloc(sj.size() * sizeof(SpillJob)));
+        SPRS_TRY_HIP(cnt_d.alloc(4));
+        SPRS_TRY_HIP(hipMemcpyAsync(sj_d.p, sj.data(), sj.size() * sizeof(SpillJob), hipMemcpyHostToDevice, stream));
+        SPRS_TRY_HIP(hipMemsetAsync(cnt_d.p, 0, 4, stream));
+        SPRS_TRY_HIP(hipMalloc(&bp->spills, (tile_off + 1) * sizeof(Spill)));     // at most one per tile
+        hipLaunchKernelGGL(bp_spill_kernel, dim3((max_tiles + 255) / 256, NP + 1), dim3(256), 0, stream,
+                           (const SpillJob *)sj_d.p, (Spill *)bp->spills, (unsigned int *)cnt_d.p);
+        SPRS_TRY_HIP(hipGetLastError());
+        SPRS_TRY_HIP(hipMemcpy(&bp->nspills, cnt_d.p, 4, hipMemcpyDeviceToHost));
+        // keep only what is used
+        if (bp->nspills < tile_off / 4) {
+            void *small = nullptr;
+            SPRS_TRY_HIP(hipMalloc(&small, ((uint64_t)bp->nspills + 1) * sizeof(Spill)));
+            SPRS_TRY_HIP(hipMemcpy(small, bp->spills, (uint64_t)bp->nspills * sizeof(Spill), hipMemcpyDeviceToDevice));
+            (void)hipFree(bp->spills);
+            bp->spills = small;
+        }
+        bp->bytes += ((uint64_t)bp->nspills + 1) * sizeof(Spill);
+    }
     // ---- launch tables -------------------------------------------------------------------------------
     SPRS_TRY_HIP(hipMalloc((void **)&bp->hot_wg_off, (nh + 1) * 4));
     SPRS_TRY_HIP(hipMemcpyAsync(bp->hot_wg_off, hot_wg_off.data(), (nh + 1) * 4, hipMemcpyHostToDevice, stream));
@@ -868,7 +998,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     uint32_t blocks = 0;
     for (uint32_t ph = 0; ph < phases; ++ph) {
         uint32_t mt = 0;
-        for (uint32_t s = 0; s < 8; ++s) mt = std::max(mt, bp->host_pieces[nh + ph * 8 + s].ntiles);
+        for (uint32_t s = 0; s < 8; ++s) mt = std::max(mt, (bp->host_pieces[nh + ph * 8 + s].ntiles + CNT / WAVE - 1) / (CNT / WAVE));
         if (!mt) continue;
         groups.push_back(ColdGroup{blocks, (uint32_t)(nh + ph * 8), 8});
         blocks += mt * 8;
@@ -876,7 +1006,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     if (bp->host_pieces[NP].ntiles) {
         bp->short_first_block = blocks;
         groups.push_back(ColdGroup{blocks, NP, 1});
-        blocks += bp->host_pieces[NP].ntiles;
+        blocks += (bp->host_pieces[NP].ntiles + CNT / WAVE - 1) / (CNT / WAVE);
     }
     bp->ngroups = (uint32_t)groups.size();
     bp->cold_blocks = blocks;
@@ -911,20 +1041,20 @@ int32_t band_scratch(BandPlan *bp, hipStream_t stream, BandScratch **out) {
     auto it = bp->scratch.find((void *)stream);
     if (it == bp->scratch.end()) {
         BandScratch sc;
-        const uint64_t pbytes = (uint64_t)bp->npieces * bp->n_long * 8;
-        SPRS_TRY_HIP(hipMalloc((void **)&sc.partial, pbytes ? pbytes : 8));
-        // rows without entries in a piece are never written by it: their partials must read as zero
-        SPRS_TRY_HIP(hipMemset(sc.partial, 0, pbytes ? pbytes : 8));
+        SPRS_TRY_HIP(hipMalloc((void **)&sc.partial, (bp->total_pairs + 1) * 8));   // every pair is written by every SpMV
         SPRS_TRY_HIP(hipMalloc((void **)&sc.carry, (bp->total_tiles + 1) * 8));
         SPRS_TRY_HIP(hipMalloc((void **)&sc.xp, bp->cols_pad * 8));
         SPRS_TRY_HIP(hipMemset(sc.xp, 0, bp->cols_pad * 8));      // the padding behind the last column is read into LDS
         std::vector<BandPiece> pcs = bp->host_pieces;
         for (uint32_t k = 0; k <= bp->npieces; ++k) {
             pcs[k].carry = sc.carry + bp->carry_off[k];
-            pcs[k].out = k < bp->npieces ? sc.partial + (uint64_t)k * bp->n_long : nullptr;
+            pcs[k].out = k < bp->npieces ? sc.partial + bp->pair_off[k] : nullptr;
         }
         SPRS_TRY_HIP(hipMalloc((void **)&sc.pieces, pcs.size() * sizeof(BandPiece)));
         SPRS_TRY_HIP(hipMemcpy(sc.pieces, pcs.data(), pcs.size() * sizeof(BandPiece), hipMemcpyHostToDevice));
+        SPRS_TRY_HIP(hipStreamCreateWithFlags(&sc.aux, hipStreamNonBlocking));
+        SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.fork, hipEventDisableTiming));
+        SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.join, hipEventDisableTiming));
         it = bp->scratch.emplace((void *)stream, sc).first;
     }
     *out = &it->second;
@@ -954,15 +1084,19 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         std::lock_guard<std::mutex> lock(a->mu);
         SPRS_TRY(band_scratch(bp, stream, &sc));
     }
-    hipLaunchKernelGGL(rl_permute_x_kernel, dim3((unsigned)((bp->cols + 255) / 256)), dim3(256), 0, stream, x, bp->perm,
-                       bp->cols, sc->xp);
+    // x into the plan's labelling; the same launch clears y (empty rows; the others are overwritten) unless accumulating
+    const uint64_t span = acc ? bp->cols : (bp->cols > a->rows ? bp->cols : a->rows);
+    hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, stream, x,
+                       (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows);
     SPRS_TRY_HIP(hipGetLastError());
-    if (!acc) SPRS_TRY_HIP(hipMemsetAsync(y, 0, a->rows * sizeof(double), stream));   // empty rows; the others are overwritten
-    if (bp->hot_wgs) {
-        hipLaunchKernelGGL(band_hot_kernel, dim3(bp->hot_wgs), dim3(HNT), 0, stream, (const BandPiece *)sc->pieces,
-                           (const uint32_t *)bp->hot_wg_off, bp->nh, bp->G, (const double *)bp->vals_hot,
-                           (const uint16_t *)bp->cid_hot, (const double *)sc->xp);
-        SPRS_TRY_HIP(hipGetLastError());
+    // Option spmv_band_overlap = 1: cold pieces + short rows on a second stream beside the hot slices.  Measured: the
+    // kernels do run concurrently, and the hot kernel slows down by exactly what the others take (1145 vs 1153 us per
+    // SpMV, profiles/r02h): off by default.
+    const bool overlap = options().spmv_band_overlap == 1 && bp->hot_wgs && bp->cold_blocks;
+    hipStream_t cstream = overlap ? sc->aux : stream;
+    if (overlap) {
+        SPRS_TRY_HIP(hipEventRecord(sc->fork, stream));           // xp (and the cleared y) are ready
+        SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux, sc->fork, 0));
     }
     if (bp->cold_blocks) {
         // one launch for the cold pieces and the short rows; option spmv_band_split_launch: two launches (profiling)
@@ -972,28 +1106,50 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         for (uint32_t part = 0; part < 2; ++part) {
             const uint32_t b0 = part ? cut : 0u, nb = part ? bp->cold_blocks - cut : cut;
             if (!nb) continue;
-            if (acc)
-                hipLaunchKernelGGL(band_cold_kernel<true>, dim3(nb), dim3(CNT), 0, stream, (const BandPiece *)sc->pieces,
-                                   (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,
-                                   (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, b0);
-            else
-                hipLaunchKernelGGL(band_cold_kernel<false>, dim3(nb), dim3(CNT), 0, stream, (const BandPiece *)sc->pieces,
-                                   (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,
-                                   (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, b0);
+#define SPRS_COLD(ACCV, POL)                                                                                              \
+    hipLaunchKernelGGL((band_cold_kernel<ACCV, POL>), dim3(nb), dim3(CNT), 0, cstream, (const BandPiece *)sc->pieces,          \
+                       (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,                             \
+                       (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, b0)
+            const int64_t pol = options().spmv_band_gather;
+            if (acc) {
+                if (pol == 1) SPRS_COLD(true, 1);
+                else if (pol == 2) SPRS_COLD(true, 2);
+                else SPRS_COLD(true, 0);
+            } else {
+                if (pol == 1) SPRS_COLD(false, 1);
+                else if (pol == 2) SPRS_COLD(false, 2);
+                else SPRS_COLD(false, 0);
+            }
+#undef SPRS_COLD
             SPRS_TRY_HIP(hipGetLastError());
         }
     }
-    if (bp->max_tiles > 1) {
-        hipLaunchKernelGGL(band_carry_kernel, dim3((bp->max_tiles + 255) / 256, bp->npieces + 1), dim3(256), 0, stream,
-                           (const BandPiece *)sc->pieces, bp->nh, y);
+    if (overlap) SPRS_TRY_HIP(hipEventRecord(sc->join, sc->aux));
+    if (bp->hot_wgs) {
+        if (bp->hot_threads == 1024)
+            hipLaunchKernelGGL(band_hot_kernel<1024>, dim3(bp->hot_wgs), dim3(1024), 0, stream, (const BandPiece *)sc->pieces,
+                               (const uint32_t *)bp->hot_wg_off, bp->nh, bp->G, (const double *)bp->vals_hot,
+                               (const uint16_t *)bp->cid_hot, (const double *)sc->xp);
+        else
+            hipLaunchKernelGGL(band_hot_kernel<512>, dim3(bp->hot_wgs), dim3(512), 0, stream, (const BandPiece *)sc->pieces,
+                               (const uint32_t *)bp->hot_wg_off, bp->nh, bp->G, (const double *)bp->vals_hot,
+                               (const uint16_t *)bp->cid_hot, (const double *)sc->xp);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    if (overlap) SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->join, 0));
+    if (bp->nspills) {
+        hipLaunchKernelGGL(band_carry_kernel, dim3((bp->nspills + 255) / 256), dim3(256), 0, stream, (const Spill *)bp->spills,
+                           bp->nspills, (const double *)sc->carry, sc->partial, y);
         SPRS_TRY_HIP(hipGetLastError());
     }
     const dim3 rg((bp->n_long + 255) / 256), rb(256);
     if (acc)
         hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, stream, (const double *)sc->partial,
+                           (const unsigned long long *)bp->wmask, (const uint32_t *)bp->wbase,
                            (const uint32_t *)bp->long_rows, y, bp->n_long, bp->npieces);
     else
         hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, stream, (const double *)sc->partial,
+                           (const unsigned long long *)bp->wmask, (const uint32_t *)bp->wbase,
                            (const uint32_t *)bp->long_rows, y, bp->n_long, bp->npieces);
     SPRS_TRY_HIP(hipGetLastError());
     return SPRS_HIP_OK;

@@ -103,7 +103,7 @@ static __global__ __launch_bounds__(256) void rl_rank_kernel(const uint32_t *__r
     }
 }
 
-static __global__ __launch_bounds__(256) void rl_permute_x_kernel(const double *__restrict__ x, const uint32_t *__restrict__ perm,
+[[maybe_unused]] static __global__ __launch_bounds__(256) void rl_permute_x_kernel(const double *__restrict__ x, const uint32_t *__restrict__ perm,
                                                            uint64_t cols, double *__restrict__ xp) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < cols) xp[perm[j]] = x[j];

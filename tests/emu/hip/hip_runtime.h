@@ -56,6 +56,15 @@ hipError_t hipGetDeviceCount(int *n);
 hipError_t hipGetDevice(int *d);
 hipError_t hipSetDevice(int d);
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b);
+struct hipemuEvent;
+typedef hipemuEvent *hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 }
 
 // ---- device side ------------------------------------------------------------------------------
@@ -157,6 +166,9 @@ inline void __threadfence_block() {}
 #define SPRS_LDS_BARRIER() hipemu::syncthreads()
 #define SPRS_WAIT_ALL() ((void)0)
 
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }

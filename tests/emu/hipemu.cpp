@@ -332,3 +332,23 @@ hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
     *total_b = (size_t)16 << 30;
     return hipSuccess;
 }
+
+// streams and events: everything runs synchronously in the emulator
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
+    *s = (hipStream_t)malloc(8);
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) {
+    free(s);
+    return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) {
+    *e = (hipEvent_t)malloc(8);
+    return hipSuccess;
+}
+hipError_t hipEventDestroy(hipEvent_t e) {
+    free(e);
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
