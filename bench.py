@@ -34,6 +34,16 @@ def algorithmic_bytes(rows, cols, nnz, idx_bytes, iptr_bytes, accumulate=False):
     return nnz * (8 + idx_bytes) + (rows + 1) * iptr_bytes + cols * 8 + rows * 8 * (2 if accumulate else 1)
 
 
+def csrc_sha16():
+    """hash of the kernel sources: ties a committed PMC measurement to the code it was taken on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "sprs_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "sprs_amd", "csrc", "*.hpp"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +63,10 @@ def main():
     ap.add_argument("--relabel", type=int, default=None, help="sliced plan column relabelling: 0 auto, 1 on, 2 off")
     ap.add_argument("--ldspad", type=int, default=None, help="extra dynamic LDS per workgroup (occupancy cap, tuning)")
     ap.add_argument("--xmask", type=int, default=None, help="timing experiment only: gather x[col & mask]")
+    ap.add_argument("--band", type=int, default=None, help="banded plan (hot columns from LDS): 0 auto, 1 on, 2 off")
+    ap.add_argument("--cold-cache", action="store_true",
+                    help="stream a 1 GiB scratch buffer between steps (outside the per-step kernel events): the matrix and x "
+                         "then come from HBM, not from the 256 MiB Infinity Cache (SURVEY 8d, config 2)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,7 +92,7 @@ def main():
     from sprs_amd import _ffi
     import ctypes as C
     _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
-    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_relabel", args.relabel), ("spmv_lds_pad", args.ldspad), ("spmv_xmask", args.xmask)):
+    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_relabel", args.relabel), ("spmv_lds_pad", args.ldspad), ("spmv_xmask", args.xmask), ("spmv_band", args.band)):
         if val is not None:
             sprs_amd.set_option(opt, val)
 
@@ -171,8 +185,11 @@ def main():
 
     # ---- timed region: exactly K steps ----------------------------------------
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    flush = torch.empty(1 << 27, dtype=torch.float64, device=dev) if args.cold_cache else None   # 1 GiB
     t_start = time.perf_counter()
     for s in range(args.steps):
+        if flush is not None:
+            flush.add_(1.0)   # reads and writes 1 GiB: evicts L2 and the Infinity Cache; part of ms_per_step, not of the kernel events
         ev[s][0].record(stream)
         sh.local_spmv(sh.block, x, sh.y[sh.r0:sh.r1])   # kernel(s) on `stream`, bracketed by HIP events
         ev[s][1].record(stream)
@@ -199,22 +216,22 @@ def main():
     # counter passes of the same command (scripts/gpu_pmc.sh -> profiles/pmc_traffic.json) and is
     # only filled in when workload, index width and options match that run.
     traffic = None
-    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.sort, args.tile, args.ldspad, args.xmask, args.relabel)) and not args.permute_cols
+    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.sort, args.tile, args.ldspad, args.xmask, args.relabel, args.band)) and not args.permute_cols
     try:
-        if world == 1 and defaults:
+        if world == 1 and defaults and not args.cold_cache:
+            sha = csrc_sha16()
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 for e in json.load(f)["entries"]:
-                    if e["workload"] == wl and e["index_bytes"] == args.idx_bytes:
+                    # only a measurement taken on exactly these kernel sources counts (stale numbers read as null)
+                    if e["workload"] == wl and e["index_bytes"] == args.idx_bytes and e.get("csrc_sha16") == sha:
                         traffic = e["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         traffic = None
-    if sprs_amd.get_option("spmv_kernel") == 2:
-        kernel_name = "sprs_hip::spmv_rowwave_kernel"
-    elif sprs_amd.get_option("spmv_xcs") == 2:
-        kernel_name = "sprs_hip::spmv_tile_kernel (+ spmv_carry_kernel)"
-    else:
-        kernel_name = ("sprs_hip::spmv_sliced_kernel + spmv_tile_kernel (short rows) + carry/reduce kernels "
-                       "of one SpMV when the XCD-sliced plan applies, else spmv_tile_kernel")
+    plan_kind, plan_bytes = handles[id(sh.block)].spmv_plan_info() if handles else (0, 0)
+    kernel_name = {3: "all kernels of one SpMV on the banded plan: band_permute + band_hot (x tile in LDS) + band_cold "
+                      "(cold pieces, short rows) + band_carry + band_reduce",
+                   2: "all kernels of one SpMV on the XCD-sliced plan: rl_permute_x + spmv_tile (short rows) + spmv_sliced + carry / reduce kernels",
+                   1: "sprs_hip::spmv_tile_kernel (+ spmv_carry_kernel)"}.get(plan_kind, "sprs_hip::spmv_rowwave_kernel")
     out = {
         "metric": "CSR SpMV GFLOP/s",
         "value": round(gflops, 3),
@@ -245,7 +262,11 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms_avg": round(kern_avg_ms, 5),
             "kernel_ms_min": round(float(np.min(kern_ms)), 5),
-            "traffic": traffic,   # HBM bytes per SpMV from committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or null
+            "traffic": traffic,   # HBM bytes per SpMV from the committed rocprofv3 --pmc passes of THESE kernel sources
+                                  # (profiles/pmc_traffic.json, matched by csrc_sha16), else null
+            "plan": {1: "nnz tiles", 2: "xcd-sliced copy", 3: "banded copy (hot columns from LDS)"}.get(plan_kind, "none"),
+            "plan_bytes": plan_bytes,
+            "cold_cache": bool(args.cold_cache),
         },
     }
 

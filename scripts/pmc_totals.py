@@ -5,13 +5,17 @@ counter means.  HBM traffic estimate per SpMV:
    read  = FETCH_SIZE [KiB] * 1024 * 2   (gfx950: requests are up to 128 B but tallied as 64 B —
                                          MI355X_MICROARCH.md, HBM section; upper estimate for gathers)
    write = WRITE_SIZE [KiB] * 1024
-usage: pmc_totals.py <pmc_summary.txt> [out.json]"""
+usage: pmc_totals.py <pmc_summary.txt> [out.json]
+       pmc_totals.py <pmc_summary.txt> --update profiles/pmc_traffic.json <workload> <index_bytes> "<plan description>"
+       (the second form replaces the entry of that workload / index width; the summary's "csrc_sha16:" line, written by
+       scripts/gpu_pmc.sh on the GPU box, ties the numbers to the kernel sources they were measured on)"""
 import json
 import re
 import sys
 
 PER_SPMV = ("spmv_tile_kernel", "spmv_sliced_kernel", "spmv_carry_kernel", "spmv_sliced_carry_kernel",
-            "xcs_reduce_kernel", "spmv_rowwave_kernel", "rl_permute_x_kernel")
+            "xcs_reduce_kernel", "spmv_rowwave_kernel", "rl_permute_x_kernel",
+            "band_permute_kernel", "band_hot_kernel", "band_cold_kernel", "band_carry_kernel", "band_reduce_kernel")
 
 
 def main():
@@ -22,7 +26,7 @@ def main():
             continue
         parts = line.split()
         name = parts[0]
-        kern = re.sub(r"[<(].*", "", name.replace("sprs_hip::", ""))
+        kern = re.sub(r"[<(].*", "", line.replace("sprs_hip::", "").replace("(anonymous namespace)::", "").split()[0])
         if kern not in PER_SPMV:
             continue
         counter, n, mean = parts[-5], int(parts[-4]), float(parts[-3])
@@ -40,7 +44,20 @@ def main():
     if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
         out["traffic_bytes_est"] = out["hbm_read_bytes_est"] + out["hbm_write_bytes_est"]
     s = json.dumps(out, indent=1, sort_keys=True)
-    if len(sys.argv) > 2:
+    if len(sys.argv) > 3 and sys.argv[2] == "--update":
+        path, wl, ib, plan = sys.argv[3], sys.argv[4], int(sys.argv[5]), sys.argv[6]
+        sha = None
+        for line in open(sys.argv[1]):
+            if line.startswith("csrc_sha16:"):
+                sha = line.split()[1]
+        doc = json.load(open(path))
+        doc["entries"] = [e for e in doc["entries"] if not (e["workload"] == wl and e["index_bytes"] == ib)]
+        doc["entries"].insert(0, {"workload": wl, "index_bytes": ib, "plan": plan, "csrc_sha16": sha,
+                                  "traffic_bytes": out.get("traffic_bytes_est"), "read_bytes": out.get("hbm_read_bytes_est"),
+                                  "write_bytes": out.get("hbm_write_bytes_est"), "counters": tot,
+                                  "per_kernel": out["per_kernel"]})
+        open(path, "w").write(json.dumps(doc, indent=1) + "\n")
+    elif len(sys.argv) > 2:
         open(sys.argv[2], "w").write(s + "\n")
     print(s)
 

@@ -700,6 +700,15 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "spmv_band_overlap")) {
         if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_overlap must be 0, 1 or 2");
         o.spmv_band_overlap = value;
+    } else if (!strcmp(name, "spmv_band_short")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_short must be 0, 1 or 2");
+        o.spmv_band_short = value;
+    } else if (!strcmp(name, "spmv_band_short_group")) {
+        if (value < 0 || value > 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_short_group must be in 0..1024");
+        o.spmv_band_short_group = value;
+    } else if (!strcmp(name, "spmv_band_split")) {
+        if (value < 0 || value == 1) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_split must be 0 (default) or >= 2");
+        o.spmv_band_split = value;
     } else if (!strcmp(name, "spmv_band_split_launch")) {
         o.spmv_band_split_launch = value ? 1 : 0;
     } else if (!strcmp(name, "spmv_band_group")) {
@@ -737,6 +746,9 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_band_phases")) *value = o.spmv_band_phases;
     else if (!strcmp(name, "spmv_band_group")) *value = o.spmv_band_group;
     else if (!strcmp(name, "spmv_band_split_launch")) *value = o.spmv_band_split_launch;
+    else if (!strcmp(name, "spmv_band_split")) *value = o.spmv_band_split;
+    else if (!strcmp(name, "spmv_band_short_group")) *value = o.spmv_band_short_group;
+    else if (!strcmp(name, "spmv_band_short")) *value = o.spmv_band_short;
     else if (!strcmp(name, "spmv_band_overlap")) *value = o.spmv_band_overlap;
     else if (!strcmp(name, "spmv_band_hot_threads")) *value = o.spmv_band_hot_threads;
     else if (!strcmp(name, "spmv_band_gather")) *value = o.spmv_band_gather;

@@ -104,11 +104,18 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // NTH threads = NTH / 64 waves per workgroup; a workgroup advances NTH / 64 wave tiles ("a block") per iteration.
 // 1024 threads: one workgroup per CU; 512: two, so that the x-tile load of one overlaps the streaming of the other.
-template <int NTH>
+// WIDE = false: a hot slice (16-bit local ids, every entry's x comes from the LDS tile, partial sums out).
+// WIDE = true:  the short-rows piece run the same way (one "slice" whose x tile holds the 8192 most referenced
+//               labels): 32-bit labels laid out as for band_cold_kernel; an entry whose label lies in the tile reads
+//               LDS, the others gather from xp; sums go to y[rowidx[...]].  On R-MAT 10M about a third of the short
+//               rows' entries hit the tile — a third fewer 128-byte line fills, which is what bounds the gathers
+//               (141 G lines/s = 16 channels x 64 B/clk per XCD; profiles/r02f-j).
+template <int NTH, bool WIDE, bool ACC>
 __global__ __launch_bounds__(NTH) void band_hot_kernel(const BandPiece *__restrict__ pieces,
                                                        const uint32_t *__restrict__ wg_off, uint32_t nh, uint32_t G,
-                                                       const double *__restrict__ vals, const uint16_t *__restrict__ cid,
-                                                       const double *__restrict__ xp) {
+                                                       const double *__restrict__ vals, const void *__restrict__ cid_any,
+                                                       const double *__restrict__ xp, double *__restrict__ y) {
+    const uint16_t *cid = (const uint16_t *)cid_any;            // WIDE: const uint32_t *
     __shared__ __attribute__((aligned(16))) double xs[CB];
     constexpr int WPB = NTH / WAVE;               // wave tiles per block = waves per workgroup
     __shared__ __attribute__((aligned(16))) double stage_s[WPB][WT];   // sums of the rows starting in the wave's tile
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(NTH) void band_hot_kernel(const BandPiece *__restri
 
     // pipeline registers: the next tile of this wave (stream in flight), tile_row of the one after
     dbl2 av[WPASS];
-    u32x4 cw;
+    u32x4 cw, cw2;
     uint32_t R0n = 0, R0nn = 0;
     auto tile_of = [&](uint32_t it) { return (b0 + it) * (uint32_t)WPB + wave; };
     auto request_row = [&](uint32_t w) { return d.tile_row[w < nwt ? w : nwt - 1]; };   // past the slice: harmless reload
@@ -140,7 +147,13 @@ __global__ __launch_bounds__(NTH) void band_hot_kernel(const BandPiece *__restri
         const uint64_t g = d.ent0 + (uint64_t)(w < nwt ? w : nwt - 1) * WT;
 #pragma unroll
         for (int p = 0; p < WPASS; ++p) av[p] = __builtin_nontemporal_load((const dbl2 *)(vals + g + p * (WAVE * 2) + lane * 2));
-        cw = __builtin_nontemporal_load((const u32x4 *)(cid + g + lane * EPL));
+        if constexpr (WIDE) {
+            const uint32_t *c32 = (const uint32_t *)cid_any;
+            cw = __builtin_nontemporal_load((const u32x4 *)(c32 + g + lane * 4));
+            cw2 = __builtin_nontemporal_load((const u32x4 *)(c32 + g + WAVE * 4 + lane * 4));
+        } else {
+            cw = __builtin_nontemporal_load((const u32x4 *)(cid + g + lane * EPL));
+        }
     };
     if (tile_of(0) < nwt) {                                      // (nwt > 0 for every launched workgroup)
         R0n = request_row(tile_of(0));
@@ -156,14 +169,27 @@ __global__ __launch_bounds__(NTH) void band_hot_kernel(const BandPiece *__restri
         // ---- products of the lane's 8 consecutive entries, row-start flags ---------------------------
         double pr[EPL];
         uint32_t fb = 0;
+        if constexpr (WIDE) {
+            double xv[EPL];
 #pragma unroll
-        for (int p = 0; p < WPASS; ++p) {
-            const uint32_t c2 = cw[p];
-            const uint32_t i0 = lane * EPL + 2 * p;
-            pr[2 * p] = i0 < cnt ? av[p][0] * xs[c2 & (CB - 1)] : 0.0;
-            pr[2 * p + 1] = i0 + 1 < cnt ? av[p][1] * xs[(c2 >> 16) & (CB - 1)] : 0.0;
-            fb |= ((c2 >> 15) & 1u) << (2 * p);
-            fb |= ((c2 >> 31) & 1u) << (2 * p + 1);
+            for (int q = 0; q < EPL; ++q) {
+                const uint32_t c = q < 4 ? cw[q % 4] : cw2[q % 4];
+                const uint32_t lab = c & 0x7FFFFFFFu;
+                xv[q] = lab < (uint32_t)CB ? xs[lab] : xp[lab];
+                fb |= (c >> 31) << q;
+            }
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) pr[q] = lane * EPL + q < cnt ? av[q / 2][q % 2] * xv[q] : 0.0;
+        } else {
+#pragma unroll
+            for (int p = 0; p < WPASS; ++p) {
+                const uint32_t c2 = cw[p];
+                const uint32_t i0 = lane * EPL + 2 * p;
+                pr[2 * p] = i0 < cnt ? av[p][0] * xs[c2 & (CB - 1)] : 0.0;
+                pr[2 * p + 1] = i0 + 1 < cnt ? av[p][1] * xs[(c2 >> 16) & (CB - 1)] : 0.0;
+                fb |= ((c2 >> 15) & 1u) << (2 * p);
+                fb |= ((c2 >> 31) & 1u) << (2 * p + 1);
+            }
         }
         const uint32_t R0 = R0n;                                 // first compact row starting in this tile
         // ---- requests for the next tile of this wave ----------------------------------------------------
@@ -217,7 +243,15 @@ __global__ __launch_bounds__(NTH) void band_hot_kernel(const BandPiece *__restri
             else stage[nf - 1] = S;                              // partial sum of the last row starting here
         }
         wave_lds_fence();                                        // stage[0 .. nf) complete
-        for (uint32_t j = lane; j < nf; j += WAVE) d.out[R0 + j] = stage[j];   // coalesced: compact rows R0 .. R0 + nf - 1
+        if constexpr (WIDE) {
+            for (uint32_t j = lane; j < nf; j += WAVE) {
+                const uint32_t r = d.rowidx[R0 + j];
+                if constexpr (ACC) y[r] = y[r] + stage[j];       // every compact row has entries: empty rows are never touched (prod.rs:120-126)
+                else y[r] = stage[j];
+            }
+        } else {
+            for (uint32_t j = lane; j < nf; j += WAVE) d.out[R0 + j] = stage[j];   // coalesced: compact rows R0 .. R0 + nf - 1
+        }
         wave_lds_fence();                                        // read before the next tile overwrites it
     }
 }
@@ -354,12 +388,33 @@ __global__ __launch_bounds__(256) void band_carry_kernel(const Spill *__restrict
                                                          const double *__restrict__ carry, double *__restrict__ partial,
                                                          double *__restrict__ y) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nspills) return;
-    const Spill sp = spills[r];
-    double acc = 0.0;
-    for (uint32_t i = 0; i < sp.n; ++i) acc += carry[sp.first + i];
-    double *out = sp.to_y ? y : partial;
-    out[sp.out] += acc;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const bool valid = r < nspills;
+    Spill sp = Spill{0, 0, 0, 0, 0};
+    if (valid) sp = spills[r];
+    // a short chain (nearly all: a row crossing one tile boundary) is added by its own thread ...
+    const bool small = sp.n <= 8;
+    if (valid && small) {
+        double acc = 0.0;
+        for (uint32_t i = 0; i < sp.n; ++i) acc += carry[sp.first + i];
+        double *out = sp.to_y ? y : partial;
+        out[sp.out] += acc;
+    }
+    // ... a long one (a hub row: hundreds of tiles) by the whole wave, lanes striding over it (fixed order)
+    unsigned long long m = __ballot(valid && !small);
+    while (m) {                                                  // wave-uniform
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint32_t first = (uint32_t)__shfl((int)sp.first, b, WAVE), n = (uint32_t)__shfl((int)sp.n, b, WAVE);
+        double acc = 0.0;
+        for (uint32_t i = lane; i < n; i += WAVE) acc += carry[first + i];
+        acc = wave_sum(acc);                                     // complete in lane 0
+        const double tot = __shfl(acc, 0, WAVE);
+        if (lane == (uint32_t)b) {
+            double *out = sp.to_y ? y : partial;
+            out[sp.out] += tot;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void band_permute_kernel(const double *__restrict__ x, const uint32_t *__restrict__ perm,
@@ -370,48 +425,76 @@ __global__ __launch_bounds__(256) void band_permute_kernel(const double *__restr
     if (y_zero && j < rows) y_zero[j] = 0.0;
 }
 
-// y[long_rows[j]] (+)= sum of the row's partials, in piece order.  One wave per 64 consecutive long rows: for
-// piece k, wmask tells which of the 64 rows have a partial there and wbase where the first of them sits; the
-// present rows' partials follow each other in memory, so the loads of a wave are contiguous.
+// y[long_rows[j]] (+)= sum of the row's partials.  One WORKGROUP per 64 consecutive long rows; its eight waves
+// take the pieces k = q, q + 8, q + 16, ... (q = wave) and the eight sums are added in wave order: a fixed
+// summation order, deterministic.  For piece k, wmask tells which of the 64 rows have a partial there and
+// wbase where the first of them sits; the present rows' partials follow each other in memory, so the loads
+// of a wave are contiguous.  Measured on R-MAT 10M (50 M partials, 128 hot slices): 140 us whatever the shape of the
+// loop — one wave per row block, four or eight waves, 16 .. 36 loads in flight, eight row blocks per workgroup with
+// the next tables prefetched (156 us) — because it is HBM-bound: 5.7 M L2 misses = 0.73 GB for 0.40 GB of
+// partials, at the same ~41 G misses/s the streaming kernels reach (profiles/r02i .. r02o).
+constexpr int RNW = 4;       // waves per row block in the reduction
+// Table slot of piece k for row block wb: the pieces of wave q (k = q, q + RNW, ...) are stored next to each other.
+__host__ __device__ __forceinline__ uint64_t reduce_slot(uint64_t wb, uint32_t k, uint32_t npieces) {
+    const uint32_t nqmax = (npieces + RNW - 1) / RNW;
+    return wb * ((uint64_t)nqmax * RNW) + (uint64_t)(k % RNW) * nqmax + k / RNW;
+}
+
 template <bool ACC>
-__global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restrict__ partial,
+__global__ __launch_bounds__(RNW * WAVE) void band_reduce_kernel(const double *__restrict__ partial,
                                                           const unsigned long long *__restrict__ wmask,
                                                           const uint32_t *__restrict__ wbase,
                                                           const uint32_t *__restrict__ long_rows, double *__restrict__ y,
-                                                          uint32_t n_long, uint32_t npieces) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+                                                          uint32_t n_long, uint32_t npieces, uint32_t amask) {
+    constexpr int NW = RNW;
+    __shared__ double red[NW][WAVE];
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    const uint64_t wb = j / WAVE;
+    const uint32_t q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));   // wave-uniform, kept in a scalar register
+    // Block b runs on XCD b % 8 (observed; only speed depends on it): give every XCD a CONTIGUOUS range of row blocks
+    // (neighbouring row blocks read neighbouring partials of every piece, often the same 128-byte line).
+    const uint64_t nb = gridDim.x, qq = nb >> 3, rem = nb & 7, xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const uint64_t wb = xcd * qq + (xcd < rem ? xcd : rem) + jj;
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (wb * WAVE >= n_long) return;                            // wave-uniform: no table entries past the last row block
+    const uint32_t nqmax = (npieces + NW - 1) / NW;
+    const uint32_t nq = npieces > q ? (npieces - q + NW - 1) / NW : 0u;     // pieces of this wave: k = q + NW i, i < nq
+    const uint64_t j = wb * WAVE + lane;
+    const uint32_t r = long_rows[j < n_long ? j : n_long - 1];  // (requested early, unconditionally: needed only at the very end)
+    // The wave's table rows are contiguous: ONE coalesced load puts the rows of 64 pieces into the lanes (lane l: piece
+    // i0 + l), scalar broadcasts hand them out.  (Indexing the tables with the wave-uniform piece number compiles to one
+    // scalar load plus a wait PER PIECE: a chain of 72 round trips.)
+    const unsigned long long *mrow = wmask + wb * ((uint64_t)nqmax * NW) + (uint64_t)q * nqmax;
+    const uint32_t *brow = wbase + wb * ((uint64_t)nqmax * NW) + (uint64_t)q * nqmax;
     double s = 0.0;
-    for (uint32_t k0 = 0; k0 < npieces; k0 += WAVE) {
-        // the table rows of 64 pieces in one coalesced load: lane l holds piece k0 + l
-        const bool in = k0 + lane < npieces;
-        const unsigned long long mk = in ? wmask[wb * npieces + k0 + lane] : 0ull;
-        const uint32_t bs = in ? wbase[wb * npieces + k0 + lane] : 0u;
-        const uint32_t nk = npieces - k0 < (uint32_t)WAVE ? npieces - k0 : (uint32_t)WAVE;
-        constexpr int U = 32;                                   // partials in flight per lane (the loop is latency bound)
+    constexpr int U = 36;                                       // partials in flight per lane: one chunk up to 144 pieces
+    for (uint32_t i0 = 0; i0 < nq; i0 += WAVE) {
+        const bool in = i0 + lane < nq;
+        const unsigned long long mk = in ? mrow[i0 + lane] : 0ull;
+        const uint32_t bs = in ? brow[i0 + lane] : 0u;
+        const uint32_t nk = nq - i0 < (uint32_t)WAVE ? nq - i0 : (uint32_t)WAVE;
         for (uint32_t kk = 0; kk < nk; kk += U) {
             double v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int src = (int)(kk + u < nk ? kk + u : nk - 1);                          // wave-uniform
-                // (src is wave-uniform: scalar broadcasts, no LDS traffic)
                 const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mk >> 32), src) << 32) |
                                              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, src);
                 const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bs, src);
                 const bool have = kk + u < nk && ((m >> lane) & 1ull);
-                v[u] = have ? partial[b + (uint32_t)__popcll(m & below)] : 0.0;
+                v[u] = have ? partial[(b + (uint32_t)__popcll(m & below)) & amask] : 0.0;   // amask: all ones (timing experiments: see spmv_xmask)
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) s += v[u];              // piece order (absent pieces add +0.0)
+            for (int u = 0; u < U; ++u) s += v[u];              // ascending pieces (absent ones add +0.0)
         }
     }
+    red[q][lane] = s;
+    __syncthreads();
+    if (q != 0) return;
     if (j >= n_long) return;
-    const uint32_t r = long_rows[j];
-    if constexpr (ACC) y[r] = y[r] + s;
-    else y[r] = s;
+    double tot = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) tot += red[w][lane];
+    if constexpr (ACC) y[r] = y[r] + tot;
+    else y[r] = tot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -619,8 +702,9 @@ __global__ __launch_bounds__(256) void bp_wave_tables_kernel(const uint64_t *__r
     const bool have = j < n_long && cnt[(uint64_t)k * n_long + j] != 0;
     const unsigned long long m = __ballot(have);
     if (lane == 0) {
-        wmask[wid] = m;
-        wbase[wid] = pb[k].row_off + (uint32_t)(pair[(uint64_t)k * n_long + wb * WAVE] - pb[k].pair0);
+        const uint64_t slot = reduce_slot(wb, k, npieces);
+        wmask[slot] = m;
+        wbase[slot] = pb[k].row_off + (uint32_t)(pair[(uint64_t)k * n_long + wb * WAVE] - pb[k].pair0);
     }
 }
 
@@ -699,6 +783,9 @@ struct BandPlan {
     void *spills = nullptr;                        // Spill records (device)
     uint32_t nspills = 0;
     uint32_t ngroups = 0, hot_wgs = 0, cold_blocks = 0, max_tiles = 0, short_first_block = 0;
+    bool has_short_group = false;
+    uint32_t short_wgs = 0, Gs = 4;                // workgroups of the tiled short-rows launch, blocks per workgroup
+    uint32_t *short_wg_off = nullptr;              // {0, short_wgs}
     uint64_t total_tiles = 0;
     std::vector<BandPiece> host_pieces;            // carry / out filled per scratch
     std::vector<uint64_t> carry_off, pair_off;
@@ -721,6 +808,7 @@ void band_free(BandPlan *bp) {
     drop(bp->rowidx_all);
     drop(bp->tile_row_all);
     drop(bp->hot_wg_off);
+    drop(bp->short_wg_off);
     drop(bp->groups);
     drop(bp->spills);
     drop(bp->wmask);
@@ -752,7 +840,8 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     const IDX *ix = (const IDX *)a->indices;
     *out = nullptr;
     if (rows >= 0xFFFFFFFFull || cols >= 0x7FFFFFFFull || !nnz) return SPRS_HIP_OK;   // bit 31 of a label flags a row start
-    const uint64_t split = (uint64_t)o.spmv_xcs_split;
+    // rows with at least this many entries are "long" (cut into pieces); 24 measured best with 128 hot slices (r02h, r02o)
+    const uint64_t split = o.spmv_band_split > 0 ? (uint64_t)o.spmv_band_split : 24ull;
 
     // ---- row classes --------------------------------------------------------------------
     TmpBuf short_flag, short_len, long_flag, short_pos, short_ptr, long_pos;
@@ -938,8 +1027,11 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     {   // ---- tables of the final reduction ---------------------------------------------------------------
         const uint64_t nwb = (n_long + WAVE - 1) / WAVE;
         bp->total_pairs = row_off;
-        SPRS_TRY_HIP(hipMalloc((void **)&bp->wmask, nwb * NP * 8));
-        SPRS_TRY_HIP(hipMalloc((void **)&bp->wbase, nwb * NP * 4));
+        const uint64_t slots = nwb * (uint64_t)((NP + RNW - 1) / RNW) * RNW;     // (padded: reduce_slot)
+        SPRS_TRY_HIP(hipMalloc((void **)&bp->wmask, slots * 8));
+        SPRS_TRY_HIP(hipMalloc((void **)&bp->wbase, slots * 4));
+        SPRS_TRY_HIP(hipMemsetAsync(bp->wmask, 0, slots * 8, stream));
+        SPRS_TRY_HIP(hipMemsetAsync(bp->wbase, 0, slots * 4, stream));
         const uint64_t waves = nwb * NP;
         hipLaunchKernelGGL(bp_wave_tables_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, cnt.u64(), pair.u64(),
                            n_long, NP, nwb, (const PieceBuild *)pb_d.p, bp->wmask, bp->wbase);
@@ -1005,11 +1097,21 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     }
     if (bp->host_pieces[NP].ntiles) {
         bp->short_first_block = blocks;
+        bp->has_short_group = true;
         groups.push_back(ColdGroup{blocks, NP, 1});
         blocks += (bp->host_pieces[NP].ntiles + CNT / WAVE - 1) / (CNT / WAVE);
     }
     bp->ngroups = (uint32_t)groups.size();
     bp->cold_blocks = blocks;
+    {   // tiled launch of the short rows: blocks of 16 wave tiles, G blocks per workgroup
+        const uint64_t sblocks = (nnz_short + HT - 1) / HT;
+        bp->Gs = (uint32_t)(o.spmv_band_short_group > 0 ? o.spmv_band_short_group : 4);
+        bp->short_wgs = (uint32_t)((sblocks + bp->Gs - 1) / bp->Gs);
+        const uint32_t tab[2] = {0u, bp->short_wgs};
+        SPRS_TRY_HIP(hipMalloc((void **)&bp->short_wg_off, sizeof tab));
+        SPRS_TRY_HIP(hipMemcpyAsync(bp->short_wg_off, tab, sizeof tab, hipMemcpyHostToDevice, stream));
+        SPRS_TRY_HIP(hipStreamSynchronize(stream));      // tab lives on this stack frame
+    }
     if (bp->ngroups) {
         SPRS_TRY_HIP(hipMalloc((void **)&bp->groups, groups.size() * sizeof(ColdGroup)));
         SPRS_TRY_HIP(hipMemcpyAsync(bp->groups, groups.data(), groups.size() * sizeof(ColdGroup), hipMemcpyHostToDevice, stream));
@@ -1089,22 +1191,25 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, stream, x,
                        (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows);
     SPRS_TRY_HIP(hipGetLastError());
-    // Option spmv_band_overlap = 1: cold pieces + short rows on a second stream beside the hot slices.  Measured: the
-    // kernels do run concurrently, and the hot kernel slows down by exactly what the others take (1145 vs 1153 us per
-    // SpMV, profiles/r02h): off by default.
-    const bool overlap = options().spmv_band_overlap == 1 && bp->hot_wgs && bp->cold_blocks;
+    // The gather-bound launch (cold pieces + short rows: L2 -> L1 line fills) runs on a second stream beside the
+    // HBM-bound hot slices (option spmv_band_overlap, 2 = off).  The two kernels do run concurrently and mostly trade
+    // time one for one (1145 vs 1153 us, profiles/r02h), but the gather workgroups fill the start-up and tail bubbles
+    // of the one-workgroup-per-CU hot kernel: 1.12 vs 1.16 ms per SpMV over repeated A/B runs (profiles/r02j, r02l).
+    const bool overlap = options().spmv_band_overlap != 2 && bp->hot_wgs && bp->cold_blocks;
     hipStream_t cstream = overlap ? sc->aux : stream;
     if (overlap) {
         SPRS_TRY_HIP(hipEventRecord(sc->fork, stream));           // xp (and the cleared y) are ready
         SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux, sc->fork, 0));
     }
+    // the short rows: with the hottest x entries in LDS (band_hot_kernel<.., true, ..>, default) or as one more gather piece
+    const bool short_tiled = options().spmv_band_short == 1 && bp->short_wgs != 0;   // measured slower than the gather piece (profiles/r02k, r02l): opt-in
     if (bp->cold_blocks) {
-        // one launch for the cold pieces and the short rows; option spmv_band_split_launch: two launches (profiling)
-        uint32_t cut = bp->cold_blocks;
-        if (options().spmv_band_split_launch && bp->short_first_block && bp->short_first_block < bp->cold_blocks)
-            cut = bp->short_first_block;
+        // one launch for the cold pieces (and the short rows when they are not tiled); option spmv_band_split_launch: two launches (profiling)
+        uint32_t cut = bp->cold_blocks, end = bp->cold_blocks;
+        if ((short_tiled || options().spmv_band_split_launch) && bp->has_short_group) cut = bp->short_first_block;
+        if (short_tiled && bp->has_short_group) end = bp->short_first_block;
         for (uint32_t part = 0; part < 2; ++part) {
-            const uint32_t b0 = part ? cut : 0u, nb = part ? bp->cold_blocks - cut : cut;
+            const uint32_t b0 = part ? cut : 0u, nb = part ? end - cut : cut;
             if (!nb) continue;
 #define SPRS_COLD(ACCV, POL)                                                                                              \
     hipLaunchKernelGGL((band_cold_kernel<ACCV, POL>), dim3(nb), dim3(CNT), 0, cstream, (const BandPiece *)sc->pieces,          \
@@ -1127,13 +1232,26 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     if (overlap) SPRS_TRY_HIP(hipEventRecord(sc->join, sc->aux));
     if (bp->hot_wgs) {
         if (bp->hot_threads == 1024)
-            hipLaunchKernelGGL(band_hot_kernel<1024>, dim3(bp->hot_wgs), dim3(1024), 0, stream, (const BandPiece *)sc->pieces,
-                               (const uint32_t *)bp->hot_wg_off, bp->nh, bp->G, (const double *)bp->vals_hot,
-                               (const uint16_t *)bp->cid_hot, (const double *)sc->xp);
+            hipLaunchKernelGGL((band_hot_kernel<1024, false, false>), dim3(bp->hot_wgs), dim3(1024), 0, stream,
+                               (const BandPiece *)sc->pieces, (const uint32_t *)bp->hot_wg_off, bp->nh, bp->G,
+                               (const double *)bp->vals_hot, (const void *)bp->cid_hot, (const double *)sc->xp, y);
         else
-            hipLaunchKernelGGL(band_hot_kernel<512>, dim3(bp->hot_wgs), dim3(512), 0, stream, (const BandPiece *)sc->pieces,
-                               (const uint32_t *)bp->hot_wg_off, bp->nh, bp->G, (const double *)bp->vals_hot,
-                               (const uint16_t *)bp->cid_hot, (const double *)sc->xp);
+            hipLaunchKernelGGL((band_hot_kernel<512, false, false>), dim3(bp->hot_wgs), dim3(512), 0, stream,
+                               (const BandPiece *)sc->pieces, (const uint32_t *)bp->hot_wg_off, bp->nh, bp->G,
+                               (const double *)bp->vals_hot, (const void *)bp->cid_hot, (const double *)sc->xp, y);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    if (short_tiled) {
+        // the short rows with the 8192 hottest x entries in LDS: pieces + npieces = the short piece, a table of one "slice"
+        const BandPiece *sp = (const BandPiece *)sc->pieces + bp->npieces;
+        if (acc)
+            hipLaunchKernelGGL((band_hot_kernel<1024, true, true>), dim3(bp->short_wgs), dim3(1024), 0, stream, sp,
+                               (const uint32_t *)bp->short_wg_off, 1u, bp->Gs, (const double *)bp->vals_cold,
+                               (const void *)bp->cid_cold, (const double *)sc->xp, y);
+        else
+            hipLaunchKernelGGL((band_hot_kernel<1024, true, false>), dim3(bp->short_wgs), dim3(1024), 0, stream, sp,
+                               (const uint32_t *)bp->short_wg_off, 1u, bp->Gs, (const double *)bp->vals_cold,
+                               (const void *)bp->cid_cold, (const double *)sc->xp, y);
         SPRS_TRY_HIP(hipGetLastError());
     }
     if (overlap) SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->join, 0));
@@ -1142,15 +1260,15 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
                            bp->nspills, (const double *)sc->carry, sc->partial, y);
         SPRS_TRY_HIP(hipGetLastError());
     }
-    const dim3 rg((bp->n_long + 255) / 256), rb(256);
+    const dim3 rg((bp->n_long + WAVE - 1) / WAVE), rb(RNW * WAVE);
     if (acc)
         hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, stream, (const double *)sc->partial,
                            (const unsigned long long *)bp->wmask, (const uint32_t *)bp->wbase,
-                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->npieces);
+                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->npieces, (uint32_t)options().spmv_xmask);
     else
         hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, stream, (const double *)sc->partial,
                            (const unsigned long long *)bp->wmask, (const uint32_t *)bp->wbase,
-                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->npieces);
+                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->npieces, (uint32_t)options().spmv_xmask);
     SPRS_TRY_HIP(hipGetLastError());
     return SPRS_HIP_OK;
 }

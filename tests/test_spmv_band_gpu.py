@@ -26,9 +26,9 @@ def hip():
 
 
 class band_options:
-    def __init__(self, hip, hot, phases, group=0, split=32):
+    def __init__(self, hip, hot, phases, group=0, split=0):
         self.hip, self.vals = hip, dict(spmv_band=1, spmv_band_hot=hot, spmv_band_phases=phases,
-                                        spmv_band_group=group, spmv_xcs_split=split)
+                                        spmv_band_group=group, spmv_band_split=split)
 
     def __enter__(self):
         for k, v in self.vals.items():
@@ -36,7 +36,7 @@ class band_options:
 
     def __exit__(self, *exc):
         for k in self.vals:
-            self.hip.set_option(k, 32 if k == "spmv_xcs_split" else 0)
+            self.hip.set_option(k, 0)
 
 
 def oracle_spmv(shape, ip, ix, dt, x, y=None):
