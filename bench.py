@@ -12,6 +12,11 @@ resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 Workload selection (for parity-sized runs, never for the headline):
   --workload rmat10m (default) | rmat1m | laplace4096 | rmat:<n>:<nnz_per_row>
+  --workload spgemm5    BASELINE config 5: C = A * A, R-MAT 1M x 1M ~8 nnz/row (smmp::mul_csr_csr twin); a step is one
+                        whole product; prints its own JSON line (seconds per product, compulsory-bytes roofline,
+                        CPU baseline = the oracle's mul_csr_csr with sprs' chunking at T = 1 and Automatic on sampled
+                        row blocks, row-block parity).  The default SpMV line carries a short "spgemm5" object too
+                        (--no-secondary skips it).
   --idx-bytes 8 (default, sprs usize) | 4
 """
 import argparse
@@ -44,6 +49,101 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
+def spgemm5(dev, idx_bytes, steps, warmup, check_rows, cpu_blocks, cpu_block_rows, with_cpu=True):
+    """BASELINE config 5: C = A * A for R-MAT 1M x 1M, ~8 nnz/row (7.78e6 entries; nnz(C) = 3.3e9, 5.5e9 products).
+    Returns the JSON object of the workload.  SURVEY 8(d): compulsory bytes = (nnzA + nnzB + nnzC)(V + S_I) + 3 (n + 1) S_P."""
+    import sprs_amd
+    from sprs_amd import gen, smmp
+    from sprs_amd.device import DeviceCsMat
+    n, k = 1_000_000, 8
+    idt = torch.int64 if idx_bytes == 8 else torch.int32
+    indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)
+    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    rl = (indptr[1:] - indptr[:-1]).to(torch.float64)
+    csz = torch.zeros(indices.numel() + 1, dtype=torch.float64, device=dev)
+    csz[1:] = torch.cumsum(rl[indices.long()], 0)          # multiply-adds of the entries before each position
+    per_row_products = csz[indptr.long()]                  # ... of the rows before each row (n + 1 values)
+    del csz
+    products = float(per_row_products[-1].item())
+    stream = torch.cuda.current_stream()
+    c = None
+    for _ in range(warmup):
+        c = None
+        c = smmp.mul_csr_csr(a, a)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        c = None                                   # the previous result goes back to the library's block pool
+        ev[s_][0].record(stream)
+        c = smmp.mul_csr_csr(a, a)                 # symbolic + prefix sum + numeric, result resident in HBM
+        ev[s_][1].record(stream)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    ms = [p.elapsed_time(q) for p, q in ev]
+    nnz_a, nnz_c = int(indices.numel()), int(c.nnz())
+    comp = (2 * nnz_a + nnz_c) * (8 + idx_bytes) + 3 * (n + 1) * 8
+    sec = float(np.mean(ms)) * 1e-3
+    out = {
+        "metric": "CSR x CSR SpGEMM seconds per product (A*A, R-MAT 1M ~8/row)", "value": round(sec, 5), "unit": "s",
+        "higher_is_better": False, "steps": steps, "warmup": warmup, "ms_per_step": round(wall * 1e3, 3), "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE config 5: C = A*A, R-MAT 1M x 1M ~8 nnz/row (seed 1, no oversampling)", "rows": n, "nnz_a": nnz_a,
+                   "nnz_c": nnz_c, "products": products, "index_bytes": idx_bytes, "indptr_bytes": 8},
+        "gflops": round(2 * products / sec / 1e9, 2),
+        "roofline": {"bound": "hbm", "kernel": "all kernels of one sprs_hip_spgemm_f64 call (row_work, task lists, symbolic, scans, numeric)",
+                     "achieved": round(comp / sec / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(comp / sec / 1e9 / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_launch": comp, "no_reuse_upper_bound_bytes": int(products * (8 + idx_bytes)),
+                     "kernel_ms_avg": round(float(np.mean(ms)), 3), "kernel_ms_min": round(float(np.min(ms)), 3), "traffic": None},
+    }
+    # ---- parity and CPU baseline on row blocks: the oracle is the checker and the timed CPU port, never the product -------
+    from oracle import oracle
+    npi = np.uint64 if idx_bytes == 8 else np.uint32
+    ip_h = indptr.cpu().numpy().view(np.uint64)
+    ix_h = indices.cpu().numpy().view(npi)
+    dt_h = data.cpu().numpy()
+    ok, worst, checked = True, 0.0, 0
+    for r0 in sorted(set([0, n // 3, max(0, n - check_rows)])):
+        r1 = min(n, r0 + check_rows)
+        s0, e0 = int(ip_h[r0]), int(ip_h[r1])
+        _, rip, rix, rdt = oracle.mul_csr_csr((r1 - r0, n), ip_h[r0:r1 + 1], ix_h[s0:e0], dt_h[s0:e0], (n, n), ip_h, ix_h, dt_h, threads=0)
+        gip, gix, gdt = c.slice_outer_to_host(r0, r1)
+        gip = gip - gip[0]
+        ok &= bool(np.array_equal(gip, rip)) and bool(np.array_equal(gix, rix))
+        if ok and rdt.size:
+            worst = max(worst, float(np.max(np.abs(gdt - rdt) / np.maximum(np.abs(rdt), 1e-300))))
+        checked += int(rix.size)
+    out["parity"] = {"rows_checked": 3 * check_rows, "entries_checked": checked, "structure_bit_exact": ok, "max_rel_err": worst,
+                     "tolerance": 1e-10, "ok": bool(ok and worst <= 1e-10)}
+    if with_cpu:
+        # evenly spaced row blocks; the whole product is extrapolated by the ratio of multiply-adds (products)
+        pr_h = per_row_products.cpu().numpy()
+        starts = [int(i * (n - cpu_block_rows) / max(1, cpu_blocks - 1)) for i in range(cpu_blocks)]
+        p_sample, t1, tauto, used_auto = 0.0, 0.0, 0.0, 0
+        for r0 in starts:
+            r1 = r0 + cpu_block_rows
+            s0, e0 = int(ip_h[r0]), int(ip_h[r1])
+            blk = ((r1 - r0, n), ip_h[r0:r1 + 1], ix_h[s0:e0], dt_h[s0:e0], (n, n), ip_h, ix_h, dt_h)
+            t = time.perf_counter()
+            oracle.mul_csr_csr(*blk, threads=1)
+            t1 += time.perf_counter() - t
+            t = time.perf_counter()
+            res = oracle.mul_csr_csr(*blk, threads=0, return_threads=True)
+            tauto += time.perf_counter() - t
+            used_auto = max(used_auto, res[-1])
+            p_sample += float(pr_h[r1] - pr_h[r0])
+        scale = products / p_sample
+        out["cpu_baseline"] = {
+            "value": round(tauto * scale, 2), "unit": "s", "cores": int(used_auto), "kind": "port",
+            "sample": "%d blocks of %d rows spread over the matrix (%.2f %% of the multiply-adds), each multiplied by the whole B with the C "
+                      "restatement of smmp::mul_csr_csr and sprs' thread-count rule (ThreadingStrategy::Automatic: min(cores, "
+                      "(nnzA + nnzB) / 8128), smmp.rs:210-227); extrapolated to the whole product by the ratio of multiply-adds; "
+                      "rustc is not available here" % (cpu_blocks, cpu_block_rows, 100.0 / scale),
+            "sample_seconds": round(tauto, 3), "single_thread_value": round(t1 * scale, 2), "single_thread_sample_seconds": round(t1, 3),
+            "host_cores": oracle.num_procs(),
+        }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,6 +152,7 @@ def main():
     ap.add_argument("--workload", default="rmat10m")
     ap.add_argument("--idx-bytes", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the short spgemm5 object")
     ap.add_argument("--permute-cols", type=int, default=0,
                     help="experiment: relabel the columns by a random permutation (seed given) before the run")
     ap.add_argument("--kernel", type=int, default=None, help="spmv_kernel option for A/B (1 tiled, 2 wave-per-row)")
@@ -95,6 +196,16 @@ def main():
     for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_relabel", args.relabel), ("spmv_lds_pad", args.ldspad), ("spmv_xmask", args.xmask), ("spmv_band", args.band)):
         if val is not None:
             sprs_amd.set_option(opt, val)
+
+    if args.workload == "spgemm5":
+        if world != 1:
+            sys.exit("spgemm5 is single-GPU (north star: SpGEMM stays on one GPU)")
+        steps = args.steps if args.steps != 50 else 5
+        out = spgemm5(dev, args.idx_bytes, steps, min(args.warmup, 2), check_rows=100, cpu_blocks=16, cpu_block_rows=1500,
+                      with_cpu=not args.no_cpu_baseline)
+        out.update({"n_gpus": 1, "scaling": "replicas only", "vs_baseline": None})
+        print(json.dumps(out))
+        return
 
     # ---- workload -----------------------------------------------------------
     idt = torch.int64 if args.idx_bytes == 8 else torch.int32
@@ -311,6 +422,20 @@ def main():
         }
         out["parity"] = {"max_rel_err_vs_oracle": float(rel.max()), "tolerance": 1e-10,
                          "ok": bool(rel.max() <= 1e-10)}
+
+    # ---- BASELINE config 5 beside the headline (rank 0, N = 1, default workload): a short SpGEMM object -----------
+    if rank == 0 and world == 1 and wl == "rmat10m" and not args.no_secondary and not args.no_cpu_baseline:
+        try:
+            del sh
+            handles.clear()
+            torch.cuda.empty_cache()
+            sg = spgemm5(dev, 8, steps=2, warmup=1, check_rows=60, cpu_blocks=8, cpu_block_rows=1000)
+            out["spgemm5"] = {"seconds_per_product": sg["value"], "gflops": sg["gflops"], "nnz_c": sg["config"]["nnz_c"],
+                              "roofline_frac": sg["roofline"]["frac"], "compulsory_bytes": sg["roofline"]["algorithmic_bytes_per_launch"],
+                              "parity": sg["parity"], "cpu_baseline": sg["cpu_baseline"],
+                              "note": "python bench.py --workload spgemm5 prints the full line"}
+        except Exception as e:   # the headline line must not depend on the secondary measurement
+            out["spgemm5"] = {"error": repr(e)[:200]}
 
     if rank == 0:
         print(json.dumps(out))

@@ -587,7 +587,9 @@ static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
     // auto: worth it only when x is much larger than one L2 and the matrix is big enough to amortise
     bool want = o.spmv_xcs == 1 || (o.spmv_xcs == 0 && a->cols * 8 >= (16ull << 20) && nnz >= (1ull << 22));
     // the banded plan (spmv_band.hip) takes such matrices when it applies (its own test of the row lengths)
-    if ((want || o.spmv_band == 1) && o.spmv_band != 2 && o.spmv_xcs != 2) {
+    // (it pays from smaller x on than the XCD-sliced plan: R-MAT 1M, x = 8 MB, cold caches: 0.101 vs 0.156 ms, profiles/r02p)
+    const bool want_band = o.spmv_band == 1 || (o.spmv_band == 0 && o.spmv_xcs != 2 && a->cols * 8 >= (4ull << 20) && nnz >= (1ull << 22));
+    if (want_band) {
         SPRS_TRY(band_build(a, stream, &pl.band));
         if (pl.band) {
             pl.built = true;

@@ -14,6 +14,8 @@ Sources (numbers only — no reference code is copied):
   sprs/tests/block_matrix.rs:71-108 block product structure
   sprs/src/sparse/vec.rs:1648-1673 dot_product known answer
   sprs/src/sparse/linalg/bicgstab.rs:336-369  test_bicgstab_f64 system (CSC 4x4, tol, max_iter)
+  sprs/src/sparse/triplet.rs:343-646  triplet_incremental / _unordered / _additions / _from_vecs / _mutate_entry /
+                                      _to_csr / _complex / _empty_lines: triplets in insertion order + expected CSC
 """
 import json
 import os
@@ -54,6 +56,54 @@ def dense(src, name):
     b = fn_body(src, name)
     rows = re.findall(r"\[([^\[\]]+)\]", re.search(r"arr2\(&\[(.*)\]\)", b, re.S).group(1))
     return [[float(v) for v in nums(r)] for r in rows]
+
+
+def triplet_cases():
+    """Every matrix built in the tests of triplet.rs:343-646: the triplets in INSERTION order (duplicates are summed by
+    the conversion) and the CSC the reference expects (its CSR expectation is `expected.to_csr()`)."""
+    src = open(os.path.join(REF, "sprs/src/sparse/triplet.rs")).read()
+    tests = src[src.index("mod test {"):]
+    cases = []
+    for m in re.finditer(r"fn (triplet_\w+)\(\)\s*\{", tests):
+        name = m.group(1)
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"{": 1, "}": -1}.get(tests[i], 0)
+            i += 1
+        body = tests[m.end():i - 1]
+        # a test may build several matrices: cut at every constructor
+        ctor = r"(?:with_capacity\(\s*\((\d+),\s*(\d+)\)|TriMatI?::new\(\((\d+),\s*(\d+)\)\)|from_triplets\(\((\d+),\s*(\d+)\))"
+        starts = list(re.finditer(ctor, body))
+        for si, sm in enumerate(starts):
+            seg = body[sm.start():starts[si + 1].start() if si + 1 < len(starts) else len(body)]
+            shape = [int(v) for v in sm.groups() if v is not None]
+            if "from_triplets" in sm.group(0):
+                pre = body[:sm.start()]
+                rows = nums(re.search(r"let row_inds = vec!\[(.*?)\];", pre, re.S).group(1))
+                cols = nums(re.search(r"let col_inds = vec!\[(.*?)\];", pre, re.S).group(1))
+                vals = nums(re.search(r"let data = vec!\[(.*?)\];", pre, re.S).group(1))
+            else:
+                trip = re.findall(r"add_triplet\((\d+),\s*(\d+),\s*(-?[\d.]+)\)", seg)
+                rows, cols, vals = [int(t[0]) for t in trip], [int(t[1]) for t in trip], [float(t[2]) for t in trip]
+                sm2 = re.search(r"set_triplet\(locations\[0\],\s*(\d+),\s*(\d+),\s*(-?[\d.]+)\)", seg)
+                if sm2:      # triplet_mutate_entry: the single entry at that position gets a new value
+                    r_, c_, v_ = int(sm2.group(1)), int(sm2.group(2)), float(sm2.group(3))
+                    hits = [q for q in range(len(rows)) if rows[q] == r_ and cols[q] == c_]
+                    assert len(hits) == 1
+                    vals[hits[0]] = v_
+            em = re.search(r"new_csc\(\s*\((\d+),\s*(\d+)\),\s*vec!\[(.*?)\],\s*vec!\[(.*?)\],\s*vec!\[(.*?)\],?\s*\)", seg, re.S)
+            if em:
+                assert [int(em.group(1)), int(em.group(2))] == shape
+                exp = dict(indptr=nums(em.group(3)), indices=nums(em.group(4)), data=[float(v) for v in nums(em.group(5))])
+            else:            # expectations given as slices (triplet_empty_lines): the CSC ones come last in the segment
+                ip = re.findall(r"assert_eq!\(m\.indptr\(\), &\[(.*?)\]\[\.\.\]\)", seg)
+                ix = re.findall(r"assert_eq!\(m\.indices\(\), &\[(.*?)\]\)", seg)
+                dt = re.findall(r"assert_eq!\(m\.data\(\), &\[(.*?)\]\)", seg)
+                exp = dict(indptr=nums(ip[-1]), indices=nums(ix[-1]), data=[float(v) for v in nums(dt[-1])])
+            assert len(exp["indptr"]) == shape[1] + 1 and exp["indptr"][-1] == len(exp["indices"]) == len(exp["data"])
+            cases.append(dict(name="%s#%d" % (name, si), shape=shape, rows=rows, cols=cols, data=[float(v) for v in vals], csc=exp))
+    assert len(cases) >= 10, len(cases)
+    return cases
 
 
 def main():
@@ -120,6 +170,7 @@ def main():
                                   data=[float(v) for v in nums(ctor.group(5))],
                                   tol=float(re.search(r"let tol = ([0-9.e-]+);", tb).group(1)),
                                   max_iter=int(re.search(r"let max_iter = (\d+);", tb).group(1)))
+    fx["triplet_cases"] = triplet_cases()
     with open(OUT, "w") as f:
         json.dump(fx, f, indent=1, sort_keys=True)
     print("wrote", OUT, "with", len(fx) - 1, "fixtures")

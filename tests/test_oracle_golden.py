@@ -267,3 +267,23 @@ def test_bicgstab_iteration_limit_is_not_an_error():
     assert info["converged"] == 0 and info["iteration_count"] == 3
     x2, info2 = oracle.bicgstab((n, n), u(a.indptr), u(a.indices), a.data, np.zeros(n), b, 1e-11, 100)
     assert info2["converged"] == 1 and np.linalg.norm(a @ x2 - b) < 1e-11 and info2["hard_restart_count"] >= 1
+
+
+def test_triplets_to_cs_golden(golden):
+    """sprs/src/sparse/triplet.rs:343-646 (triplet_incremental, _unordered, _additions, _from_vecs, _mutate_entry,
+    _to_csr, _complex, _empty_lines): the oracle's restatement of TriMatIter::into_cs (triplet_iter.rs:127-224) must give
+    the CSC the reference asserts, and for to_csr the reference's `expected.to_csr()` (its conversion, pinned above)."""
+    cases = golden["triplet_cases"]
+    assert {c["name"].split("#")[0] for c in cases} >= {"triplet_incremental", "triplet_unordered", "triplet_additions",
+                                                         "triplet_from_vecs", "triplet_mutate_entry", "triplet_to_csr",
+                                                         "triplet_complex", "triplet_empty_lines"}
+    for c in cases:
+        rows, cols = c["shape"]
+        exp = c["csc"]
+        ip, ix, dt = oracle.triplets_to_cs((rows, cols), c["rows"], c["cols"], c["data"], storage="CSC")
+        assert ip.tolist() == exp["indptr"] and ix.tolist() == exp["indices"] and dt.tolist() == exp["data"], c["name"]
+        # expected.to_csr(): convert the asserted CSC with the (pinned) storage conversion
+        eip, eix, edt = oracle.convert_storage(cols, rows, np.array(exp["indptr"], dtype=np.uint64),
+                                               np.array(exp["indices"], dtype=np.uint64), np.array(exp["data"]))
+        rip, rix, rdt = oracle.triplets_to_cs((rows, cols), c["rows"], c["cols"], c["data"], storage="CSR")
+        assert rip.tolist() == eip.tolist() and rix.tolist() == eix.tolist() and rdt.tolist() == edt.tolist(), c["name"]

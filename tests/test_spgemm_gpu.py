@@ -366,3 +366,46 @@ def test_config5_full_size_row_blocks(hip, idx_bytes):
     assert d["parity"]["structure_bit_exact"] and d["parity"]["max_rel_err"] <= TOL
     assert d["parity"]["values_bit_exact"], d["parity"]
     assert d["structure_checks"]["rows_strictly_increasing"] and d["structure_checks"]["indptr_monotone"]
+
+
+def test_config5_five_products_bit_identical(hip):
+    """BASELINE config 5 at full size, five times: nnz, indptr and position-weighted 64-bit checksums of the
+    indices and of the value BITS must be identical from product to product (the accumulation order is fixed:
+    no float atomics; the ordering race noted in spgemm.hip would show up here)."""
+    import ctypes as C
+    import torch
+    from sprs_amd import _ffi, gen, smmp
+    from sprs_amd.device import DeviceCsMat
+    dev = torch.device("cuda", 0)
+    n = 1_000_000
+    indptr, indices, data = gen.rmat_csr(n, 8, device=dev, oversample=1.0)
+    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+
+    def fingerprint(c):
+        nnz = c.nnz()
+        p_ip, p_ix, p_dt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _ffi.check(_ffi.lib.sprs_hip_csmat_device_ptrs(c._h, C.byref(p_ip), C.byref(p_ix), C.byref(p_dt)))
+        blk = 1 << 27
+        buf = torch.empty(blk, dtype=torch.int64, device=dev)
+        w = torch.arange(1, blk + 1, dtype=torch.int64, device=dev)
+        sums = []
+        for base in (p_ix.value, p_dt.value):
+            acc = 0
+            for lo in range(0, nnz, blk):
+                m = min(blk, nnz - lo)
+                _ffi.check(_ffi.lib.sprs_hip_memcpy_d2d(C.c_void_p(buf.data_ptr()), C.c_void_p(base + lo * 8), m * 8, None))
+                torch.cuda.synchronize()
+                acc = (acc * 1000003 + int((buf[:m] * w[:m]).sum().item())) & 0xFFFFFFFFFFFFFFFF   # int64 wraps: fine for a checksum
+            sums.append(acc)
+        ip = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        _ffi.check(_ffi.lib.sprs_hip_memcpy_d2d(C.c_void_p(ip.data_ptr()), p_ip, (n + 1) * 8, None))
+        torch.cuda.synchronize()
+        return nnz, int((ip * torch.arange(1, n + 2, dtype=torch.int64, device=dev)).sum().item()), sums[0], sums[1]
+
+    prints = []
+    for _ in range(5):
+        c = smmp.mul_csr_csr(a, a)
+        prints.append(fingerprint(c))
+        del c
+    assert prints[0][0] > 3_000_000_000
+    assert all(p == prints[0] for p in prints[1:]), prints

@@ -398,3 +398,96 @@ def test_refresh_after_in_place_update(hip):
     finally:
         hip.set_option("spmv_xcs", 0)
     assert torch.equal(y2, 2.0 * y1)          # scaling by 2 is exact in binary floating point
+
+
+def _whole_vector_vs_oracle(indptr, indices, data, x, y, n, bound_componentwise=False):
+    """whole GPU result against the oracle's serial SpMV (prod.rs:120-126) on the host copy of the same arrays"""
+    from oracle import oracle
+    ip_h, ix_h, dt_h = indptr.cpu().numpy().view(np.uint64), indices.cpu().numpy().view(np.uint64), data.cpu().numpy()
+    x_h = x.cpu().numpy()
+    ref = np.zeros(n)
+    oracle.mul_acc_mat_vec_csr((n, n), ip_h, ix_h, dt_h, x_h, ref)
+    got = y.cpu().numpy()
+    if bound_componentwise:
+        bound = np.zeros(n)
+        oracle.mul_acc_mat_vec_csr((n, n), ip_h, ix_h, np.abs(dt_h), np.abs(x_h), bound)
+        assert np.all(np.abs(got - ref) <= TOL * bound)
+    else:
+        assert rel_err(got, ref) <= TOL
+    empty = np.diff(ip_h.astype(np.int64)) == 0
+    assert np.all(got[empty] == 0.0)
+    return ref
+
+
+def test_config2_full_size_whole_vector(hip):
+    """BASELINE config 2 (R-MAT 1M x 1M, ~16 nnz/row) at full size: EVERY component of y against the oracle
+    (<= 1e-10 relative; positive data, no cancellation), for the plain plan and for the banded one."""
+    import torch
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    dev = torch.device("cuda", 0)
+    n = 1_000_000
+    indptr, indices, data = gen.rmat_csr(n, 16, device=dev)
+    x = gen.dense_vector(n, seed=3, device=dev)
+    for band, kind in ((2, 1), (1, 3)):
+        hip.set_option("spmv_band", band)
+        try:
+            a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+            y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+            prod.csmat_mul_vec(a, DeviceVec.borrow(x), out=DeviceVec.borrow(y))
+            torch.cuda.synchronize()
+            assert a.spmv_plan_info()[0] == kind
+        finally:
+            hip.set_option("spmv_band", 0)
+        _whole_vector_vs_oracle(indptr, indices, data, x, y, n)
+
+
+def test_config3_full_size_whole_vector(hip):
+    """BASELINE config 3 (5-point Laplacian of a 4096 x 4096 grid, heat.rs:45-80) at full size: every component
+    within the componentwise bound |dy_i| <= 1e-10 (|A||x|)_i (mixed signs), Dirichlet rows exact."""
+    import torch
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    dev = torch.device("cuda", 0)
+    g = 4096
+    n = g * g
+    indptr, indices, data = gen.grid_laplacian(g, g, device=dev)
+    x = gen.dense_vector(n, seed=3, device=dev)
+    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    prod.csmat_mul_vec(a, DeviceVec.borrow(x), out=DeviceVec.borrow(y))
+    torch.cuda.synchronize()
+    _whole_vector_vs_oracle(indptr, indices, data, x, y, n, bound_componentwise=True)
+    border = (indptr[1:] - indptr[:-1]) == 1
+    assert torch.equal(y[border], x[border])             # border rows are 1.0 * x exactly
+
+
+def test_config4_full_size_whole_vector_and_determinism(hip):
+    """BASELINE config 4 / the north star's target matrix (R-MAT 10M x 10M, ~32 nnz/row, usize indices) on one
+    GPU with the DEFAULT plan (banded: hot columns from LDS): every component against the oracle, the
+    accumulate form (prod.rs:103-127) against y0 + A x, and five SpMVs bit-identical."""
+    import torch
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    dev = torch.device("cuda", 0)
+    n = 10_000_000
+    indptr, indices, data = gen.rmat_csr(n, 32, device=dev)
+    x = gen.dense_vector(n, seed=3, device=dev)
+    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    ys = []
+    for _ in range(5):
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+        prod.csmat_mul_vec(a, DeviceVec.borrow(x), out=DeviceVec.borrow(y))
+        torch.cuda.synchronize()
+        ys.append(y)
+    assert a.spmv_plan_info()[0] == 3
+    for y in ys[1:]:
+        assert torch.equal(y, ys[0])
+    ref = _whole_vector_vs_oracle(indptr, indices, data, x, ys[0], n)
+    y0 = gen.dense_vector(n, seed=9, device=dev)
+    yacc = y0.clone()
+    prod.mul_acc_mat_vec_csr(a, DeviceVec.borrow(x), DeviceVec.borrow(yacc))
+    torch.cuda.synchronize()
+    assert rel_err(yacc.cpu().numpy(), ref + y0.cpu().numpy()) <= TOL
+    empty = (indptr[1:] - indptr[:-1]) == 0
+    assert torch.equal(yacc[empty], y0[empty])            # empty rows untouched, bit for bit

@@ -87,3 +87,22 @@ def test_matrix_market_to_device_and_multiply(hip):
     out = io.StringIO()
     write_matrix_market(out, a)
     assert np.allclose(scipy.io.mmread(io.BytesIO(out.getvalue().encode())).toarray(), dense, rtol=1e-13, atol=1e-13)
+
+
+def test_reference_golden_cases(hip, golden):
+    """the reference's own triplet tests (triplet.rs:343-646, tests/golden/sprs_fixtures.json): to_csc must give the CSC
+    it asserts, to_csr that matrix converted (`expected.to_csr()`), for 8- and 4-byte indices"""
+    from oracle import oracle
+    from sprs_amd.triplet import TriMat
+    for c in golden["triplet_cases"]:
+        rows, cols = c["shape"]
+        exp = c["csc"]
+        eip, eix, edt = oracle.convert_storage(cols, rows, np.array(exp["indptr"], dtype=np.uint64),
+                                               np.array(exp["indices"], dtype=np.uint64), np.array(exp["data"]))
+        for idx in (np.uint64, np.uint32):
+            t = TriMat((rows, cols), c["rows"], c["cols"], c["data"])
+            shape, ip, ix, dt = t.to_csc(idx).to_host()
+            assert shape == (rows, cols)
+            assert ip.tolist() == exp["indptr"] and ix.tolist() == exp["indices"] and dt.tolist() == exp["data"], c["name"]
+            shape, ip, ix, dt = t.to_csr(idx).to_host()
+            assert ip.tolist() == eip.tolist() and ix.tolist() == eix.tolist() and dt.tolist() == edt.tolist(), c["name"]
