@@ -228,6 +228,17 @@ int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b
  * order.  SPRS_HIP_INDEX_OVERFLOW where the reference panics (csmat.rs:1794). */
 int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out);
 
+/* Triplet (COO) assembly: twin of TriMatBase::to_csr / to_csc (triplet.rs:262-276) = TriMatIter::into_cs
+ * (triplet_iter.rs:127-224): the n triplets (row_inds[p], col_inds[p], data[p]) — arrays in DEVICE memory, indices of
+ * in_idx_bytes (4 or 8) each — are sorted by (outer, inner) with a stable device radix sort, duplicates are summed in
+ * triplet order (`slot = slot + next`, triplet_iter.rs:168-171; the reference's unstable sort leaves that order
+ * open), explicit zeros stay stored, empty outer slices get their indptr entries.  New owning handle with `storage`,
+ * indices of out_idx_bytes and indptr of out_iptr_bytes.  SPRS_HIP_INVALID_ARG for an index out of bounds (add_triplet
+ * asserts it, triplet.rs:171-172) or more than 2^32 rows / columns; SPRS_HIP_INDEX_OVERFLOW as CsMat construction. */
+int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const void *row_inds_dev, const void *col_inds_dev,
+                                int32_t in_idx_bytes, const double *data_dev, int32_t storage, int32_t out_idx_bytes,
+                                int32_t out_iptr_bytes, sprs_hip_csmat **out);
+
 /* ---- tuning knobs (A/B runs; never needed for correctness) -------------- */
 
 /* name = "spmv_kernel":    0 auto, 1 nnz-tiled streaming kernel, 2 wave-per-row (A/B only);

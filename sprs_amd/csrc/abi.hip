@@ -635,6 +635,22 @@ int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint
     return slice_outer(m, start, end, out);
 }
 
+int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const void *row_inds_dev, const void *col_inds_dev,
+                                int32_t in_idx_bytes, const double *data_dev, int32_t storage, int32_t out_idx_bytes,
+                                int32_t out_iptr_bytes, sprs_hip_csmat **out) {
+    clear_error();
+    if (!out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    if (storage != SPRS_HIP_CSR && storage != SPRS_HIP_CSC) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "bad storage tag %d", storage);
+    if (!widths_ok(out_iptr_bytes, out_idx_bytes) || (in_idx_bytes != 4 && in_idx_bytes != 8))
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "index widths must be 4 or 8 bytes");
+    if (n && (!row_inds_dev || !col_inds_dev || !data_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL triplet array with n > 0");
+    const uint64_t inner = storage == SPRS_HIP_CSR ? cols : rows, outer = storage == SPRS_HIP_CSR ? rows : cols;
+    if (out_idx_bytes == 4 && inner > 0xFFFFFFFFull) SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Index type not large enough for this matrix");
+    if (out_iptr_bytes == 4 && outer + 1 > 0xFFFFFFFFull) SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Iptr type not large enough for this matrix");
+    return triplets_to_cs(rows, cols, n, row_inds_dev, col_inds_dev, in_idx_bytes, data_dev, storage, out_idx_bytes, out_iptr_bytes, out);
+}
+
 int32_t sprs_hip_set_option(const char *name, int64_t value) {
     clear_error();
     if (!name) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL name");

@@ -167,6 +167,9 @@ int32_t spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hi
 // spmm.hip
 int32_t spmm_rowmaj_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, double *out,
                         uint64_t ld_out, bool accumulate, hipStream_t stream);
+// triplet.hip
+int32_t triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const void *row_inds, const void *col_inds, int32_t in_idx_bytes,
+                       const double *data, int32_t storage, int32_t out_idx_bytes, int32_t out_iptr_bytes, sprs_hip_csmat **out);
 // convert.hip
 int32_t to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out);
 // bicgstab.hip

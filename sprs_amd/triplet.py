@@ -2,7 +2,11 @@
 `TriMatBase::to_csr / to_csc` (sprs/src/sparse/triplet.rs:262-276 -> TriMatIter::into_cs,
 sprs/src/sparse/triplet_iter.rs:127-224): entries sorted by (outer, inner), DUPLICATES SUMMED.
 
-No new kernel is involved.  With n triplets (r_p, c_p, v_p), let
+Default route: `sprs_hip_triplets_to_cs` (sprs_amd/csrc/triplet.hip): keys (outer << 32 | inner), a stable device
+radix sort (sort.hip), duplicates folded left to right in triplet order, indptr filled including empty slices.
+
+Alternative route (method="product", the first implementation, kept as a cross-check): no kernel of its own.
+With n triplets (r_p, c_p, v_p), let
     R  (rows x n):  R[r_p, p] = 1      — its CSC arrays are (0..n, r, ones): one entry per column
     E  (n x cols):  E[p, c_p] = v_p    — its CSR arrays are (0..n, c, v):    one entry per row
 then  A = R * E  is the assembled matrix: A[i, j] = sum over the triplets p with (r_p, c_p) = (i, j) of
@@ -16,10 +20,13 @@ order of equal (row, col) keys unspecified; triplet order is one of its possible
 a stable sort gives.  Two duplicates commute, so the result differs from ANY outcome of the reference
 only for cells with three or more entries, and then only in rounding.
 """
+import ctypes as C
+
 import numpy as np
 
-from ._ffi import CSC, CSR
-from .device import DeviceCsMat
+from . import _ffi
+from ._ffi import CSC, CSR, check, lib
+from .device import DeviceCsMat, DeviceVec
 
 
 class TriMat:
@@ -62,8 +69,34 @@ class TriMat:
         ptr = np.arange(n + 1, dtype=np.uint64)
         return n, ptr, self.row_inds.astype(idx_dtype), self.col_inds.astype(idx_dtype)
 
-    def to_csr(self, idx_dtype=np.uint64):
+    def _assemble(self, storage, idx_dtype):
+        n = self.nnz()
+        ib = np.dtype(idx_dtype).itemsize
+        if max(self.rows, self.cols) >= 2 ** 32 - 1 and ib == 4:
+            raise OverflowError("Index type is not large enough to hold the matrix")     # SpIndex::from_usize
+        bufs = []
+
+        def up(arr):
+            p = C.c_void_p()
+            check(lib.sprs_hip_malloc(C.byref(p), max(arr.nbytes, 8)))
+            bufs.append(p)
+            if arr.nbytes:
+                check(lib.sprs_hip_memcpy_h2d(p, C.c_void_p(arr.ctypes.data), arr.nbytes))
+            return p
+
+        try:
+            r, c, v = up(self.row_inds), up(self.col_inds), up(self.data)
+            h = C.c_void_p()
+            check(lib.sprs_hip_triplets_to_cs(self.rows, self.cols, n, r, c, 8, v, storage, ib, 8, C.byref(h)))
+            return DeviceCsMat(h.value)
+        finally:
+            for p in bufs:
+                lib.sprs_hip_free(p)
+
+    def to_csr(self, idx_dtype=np.uint64, method="sort"):
         """TriMatBase::to_csr (triplet.rs:270-276).  Index type I = idx_dtype, Iptr = u64."""
+        if method == "sort":
+            return self._assemble(CSR, idx_dtype)
         from . import smmp
         n, ptr, r, c = self._selectors(idx_dtype)
         if n == 0:
@@ -73,8 +106,10 @@ class TriMat:
         ent = DeviceCsMat.from_host((n, self.cols), ptr, c, self.data)                                   # E
         return smmp.mul_csr_csr(sel, ent)
 
-    def to_csc(self, idx_dtype=np.uint64):
-        """TriMatBase::to_csc (triplet.rs:262-268): computed as (E^T R^T)^T, whose CSR arrays are A's CSC arrays."""
+    def to_csc(self, idx_dtype=np.uint64, method="sort"):
+        """TriMatBase::to_csc (triplet.rs:262-268); method="product": computed as (E^T R^T)^T, whose CSR arrays are A's CSC arrays."""
+        if method == "sort":
+            return self._assemble(CSC, idx_dtype)
         from . import smmp
         n, ptr, r, c = self._selectors(idx_dtype)
         if n == 0:

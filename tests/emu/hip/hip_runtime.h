@@ -169,6 +169,8 @@ inline void __threadfence_block() {}
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
+inline long long __double_as_longlong(double v) { long long b; memcpy(&b, &v, 8); return b; }
+inline double __longlong_as_double(long long b) { double v; memcpy(&v, &b, 8); return v; }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }

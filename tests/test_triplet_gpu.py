@@ -106,3 +106,33 @@ def test_reference_golden_cases(hip, golden):
             assert ip.tolist() == exp["indptr"] and ix.tolist() == exp["indices"] and dt.tolist() == exp["data"], c["name"]
             shape, ip, ix, dt = t.to_csr(idx).to_host()
             assert ip.tolist() == eip.tolist() and ix.tolist() == eix.tolist() and dt.tolist() == edt.tolist(), c["name"]
+
+
+@pytest.mark.parametrize("storage", ["CSR", "CSC"])
+def test_sort_route_equals_selector_product(hip, storage):
+    """the radix-sort kernel route (sprs_hip_triplets_to_cs) and the selector-product route (to_other_storage +
+    mul_csr_csr) fold duplicates in the same (triplet) order: identical bits; 2e5 triplets with heavy duplication,
+    indices that need more than one radix pass in both fields"""
+    from sprs_amd.triplet import TriMat
+    rows, cols, n = 70000, 300, 200000
+    r, c, v = random_triplets(rows, cols, n, seed=11, hot=0.3)
+    t = TriMat((rows, cols), r, c, v)
+    a = (t.to_csr() if storage == "CSR" else t.to_csc()).to_host()
+    b = (t.to_csr(method="product") if storage == "CSR" else t.to_csc(method="product")).to_host()
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
+
+
+def test_out_of_bounds_and_widths(hip):
+    import ctypes as C
+    from sprs_amd import _ffi
+    from sprs_amd.device import DeviceVec
+    r = DeviceVec.from_host(np.array([0, 5], dtype=np.uint64).view(np.float64))
+    c = DeviceVec.from_host(np.array([1, 1], dtype=np.uint64).view(np.float64))
+    v = DeviceVec.from_host(np.array([1.0, 2.0]))
+    h = C.c_void_p()
+    st = _ffi.lib.sprs_hip_triplets_to_cs(4, 4, 2, C.c_void_p(r.ptr), C.c_void_p(c.ptr), 8, C.c_void_p(v.ptr), 0, 8, 8, C.byref(h))
+    assert st == _ffi.INVALID_ARG and b"out of bounds" in _ffi.lib.sprs_hip_last_error()
+    st = _ffi.lib.sprs_hip_triplets_to_cs(4, 4, 2, C.c_void_p(r.ptr), C.c_void_p(c.ptr), 2, C.c_void_p(v.ptr), 0, 8, 8, C.byref(h))
+    assert st == _ffi.INVALID_ARG
