@@ -4,7 +4,7 @@
 //   fold equal neighbours, slot = slot + next      triplet_iter.rs:160-180, left to right
 //   fill indptr, empty outer slices included       triplet_iter.rs:182-214
 // Here the sort is a STABLE radix sort (sort.hip), so a group of duplicates is summed in triplet order — one of the
-// orders the reference's unstable sort may produce, and the one the oracle's restatement takes.  Explicit zeros and
+// orders the reference's unstable sort may produce (the CPU restatement used by the tests takes the same one).  Explicit zeros and
 // sums that cancel stay stored.  HBM-bound integer work (32 B per triplet and radix pass), no MFMA.
 #include "common.hpp"
 
