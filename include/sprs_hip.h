@@ -223,6 +223,28 @@ int32_t sprs_hip_spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sp
 int32_t sprs_hip_spgemm_symbolic(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c_structure);
 int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c);
 
+/* The same split with the symbolic work KEPT, as the reference's callers keep (indptr, indices) between symbolic and
+ * numeric (smmp.rs:81-131 -> 151-189; sprs-benches/src/main.rs:211-260 re-multiplies the same operands):
+ *   sprs_hip_spgemm_plan_create     the symbolic phase for (a, b): per-row product counts, how the rows are cut into
+ *                                   tasks, the exact output counts, their prefix sum = C.indptr, nnz(C)
+ *   sprs_hip_spgemm_plan_nnz        nnz of the product
+ *   sprs_hip_spgemm_plan_structure  C with indptr + sorted indices, values 0.0            (what smmp::symbolic returns)
+ *   sprs_hip_spgemm_plan_product    C complete: structure and values in one numeric pass  (== sprs_hip_spgemm_f64)
+ *   sprs_hip_spgemm_plan_numeric    the VALUES into a c of the product's structure (shape, nnz, indptr checked ->
+ *                                   SPRS_HIP_BAD_STRUCTURE; c's indices are not touched): only the value kernels run
+ * a and b must be the handles (same structure buffers) the plan was made for, else SPRS_HIP_INVALID_ARG; their VALUES
+ * may have changed in place in between.  All of these block until done. */
+typedef struct sprs_hip_spgemm_plan sprs_hip_spgemm_plan;
+int32_t sprs_hip_spgemm_plan_create(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_spgemm_plan **plan);
+int32_t sprs_hip_spgemm_plan_nnz(const sprs_hip_spgemm_plan *plan, uint64_t *nnz);
+int32_t sprs_hip_spgemm_plan_structure(sprs_hip_spgemm_plan *plan, const sprs_hip_csmat *a, const sprs_hip_csmat *b,
+                                       sprs_hip_csmat **c_structure);
+int32_t sprs_hip_spgemm_plan_product(sprs_hip_spgemm_plan *plan, const sprs_hip_csmat *a, const sprs_hip_csmat *b,
+                                     sprs_hip_csmat **c);
+int32_t sprs_hip_spgemm_plan_numeric(sprs_hip_spgemm_plan *plan, const sprs_hip_csmat *a, const sprs_hip_csmat *b,
+                                     sprs_hip_csmat *c);
+int32_t sprs_hip_spgemm_plan_free(sprs_hip_spgemm_plan *plan);
+
 /* Storage conversion raw::convert_mat_storage / to_other_storage
  * (csmat.rs:1405-1426, 1782-1829): new owning handle with the other storage
  * order.  SPRS_HIP_INDEX_OVERFLOW where the reference panics (csmat.rs:1794). */

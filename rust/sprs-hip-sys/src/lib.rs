@@ -16,6 +16,11 @@ pub const SPRS_HIP_CSR: i32 = 0;
 pub const SPRS_HIP_CSC: i32 = 1;
 
 #[repr(C)]
+pub struct sprs_hip_spgemm_plan {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
 pub struct sprs_hip_csmat {
     _private: [u8; 0],
 }
@@ -93,6 +98,12 @@ extern "C" {
     pub fn sprs_hip_spgemm_f64(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_spgemm_symbolic(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c_structure: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_spgemm_numeric(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_spgemm_plan_create(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, plan: *mut *mut sprs_hip_spgemm_plan) -> i32;
+    pub fn sprs_hip_spgemm_plan_nnz(plan: *const sprs_hip_spgemm_plan, nnz: *mut u64) -> i32;
+    pub fn sprs_hip_spgemm_plan_structure(plan: *mut sprs_hip_spgemm_plan, a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c_structure: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_spgemm_plan_product(plan: *mut sprs_hip_spgemm_plan, a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_spgemm_plan_numeric(plan: *mut sprs_hip_spgemm_plan, a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_spgemm_plan_free(plan: *mut sprs_hip_spgemm_plan) -> i32;
     pub fn sprs_hip_csmat_to_other_storage(m: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_triplets_to_cs(
         rows: u64, cols: u64, n: u64, row_inds_dev: *const c_void, col_inds_dev: *const c_void, in_idx_bytes: i32,

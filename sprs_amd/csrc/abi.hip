@@ -571,6 +571,15 @@ static int32_t spgemm_contract(const sprs_hip_csmat *a, const sprs_hip_csmat *b)
     return SPRS_HIP_OK;
 }
 
+static int32_t numeric_target_ok(const sprs_hip_csmat *a, const sprs_hip_csmat *b, const sprs_hip_csmat *c) {
+    // smmp.rs:161-166: the asserts of numeric() on the shape of c
+    if (c->rows != a->rows || c->cols != b->cols) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if (c->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    if (c->iptr_bytes != a->iptr_bytes || c->idx_bytes != a->idx_bytes)
+        SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "C must share the operands' index types");
+    return SPRS_HIP_OK;
+}
+
 int32_t sprs_hip_spgemm_symbolic(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
     clear_error();
     if (!a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
@@ -583,15 +592,59 @@ int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b
     clear_error();
     if (!a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     SPRS_TRY(spgemm_contract(a, b));
-    // smmp.rs:161-166: the asserts of numeric() on the shape of c
-    if (c->rows != a->rows || c->cols != b->cols) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
-    if (c->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
-    if (c->iptr_bytes != a->iptr_bytes || c->idx_bytes != a->idx_bytes)
-        SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "C must share the operands' index types");
+    SPRS_TRY(numeric_target_ok(a, b, c));
     std::lock_guard<std::mutex> lock(c->mu);
     c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
     c->mm.release();
     return spgemm_numeric(a, b, c);
+}
+
+int32_t sprs_hip_spgemm_plan_create(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_spgemm_plan **plan) {
+    clear_error();
+    if (!a || !b || !plan) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *plan = nullptr;
+    SPRS_TRY(spgemm_contract(a, b));
+    return spgemm_plan_create(a, b, plan);
+}
+
+int32_t sprs_hip_spgemm_plan_nnz(const sprs_hip_spgemm_plan *plan, uint64_t *nnz) {
+    clear_error();
+    if (!plan || !nnz) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *nnz = spgemm_plan_nnz(plan);
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_spgemm_plan_structure(sprs_hip_spgemm_plan *plan, const sprs_hip_csmat *a, const sprs_hip_csmat *b,
+                                       sprs_hip_csmat **c_structure) {
+    clear_error();
+    if (!plan || !a || !b || !c_structure) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *c_structure = nullptr;
+    return spgemm_plan_structure(plan, a, b, c_structure, false);
+}
+
+int32_t sprs_hip_spgemm_plan_product(sprs_hip_spgemm_plan *plan, const sprs_hip_csmat *a, const sprs_hip_csmat *b,
+                                     sprs_hip_csmat **c) {
+    clear_error();
+    if (!plan || !a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *c = nullptr;
+    return spgemm_plan_structure(plan, a, b, c, true);
+}
+
+int32_t sprs_hip_spgemm_plan_numeric(sprs_hip_spgemm_plan *plan, const sprs_hip_csmat *a, const sprs_hip_csmat *b,
+                                     sprs_hip_csmat *c) {
+    clear_error();
+    if (!plan || !a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    SPRS_TRY(numeric_target_ok(a, b, c));
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
+    c->mm.release();
+    return spgemm_plan_numeric(plan, a, b, c);
+}
+
+int32_t sprs_hip_spgemm_plan_free(sprs_hip_spgemm_plan *plan) {
+    clear_error();
+    spgemm_plan_free(plan);
+    return SPRS_HIP_OK;
 }
 
 int32_t sprs_hip_bicgstab_f64(sprs_hip_csmat *a, const double *x0_dev, const double *b_dev, uint64_t n, double tol,
@@ -687,6 +740,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "pool_max_bytes")) {
         if (value < 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "pool_max_bytes must be >= 0");
         o.pool_max_bytes = value;
+    } else if (!strcmp(name, "spgemm_task_order")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_task_order must be 0, 1 or 2");
+        o.spgemm_task_order = value;
     } else if (!strcmp(name, "spgemm_minwin")) {
         if (value < 11 || value > 16) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_minwin must be 11..16");
         o.spgemm_minwin = value;
@@ -751,6 +807,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_prof")) *value = o.spgemm_prof;
     else if (!strcmp(name, "spgemm_heavy")) *value = o.spgemm_heavy;
     else if (!strcmp(name, "spgemm_minwin")) *value = o.spgemm_minwin;
+    else if (!strcmp(name, "spgemm_task_order")) *value = o.spgemm_task_order;
     else if (!strcmp(name, "pool")) *value = o.pool;
     else if (!strcmp(name, "pool_max_bytes")) *value = o.pool_max_bytes;
     else if (!strcmp(name, "pool_cached_bytes")) *value = (int64_t)pool_cached_bytes();

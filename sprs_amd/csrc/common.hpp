@@ -11,6 +11,8 @@
 
 #include "../../include/sprs_hip.h"
 
+struct sprs_hip_spgemm_plan;      // spgemm.hip
+
 namespace sprs_hip {
 
 // ---- thread-local error state ------------------------------------------
@@ -45,6 +47,7 @@ struct Options {
     int64_t spmv_sort_tiles = 0;   // plan copies: entries of a tile sorted by column (measured 10 % SLOWER: profiles/r01v)
     int64_t spmv_relabel = 0;      // sliced plan: columns relabelled by count class, x permuted per SpMV: 0 auto (on), 1 on, 2 off
     int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
+    int64_t spgemm_task_order = 0; // large-row tasks: 0/1 window-major (sorted by first column, then row), 2 row-major (A/B)
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
     int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
     int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)
@@ -164,6 +167,11 @@ int32_t spmv_f64(sprs_hip_csmat *a, const double *x, double *y, bool accumulate,
 int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c);
 int32_t spgemm_symbolic(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c);
 int32_t spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c);
+int32_t spgemm_plan_create(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_spgemm_plan **out);
+int32_t spgemm_plan_structure(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **out, bool with_values);
+int32_t spgemm_plan_numeric(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c);
+uint64_t spgemm_plan_nnz(const sprs_hip_spgemm_plan *pl);
+void spgemm_plan_free(sprs_hip_spgemm_plan *pl);
 // spmm.hip
 int32_t spmm_rowmaj_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, double *out,
                         uint64_t ld_out, bool accumulate, hipStream_t stream);

@@ -36,6 +36,8 @@
 #include "common.hpp"
 #include "scan.hpp"
 
+#include <vector>
+
 namespace sprs_hip {
 
 namespace {
@@ -191,25 +193,52 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
     }
 }
 
-__global__ void make_tasks_kernel(const uint64_t *__restrict__ ub, const uint64_t *__restrict__ ntasks,
-                                  const uint64_t *__restrict__ first_task, uint64_t rows,
-                                  uint64_t *__restrict__ task_row, uint64_t *__restrict__ small_list,
-                                  uint64_t *__restrict__ large_list, uint64_t list_len,
-                                  unsigned long long *__restrict__ counters) {
+// Task lists, deterministic (first version: atomicAdd tickets, i.e. an arbitrary order that changed from call to call).
+// Classes of a row: tiny (<= 64 products), small (<= 512), large (one task per column window).
+__global__ void task_class_kernel(const uint64_t *__restrict__ ub, const uint64_t *__restrict__ ntasks, uint64_t rows,
+                                  uint64_t *__restrict__ is_tiny, uint64_t *__restrict__ is_small, uint64_t *__restrict__ n_large) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint64_t n = ntasks[r], u = ub[r];
+    is_tiny[r] = (n && u <= TINY_MAX) ? 1 : 0;
+    is_small[r] = (n && u > TINY_MAX && u <= SMALL_MAX) ? 1 : 0;
+    n_large[r] = (n && u > SMALL_MAX) ? n : 0;
+}
+
+// lists in row order; for the large tasks also the sort key (first column of the window, row): the launch walks them
+// WINDOW-major, so that the tasks running at the same time read the same column range of B
+__global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uint64_t *__restrict__ first_task,
+                                  const uint8_t *__restrict__ wlog, uint64_t rows, const uint64_t *__restrict__ pos_tiny,
+                                  const uint64_t *__restrict__ pos_small, const uint64_t *__restrict__ pos_large,
+                                  const uint64_t *__restrict__ is_tiny, const uint64_t *__restrict__ is_small,
+                                  uint64_t *__restrict__ task_row, uint64_t *__restrict__ tiny_list,
+                                  uint64_t *__restrict__ small_list, uint64_t *__restrict__ large_list,
+                                  uint64_t *__restrict__ large_key) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const uint64_t n = ntasks[r];
     if (!n) return;
     const uint64_t f = first_task[r];
     for (uint64_t j = 0; j < n; ++j) task_row[f + j] = r;
-    if (ub[r] <= TINY_MAX) {
-        small_list[list_len - 1 - atomicAdd(&counters[2], 1ull)] = f;     // tiny rows: from the end of the same list
-    } else if (ub[r] <= SMALL_MAX) {
-        small_list[atomicAdd(&counters[0], 1ull)] = f;
+    if (is_tiny[r]) {
+        tiny_list[pos_tiny[r]] = f;
+    } else if (is_small[r]) {
+        small_list[pos_small[r]] = f;
     } else {
-        const uint64_t pos = atomicAdd(&counters[1], (unsigned long long)n);
-        for (uint64_t j = 0; j < n; ++j) large_list[pos + j] = f + j;
+        const uint64_t pos = pos_large[r];
+        const uint32_t wl = wlog[r];
+        for (uint64_t j = 0; j < n; ++j) {
+            large_list[pos + j] = f + j;
+            large_key[pos + j] = ((j << wl) << 32) | (r & 0xFFFFFFFFull);
+        }
     }
+}
+
+// Block b runs on XCD b % 8 (observed; only speed depends on it): every XCD gets a contiguous run of the (window-major)
+// task list, so that the tasks sharing a column window of B — and its lines in the private 4 MiB L2 — stay together.
+__device__ __forceinline__ uint64_t task_of_block(uint64_t bid, uint64_t n) {
+    const uint64_t q = n >> 3, rem = n & 7, k = bid & 7, j = bid >> 3;
+    return k * q + (k < rem ? k : rem) + j;
 }
 
 // ---------------------------------------------------------------------------
@@ -369,7 +398,7 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
             }
             const uint64_t o = off[t];
             for (uint32_t i = lane; i < need; i += WAVE) {
-                c_indices[o + i] = (IDX)keys[i];
+                if (c_indices) c_indices[o + i] = (IDX)keys[i];   // null: C already has its structure (numeric on a kept plan)
                 if (c_data) c_data[o + i] = vals[i];      // null: structure only (the twin of smmp::symbolic)
             }
             __builtin_amdgcn_wave_barrier();
@@ -520,7 +549,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, P
     __shared__ uint32_t kP[K_CAP + 1];
     __shared__ uint64_t wt[16];
     __shared__ uint64_t red[LG_WAVES];
-    const uint64_t t = large_list[blockIdx.x];
+    const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x)];
     const uint64_t r = task_row[t];
     const uint64_t w = t - first_task[r];
     const uint32_t wl = wlog[r];
@@ -565,7 +594,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     __shared__ double kA[K_CAP];
     __shared__ uint64_t wt[16];
     const uint32_t tid = threadIdx.x;
-    const uint64_t t = large_list[blockIdx.x];
+    const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x)];
     const uint64_t r = task_row[t];
     const uint64_t w = t - first_task[r];
     const uint32_t wl = wlog[r];
@@ -631,7 +660,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     lds_barrier();
     // indices come out sorted: walk the set bits of each word in order
 #pragma unroll 1
-    for (int i = 0; i < WPT; ++i) {
+    for (int i = 0; i < WPT && c_indices; ++i) {                // (no index array: C already has its structure)
         const int word = i * LG_BLOCK + (int)tid;
         if (word >= words) break;
         unsigned long long m = bm[word];
@@ -817,97 +846,168 @@ __global__ void compare_indptr_kernel(const uint64_t *__restrict__ first_task, c
     if ((uint64_t)indptr[r] != off[first_task[r]]) atomicOr(mismatch, 1u);
 }
 
+// temporaries come from the library's block pool (abi.hip): a product per iteration no longer pays ~15 hipMalloc / hipFree
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
+    uint64_t cap = 0;
+    int dev = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) pool_free(p, cap, dev);
+        p = nullptr;
     }
-    hipError_t alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    hipError_t alloc(uint64_t bytes) {
+        release();
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        return pool_alloc(&p, bytes ? bytes : 8, &cap, dev);
+    }
     template <typename T>
     T *as() { return (T *)p; }
 };
 
+}  // namespace
+
+int32_t radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t n, const std::vector<std::pair<int, int>> &fields, hipStream_t stream);   // sort.hip
+
+}  // namespace sprs_hip
+
+// The symbolic phase of a product, kept: per-task output counts and offsets, the task lists, the column-bucket table of
+// B.  What smmp::symbolic hands to smmp::numeric in the reference is C's indptr and indices (smmp.rs:81-131, 151-189);
+// here the plan additionally remembers how the work was cut, so that numeric launches the value kernels only.
+struct sprs_hip_spgemm_plan {
+    int32_t idx_bytes = 8, iptr_bytes = 8;
+    uint64_t rows = 0, inner = 0, b_cols = 0, nnz_a = 0, nnz_b = 0;
+    const void *a_indptr = nullptr, *a_indices = nullptr, *b_indptr = nullptr, *b_indices = nullptr;   // whose structure it describes
+    uint64_t ntask_total = 0, n_small = 0, n_large = 0, n_tiny = 0, c_nnz = 0, nb = 0;
+    int64_t winlog = 17;
+    sprs_hip::DevBuf bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, large_list, count, off;
+};
+
+namespace sprs_hip {
+
+namespace {
+
+int bits_of(uint64_t n) {
+    int b = 0;
+    while (b < 32 && (1ull << b) < n) ++b;
+    return b ? b : 1;
+}
+
 template <typename IDX, typename PTR>
-int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c_out, bool structure_only,
-                    sprs_hip_csmat *c_into) {
+CsrView<IDX, PTR> view_of(const sprs_hip_csmat *m) {
+    return CsrView<IDX, PTR>{(const PTR *)m->indptr, (const IDX *)m->indices, m->data, nullptr, 0};
+}
+
+// ---- symbolic phase: counts, offsets, task lists ---------------------------------------------------------
+template <typename IDX, typename PTR>
+int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_spgemm_plan *pl) {
     hipStream_t stream = nullptr;
     const uint64_t rows = a->rows, b_cols = b->cols;
-    CsrView<IDX, PTR> A{(const PTR *)a->indptr, (const IDX *)a->indices, a->data, nullptr, 0};
-    CsrView<IDX, PTR> B{(const PTR *)b->indptr, (const IDX *)b->indices, b->data, nullptr, 0};
-    // column-bucket table of B (4 bytes per 4096 columns per row) when it fits a budget of 8 GiB
-    DevBuf bucket;
+    pl->idx_bytes = (int32_t)sizeof(IDX);
+    pl->iptr_bytes = (int32_t)sizeof(PTR);
+    pl->rows = rows;
+    pl->inner = a->cols;
+    pl->b_cols = b_cols;
+    pl->nnz_a = a->nnz;
+    pl->nnz_b = b->nnz;
+    pl->a_indptr = a->indptr;
+    pl->a_indices = a->indices;
+    pl->b_indptr = b->indptr;
+    pl->b_indices = b->indices;
+    pl->winlog = options().spgemm_winlog;
+    CsrView<IDX, PTR> A = view_of<IDX, PTR>(a), B = view_of<IDX, PTR>(b);
+    // column-bucket table of B (4 bytes per 2048 columns per row): only when it stays within a small multiple of B's own
+    // size and is not pointless (every row of B has at most one entry); on allocation failure: binary searches instead
     {
         const uint64_t nb = (b_cols >> BUCKET_LOG2) + 2;
         const uint64_t bytes = b->rows * nb * sizeof(uint32_t);
-        if (options().spgemm_bucket && b->rows && bytes <= (8ull << 30)) {
-            SPRS_TRY_HIP(bucket.alloc(bytes));
-            uint64_t blocks = (b->rows + 3) / 4;
-            if (blocks > 256 * 64) blocks = 256 * 64;
-            hipLaunchKernelGGL((build_bucket_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, B.indptr,
-                               B.indices, b->rows, nb, bucket.as<uint32_t>());
-            SPRS_TRY_HIP(hipGetLastError());
-            B.bucket = bucket.as<uint32_t>();
-            B.nb = nb;
+        const uint64_t b_bytes = b->nnz * (8 + sizeof(IDX)) + (b->rows + 1) * sizeof(PTR);
+        if (options().spgemm_bucket && b->rows && b->nnz > b->rows && bytes <= (8ull << 30) && bytes <= 4 * b_bytes + (64ull << 20)) {
+            if (pl->bucket.alloc(bytes) == hipSuccess) {
+                uint64_t blocks = (b->rows + 3) / 4;
+                if (blocks > 256 * 64) blocks = 256 * 64;
+                hipLaunchKernelGGL((build_bucket_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, B.indptr,
+                                   B.indices, b->rows, nb, pl->bucket.as<uint32_t>());
+                SPRS_TRY_HIP(hipGetLastError());
+                pl->nb = nb;
+            } else {
+                (void)hipGetLastError();
+                clear_error();
+            }
         }
     }
+    B.bucket = pl->nb ? pl->bucket.as<uint32_t>() : nullptr;
+    B.nb = pl->nb;
 
-    DevBuf ub, ntasks, first_task, counters, wlog;
-    SPRS_TRY_HIP(wlog.alloc(rows));
-    SPRS_TRY_HIP(ub.alloc(rows * 8));
-    SPRS_TRY_HIP(ntasks.alloc(rows * 8));
-    SPRS_TRY_HIP(first_task.alloc((rows + 1) * 8));
-    SPRS_TRY_HIP(counters.alloc(32));
-    SPRS_TRY_HIP(hipMemsetAsync(counters.p, 0, 32, stream));
-    uint64_t ntask_total = 0;
+    DevBuf is_tiny, is_small, n_large_r, pos_tiny, pos_small, pos_large, large_key;
+    SPRS_TRY_HIP(pl->wlog.alloc(rows));
+    SPRS_TRY_HIP(pl->ub.alloc(rows * 8));
+    SPRS_TRY_HIP(pl->ntasks.alloc(rows * 8));
+    SPRS_TRY_HIP(pl->first_task.alloc((rows + 1) * 8));
+    SPRS_TRY_HIP(is_tiny.alloc(rows * 8));
+    SPRS_TRY_HIP(is_small.alloc(rows * 8));
+    SPRS_TRY_HIP(n_large_r.alloc(rows * 8));
+    SPRS_TRY_HIP(pos_tiny.alloc((rows + 1) * 8));
+    SPRS_TRY_HIP(pos_small.alloc((rows + 1) * 8));
+    SPRS_TRY_HIP(pos_large.alloc((rows + 1) * 8));
+    const dim3 rgrid((unsigned)((rows + 255) / 256)), rblock(256);
     if (rows) {
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
                            (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint32_t)options().spgemm_minwin,
-                           ub.as<uint64_t>(), ntasks.as<uint64_t>(), wlog.as<uint8_t>());
+                           pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>());
+        SPRS_TRY_HIP(hipGetLastError());
+        hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), rows,
+                           is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), n_large_r.as<uint64_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
-    SPRS_TRY(exclusive_scan_u64(ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows, stream));
-    SPRS_TRY_HIP(hipMemcpy(&ntask_total, first_task.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
+    SPRS_TRY(exclusive_scan_u64(pl->ntasks.as<uint64_t>(), pl->first_task.as<uint64_t>(), rows, stream));
+    SPRS_TRY(exclusive_scan_u64(is_tiny.as<uint64_t>(), pos_tiny.as<uint64_t>(), rows, stream));
+    SPRS_TRY(exclusive_scan_u64(is_small.as<uint64_t>(), pos_small.as<uint64_t>(), rows, stream));
+    SPRS_TRY(exclusive_scan_u64(n_large_r.as<uint64_t>(), pos_large.as<uint64_t>(), rows, stream));
+    SPRS_TRY_HIP(hipMemcpy(&pl->ntask_total, pl->first_task.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
+    SPRS_TRY_HIP(hipMemcpy(&pl->n_tiny, pos_tiny.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
+    SPRS_TRY_HIP(hipMemcpy(&pl->n_small, pos_small.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
+    SPRS_TRY_HIP(hipMemcpy(&pl->n_large, pos_large.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
+    const uint64_t ntask_total = pl->ntask_total, n_small = pl->n_small, n_large = pl->n_large, n_tiny = pl->n_tiny;
+    if (n_large > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many SpGEMM tasks for one launch");
 
-    DevBuf task_row, small_list, large_list, count, off;
-    SPRS_TRY_HIP(task_row.alloc(ntask_total * 8));
-    SPRS_TRY_HIP(small_list.alloc(ntask_total * 8));
-    SPRS_TRY_HIP(large_list.alloc(ntask_total * 8));
-    SPRS_TRY_HIP(count.alloc(ntask_total * 8));
-    SPRS_TRY_HIP(off.alloc((ntask_total + 1) * 8));
-    uint64_t n_small = 0, n_large = 0, n_tiny = 0;
+    SPRS_TRY_HIP(pl->task_row.alloc(ntask_total * 8));
+    SPRS_TRY_HIP(pl->tiny_list.alloc(n_tiny * 8));
+    SPRS_TRY_HIP(pl->small_list.alloc(n_small * 8));
+    SPRS_TRY_HIP(pl->large_list.alloc(n_large * 8));
+    SPRS_TRY_HIP(large_key.alloc(n_large * 8));
+    SPRS_TRY_HIP(pl->count.alloc(ntask_total * 8));
+    SPRS_TRY_HIP(pl->off.alloc((ntask_total + 1) * 8));
     if (ntask_total) {
-        hipLaunchKernelGGL(make_tasks_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream,
-                           ub.as<uint64_t>(), ntasks.as<uint64_t>(), first_task.as<uint64_t>(), rows,
-                           task_row.as<uint64_t>(), small_list.as<uint64_t>(), large_list.as<uint64_t>(),
-                           ntask_total, counters.as<unsigned long long>());
+        hipLaunchKernelGGL(make_tasks_kernel, rgrid, rblock, 0, stream, pl->ntasks.as<uint64_t>(), pl->first_task.as<uint64_t>(),
+                           pl->wlog.as<uint8_t>(), rows, pos_tiny.as<uint64_t>(), pos_small.as<uint64_t>(), pos_large.as<uint64_t>(),
+                           is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->tiny_list.as<uint64_t>(),
+                           pl->small_list.as<uint64_t>(), pl->large_list.as<uint64_t>(), large_key.as<uint64_t>());
         SPRS_TRY_HIP(hipGetLastError());
-        uint64_t h[3];
-        SPRS_TRY_HIP(hipMemcpy(h, counters.p, 24, hipMemcpyDeviceToHost));
-        n_small = h[0];
-        n_large = h[1];
-        n_tiny = h[2];
     }
+    // window-major order of the large tasks: stable sort by (first column of the window, row)
+    if (n_large > 1 && rows <= 0xFFFFFFFFull && options().spgemm_task_order != 2)
+        SPRS_TRY(radix_sort_pairs(large_key.as<uint64_t>(), pl->large_list.as<uint64_t>(), n_large,
+                                  {{0, bits_of(rows)}, {32, bits_of(b_cols)}}, stream));
+
     auto small_grid = [&](uint64_t n_tasks) {
         uint64_t g = (n_tasks + SM_WAVES - 1) / SM_WAVES;
         if (g > 256 * 32) g = 256 * 32;
         return dim3((unsigned)g);
     };
-    const uint64_t *tiny_list = small_list.as<uint64_t>() + (ntask_total - n_tiny);
-    if (n_large > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many SpGEMM tasks for one launch");
-
-    // ---- symbolic ----------------------------------------------------------
     if (n_tiny) {
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, stream,
-                           A, B, tiny_list, n_tiny, task_row.as<uint64_t>(), ub.as<uint64_t>(), count.as<uint64_t>(),
-                           (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
+                           A, B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
+                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
         SPRS_TRY_HIP(hipGetLastError());
     }
     if (n_small) {
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, stream,
-                           A, B, small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
-                           count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
+                           A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
+                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
         SPRS_TRY_HIP(hipGetLastError());
     }
     // ONE launch for all large tasks, in the LDS layout of the widest window (option spgemm_winlog).  Splitting
@@ -917,9 +1017,9 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
 #define SPRS_LG_SYM(WL)                                                                                              \
     hipLaunchKernelGGL((large_symbolic_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, b_cols,                       \
-                       large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),                \
-                       ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>())
-        switch (options().spgemm_winlog) {
+                       pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
+                       pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>())
+        switch (pl->winlog) {
             case 16: SPRS_LG_SYM(16); break;
             case 18: SPRS_LG_SYM(18); break;
             case 19: SPRS_LG_SYM(19); break;
@@ -928,41 +1028,31 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
 #undef SPRS_LG_SYM
         SPRS_TRY_HIP(hipGetLastError());
     }
-
     // ---- prefix sum of the counts -> offsets, C.indptr (smmp.rs:320-331) ----
-    SPRS_TRY(exclusive_scan_u64(count.as<uint64_t>(), off.as<uint64_t>(), ntask_total, stream));
-    uint64_t c_nnz = 0;
-    SPRS_TRY_HIP(hipMemcpy(&c_nnz, off.as<uint64_t>() + ntask_total, 8, hipMemcpyDeviceToHost));
-    if (sizeof(PTR) == 4 && c_nnz > 0xFFFFFFFFull)
+    SPRS_TRY(exclusive_scan_u64(pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), ntask_total, stream));
+    SPRS_TRY_HIP(hipMemcpy(&pl->c_nnz, pl->off.as<uint64_t>() + ntask_total, 8, hipMemcpyDeviceToHost));
+    if (sizeof(PTR) == 4 && pl->c_nnz > 0xFFFFFFFFull)
         SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Index type is not large enough to hold the nnz of the product (%llu)",
-                  (unsigned long long)c_nnz);   // Iptr::from_usize, smmp.rs:121
+                  (unsigned long long)pl->c_nnz);   // Iptr::from_usize, smmp.rs:121
+    return SPRS_HIP_OK;
+}
 
-    sprs_hip_csmat *c = nullptr;
-    if (c_into) {
-        // smmp::numeric (smmp.rs:151-189) fills the values of a matrix that already has the product's
-        // structure (the one smmp::symbolic produced): check it instead of trusting it
-        if (c_into->nnz != c_nnz)
-            SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "numeric: C holds %llu entries, the product has %llu",
-                      (unsigned long long)c_into->nnz, (unsigned long long)c_nnz);
-        DevBuf flag;
-        SPRS_TRY_HIP(flag.alloc(4));
-        SPRS_TRY_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
-        hipLaunchKernelGGL((compare_indptr_kernel<PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream,
-                           first_task.as<uint64_t>(), off.as<uint64_t>(), rows, (const PTR *)c_into->indptr,
-                           flag.as<unsigned int>());
-        unsigned int bad = 0;
-        SPRS_TRY_HIP(hipMemcpy(&bad, flag.p, 4, hipMemcpyDeviceToHost));
-        if (bad) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "numeric: the indptr of C is not the product's");
-        c = c_into;
-    } else {
-        SPRS_TRY(alloc_csmat(&c, SPRS_HIP_CSR, rows, b_cols, c_nnz, (int32_t)sizeof(PTR), (int32_t)sizeof(IDX)));
-        hipLaunchKernelGGL((write_indptr_kernel<PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream,
-                           first_task.as<uint64_t>(), off.as<uint64_t>(), rows, (PTR *)c->indptr);
-        if (structure_only) SPRS_TRY_HIP(hipMemsetAsync(c->data, 0, (c_nnz ? c_nnz : 1) * sizeof(double), stream));
-    }
-    double *c_values = structure_only ? nullptr : c->data;
-
-    // ---- numeric -------------------------------------------------------------
+// ---- numeric phase: indices (optional) and values into a matrix of the product's structure -------------------------
+template <typename IDX, typename PTR>
+int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c, bool values,
+                 bool indices) {
+    hipStream_t stream = nullptr;
+    CsrView<IDX, PTR> A = view_of<IDX, PTR>(a), B = view_of<IDX, PTR>(b);
+    B.bucket = pl->nb ? pl->bucket.as<uint32_t>() : nullptr;
+    B.nb = pl->nb;
+    const uint64_t n_tiny = pl->n_tiny, n_small = pl->n_small, n_large = pl->n_large;
+    double *c_values = values ? c->data : nullptr;
+    IDX *c_indices = indices ? (IDX *)c->indices : nullptr;
+    auto small_grid = [&](uint64_t n_tasks) {
+        uint64_t g = (n_tasks + SM_WAVES - 1) / SM_WAVES;
+        if (g > 256 * 32) g = 256 * 32;
+        return dim3((unsigned)g);
+    };
     DevBuf prof;
     if (options().spgemm_prof) {
         SPRS_TRY_HIP(prof.alloc(128));
@@ -970,20 +1060,20 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     }
     if (n_tiny)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, stream, A,
-                           B, tiny_list, n_tiny, task_row.as<uint64_t>(), ub.as<uint64_t>(), count.as<uint64_t>(),
-                           off.as<uint64_t>(), (IDX *)c->indices, c_values);
+                           B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
+                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
     if (n_small)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, stream,
-                           A, B, small_list.as<uint64_t>(), n_small, task_row.as<uint64_t>(), ub.as<uint64_t>(),
-                           count.as<uint64_t>(), off.as<uint64_t>(), (IDX *)c->indices, c_values);
+                           A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
+                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
 #define SPRS_LG_NUM(WL)                                                                                              \
-    hipLaunchKernelGGL((large_numeric_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, b_cols,                        \
-                       large_list.as<uint64_t>(), task_row.as<uint64_t>(), first_task.as<uint64_t>(),                \
-                       ntasks.as<uint64_t>(), wlog.as<uint8_t>(), count.as<uint64_t>(), off.as<uint64_t>(),          \
-                       (IDX *)c->indices, c_values, prof.as<unsigned long long>())
-        switch (options().spgemm_winlog) {
+    hipLaunchKernelGGL((large_numeric_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, pl->b_cols,                    \
+                       pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
+                       pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(),                  \
+                       pl->off.as<uint64_t>(), c_indices, c_values, prof.as<unsigned long long>())
+        switch (pl->winlog) {
             case 16: SPRS_LG_NUM(16); break;
             case 18: SPRS_LG_NUM(18); break;
             case 19: SPRS_LG_NUM(19); break;
@@ -993,10 +1083,7 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) {
-        if (!c_into) sprs_hip_csmat_free(c);
-        return fail_hip(e, "spgemm numeric");
-    }
+    if (e != hipSuccess) return fail_hip(e, "spgemm numeric");
     if (prof.p) {
         unsigned long long h[16];
         if (hipMemcpy(h, prof.p, 128, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -1009,33 +1096,125 @@ int32_t spgemm_impl(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_c
                     h[1], h[6]);
         }
     }
-    if (c_out) *c_out = c;
     return SPRS_HIP_OK;
 }
 
-}  // namespace
-
-static int32_t spgemm_dispatch(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c, bool structure_only,
-                               sprs_hip_csmat *c_into) {
-    if (b->cols > 0xFFFFFFFEull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "SpGEMM: more than 2^32-2 columns is not supported");
-    if (a->idx_bytes == 8 && a->iptr_bytes == 8) return spgemm_impl<uint64_t, uint64_t>(a, b, c, structure_only, c_into);
-    if (a->idx_bytes == 4 && a->iptr_bytes == 8) return spgemm_impl<uint32_t, uint64_t>(a, b, c, structure_only, c_into);
-    if (a->idx_bytes == 8 && a->iptr_bytes == 4) return spgemm_impl<uint64_t, uint32_t>(a, b, c, structure_only, c_into);
-    return spgemm_impl<uint32_t, uint32_t>(a, b, c, structure_only, c_into);
+template <typename PTR>
+int32_t plan_indptr(sprs_hip_spgemm_plan *pl, sprs_hip_csmat *c, bool compare) {
+    hipStream_t stream = nullptr;
+    const dim3 g((unsigned)((pl->rows + 256) / 256)), b(256);
+    if (!compare) {
+        hipLaunchKernelGGL((write_indptr_kernel<PTR>), g, b, 0, stream, pl->first_task.as<uint64_t>(), pl->off.as<uint64_t>(),
+                           pl->rows, (PTR *)c->indptr);
+        SPRS_TRY_HIP(hipGetLastError());
+        return SPRS_HIP_OK;
+    }
+    DevBuf flag;
+    SPRS_TRY_HIP(flag.alloc(4));
+    SPRS_TRY_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+    hipLaunchKernelGGL((compare_indptr_kernel<PTR>), g, b, 0, stream, pl->first_task.as<uint64_t>(), pl->off.as<uint64_t>(),
+                       pl->rows, (const PTR *)c->indptr, flag.as<unsigned int>());
+    unsigned int bad = 0;
+    SPRS_TRY_HIP(hipMemcpy(&bad, flag.p, 4, hipMemcpyDeviceToHost));
+    if (bad) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "numeric: the indptr of C is not the product's");
+    return SPRS_HIP_OK;
 }
 
+#define SPRS_SPGEMM_DISPATCH(pl, CALL)                                                   \
+    ((pl)->idx_bytes == 8 && (pl)->iptr_bytes == 8   ? CALL(uint64_t, uint64_t)          \
+     : (pl)->idx_bytes == 4 && (pl)->iptr_bytes == 8 ? CALL(uint32_t, uint64_t)          \
+     : (pl)->idx_bytes == 8                          ? CALL(uint64_t, uint32_t)          \
+                                                     : CALL(uint32_t, uint32_t))
+
+}  // namespace
+
+int32_t spgemm_plan_create(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_spgemm_plan **out) {
+    if (b->cols > 0xFFFFFFFEull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "SpGEMM: more than 2^32-2 columns is not supported");
+    auto *pl = new sprs_hip_spgemm_plan();
+    pl->idx_bytes = a->idx_bytes;
+    pl->iptr_bytes = a->iptr_bytes;
+#define SPRS_CALL(I, P) plan_build<I, P>(a, b, pl)
+    const int32_t st = SPRS_SPGEMM_DISPATCH(pl, SPRS_CALL);
+#undef SPRS_CALL
+    if (st != SPRS_HIP_OK) {
+        delete pl;
+        return st;
+    }
+    *out = pl;
+    return SPRS_HIP_OK;
+}
+
+void spgemm_plan_free(sprs_hip_spgemm_plan *pl) { delete pl; }
+
+static int32_t plan_matches(const sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_hip_csmat *b) {
+    if (pl->rows != a->rows || pl->inner != a->cols || pl->b_cols != b->cols || pl->nnz_a != a->nnz || pl->nnz_b != b->nnz ||
+        pl->idx_bytes != a->idx_bytes || pl->iptr_bytes != a->iptr_bytes || pl->a_indptr != a->indptr || pl->a_indices != a->indices ||
+        pl->b_indptr != b->indptr || pl->b_indices != b->indices)
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "the plan was made for other operands (shape, index types or structure buffers differ)");
+    return SPRS_HIP_OK;
+}
+
+// structure of the product as a new matrix (values zero): what smmp::symbolic returns
+int32_t spgemm_plan_structure(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **out,
+                              bool with_values) {
+    SPRS_TRY(plan_matches(pl, a, b));
+    sprs_hip_csmat *c = nullptr;
+    SPRS_TRY(alloc_csmat(&c, SPRS_HIP_CSR, pl->rows, pl->b_cols, pl->c_nnz, pl->iptr_bytes, pl->idx_bytes));
+    int32_t st = pl->iptr_bytes == 8 ? plan_indptr<uint64_t>(pl, c, false) : plan_indptr<uint32_t>(pl, c, false);
+    if (st == SPRS_HIP_OK && !with_values) {
+        const hipError_t e = hipMemsetAsync(c->data, 0, (pl->c_nnz ? pl->c_nnz : 1) * sizeof(double), nullptr);
+        if (e != hipSuccess) st = fail_hip(e, "spgemm structure");
+    }
+#define SPRS_CALL(I, P) plan_run<I, P>(pl, a, b, c, with_values, true)
+    if (st == SPRS_HIP_OK) st = SPRS_SPGEMM_DISPATCH(pl, SPRS_CALL);
+#undef SPRS_CALL
+    if (st != SPRS_HIP_OK) {
+        sprs_hip_csmat_free(c);
+        return st;
+    }
+    *out = c;
+    return SPRS_HIP_OK;
+}
+
+// values into a matrix that already has the product's structure (smmp::numeric, smmp.rs:151-189): shape, nnz and indptr
+// are checked; the indices of c are neither read nor written
+int32_t spgemm_plan_numeric(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c) {
+    SPRS_TRY(plan_matches(pl, a, b));
+    if (c->nnz != pl->c_nnz)
+        SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "numeric: C holds %llu entries, the product has %llu", (unsigned long long)c->nnz,
+                  (unsigned long long)pl->c_nnz);
+    SPRS_TRY(pl->iptr_bytes == 8 ? plan_indptr<uint64_t>(pl, c, true) : plan_indptr<uint32_t>(pl, c, true));
+#define SPRS_CALL(I, P) plan_run<I, P>(pl, a, b, c, true, false)
+    return SPRS_SPGEMM_DISPATCH(pl, SPRS_CALL);
+#undef SPRS_CALL
+}
+
+uint64_t spgemm_plan_nnz(const sprs_hip_spgemm_plan *pl) { return pl->c_nnz; }
+
 int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
-    return spgemm_dispatch(a, b, c, false, nullptr);
+    sprs_hip_spgemm_plan *pl = nullptr;
+    SPRS_TRY(spgemm_plan_create(a, b, &pl));
+    const int32_t st = spgemm_plan_structure(pl, a, b, c, true);
+    spgemm_plan_free(pl);
+    return st;
 }
 
 // smmp::symbolic (smmp.rs:81-131): structure only; the values of the result are zero
 int32_t spgemm_symbolic(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {
-    return spgemm_dispatch(a, b, c, true, nullptr);
+    sprs_hip_spgemm_plan *pl = nullptr;
+    SPRS_TRY(spgemm_plan_create(a, b, &pl));
+    const int32_t st = spgemm_plan_structure(pl, a, b, c, false);
+    spgemm_plan_free(pl);
+    return st;
 }
 
-// smmp::numeric (smmp.rs:151-189): values into a matrix that has the product's structure
+// smmp::numeric (smmp.rs:151-189) without a kept plan: the symbolic phase is redone to check c and to cut the work
 int32_t spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c) {
-    return spgemm_dispatch(a, b, nullptr, false, c);
+    sprs_hip_spgemm_plan *pl = nullptr;
+    SPRS_TRY(spgemm_plan_create(a, b, &pl));
+    const int32_t st = spgemm_plan_numeric(pl, a, b, c);
+    spgemm_plan_free(pl);
+    return st;
 }
 
 }  // namespace sprs_hip

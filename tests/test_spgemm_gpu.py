@@ -257,7 +257,7 @@ def test_result_pool_reuse_and_trim(hip):
     del c1
     assert hip.get_option("pool_cached_bytes") >= nbytes            # both blocks came back
     c2 = a * a                                                       # ... and serve the next result
-    assert hip.get_option("pool_cached_bytes") == 0
+    assert hip.get_option("pool_cached_bytes") < nbytes              # (what is cached now: the product's own temporaries)
     for x, y in zip(ref[1:], c2.to_host()[1:]):
         assert np.array_equal(x, y)
     del c2
@@ -409,3 +409,65 @@ def test_config5_five_products_bit_identical(hip):
         del c
     assert prints[0][0] > 3_000_000_000
     assert all(p == prints[0] for p in prints[1:]), prints
+
+
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_kept_plan_symbolic_numeric_split(hip, idx, ptr):
+    """sprs_hip_spgemm_plan_*: the symbolic phase kept between smmp::symbolic and smmp::numeric (smmp.rs:81-131,
+    151-189).  plan.product() == a * b bit for bit; plan.structure() == symbolic(a, b); plan.numeric(c) fills the values
+    of a c with that structure — also after the VALUES of a changed in place — and leaves c's indices alone; a plan
+    refuses other operands and a c of another structure."""
+    from sprs_amd import gen, smmp
+    from sprs_amd.device import DeviceCsMat
+    n = 20000
+    indptr, indices, data = gen.rmat_csr(n, 10, seed=21)
+    ip, ix, dt = indptr.numpy().astype(ptr), indices.numpy().astype(idx), data.numpy()
+    a = DeviceCsMat.from_host((n, n), ip, ix, dt)
+    full = (a * a).to_host()
+    plan = smmp.SpgemmPlan(a, a)
+    assert plan.nnz() == full[3].size
+    for x, y in zip(full[1:], plan.product().to_host()[1:]):
+        assert np.array_equal(x, y)
+    st = plan.structure()
+    sh, sip, six, sdt = st.to_host()
+    assert np.array_equal(sip, full[1]) and np.array_equal(six, full[2]) and not sdt.any()
+    plan.numeric(st)                                             # value kernels only
+    assert np.array_equal(st.to_host()[3], full[3]) and np.array_equal(st.to_host()[2], full[2])
+    # new values, same structure: a second matrix sharing nothing but the pattern gives the reference result
+    dt2 = dt * 3.0 + 1.0
+    a2 = DeviceCsMat.from_host((n, n), ip, ix, dt2)
+    want = (a2 * a2).to_host()
+    with pytest.raises(hip.SprsHipError) as e:                   # the plan belongs to (a, a)
+        plan_for_other(hip, plan, a2, st)
+    assert e.value.status == hip._ffi.INVALID_ARG
+    plan2 = smmp.SpgemmPlan(a2, a2)
+    plan2.numeric(st)                                            # same structure, other values
+    assert np.array_equal(st.to_host()[3], want[3])
+    other = (a2 * DeviceCsMat.eye(n, idx, ptr))                  # a matrix with another structure
+    with pytest.raises(hip.SprsHipError) as e:
+        plan2.numeric(other)
+    assert e.value.status == hip._ffi.BAD_STRUCTURE
+
+
+def plan_for_other(hip, plan, a2, c):
+    import ctypes as C
+    from sprs_amd._ffi import check, lib
+    check(lib.sprs_hip_spgemm_plan_numeric(plan._h, a2._h, a2._h, c._h))
+
+
+def test_task_order_does_not_change_the_result(hip):
+    """window-major (default) and row-major order of the large-row tasks: same bits (the order only decides which
+    tasks run side by side)"""
+    from sprs_amd import gen
+    from sprs_amd.device import DeviceCsMat
+    n = 30000
+    indptr, indices, data = gen.rmat_csr(n, 12, seed=5)
+    a = DeviceCsMat.from_host((n, n), indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy())
+    r1 = (a * a).to_host()
+    hip.set_option("spgemm_task_order", 2)
+    try:
+        r2 = (a * a).to_host()
+    finally:
+        hip.set_option("spgemm_task_order", 0)
+    for x, y in zip(r1[1:], r2[1:]):
+        assert np.array_equal(x, y)
