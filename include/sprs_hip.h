@@ -90,6 +90,10 @@ typedef struct sprs_hip_csmat sprs_hip_csmat;
  * validate != 0 runs check_compressed_structure (sparse.rs:300-358) first and
  * returns SPRS_HIP_BAD_STRUCTURE where CsMat::new would panic; validate == 0
  * is new_trusted / new_unchecked (csmat.rs:265-301). */
+/* Index widths: 4 or 8 bytes on the device.  Host arrays may also be 2 bytes wide (sprs' u16 / i16, indexing.rs:124-130):
+ * they are widened to 4 bytes on upload, sprs_hip_csmat_info keeps reporting 2, downloads narrow again, and every
+ * result derived from such a matrix is checked against the 2-byte range where the reference's I::from_usize /
+ * Iptr::from_usize would panic (SPRS_HIP_INDEX_OVERFLOW; sprs/tests/gh374.rs is reproduced literally). */
 int32_t sprs_hip_csmat_upload(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols,
                               const void *indptr, int32_t iptr_bytes, const void *indices,
                               int32_t idx_bytes, const double *data, int32_t validate);
@@ -249,6 +253,12 @@ int32_t sprs_hip_spgemm_plan_free(sprs_hip_spgemm_plan *plan);
  * (csmat.rs:1405-1426, 1782-1829): new owning handle with the other storage
  * order.  SPRS_HIP_INDEX_OVERFLOW where the reference panics (csmat.rs:1794). */
 int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out);
+
+/* `&lhs * &rhs` for two sparse matrices: csmat_mul_csmat (csmat.rs:1895-1949), the storage dispatch around
+ * smmp::mul_csr_csr — (CSR,CSR) multiplies directly, (CSR,CSC) converts the rhs, (CSC,*) multiplies the transpose
+ * views the other way round and transposes back; the result has the storage of the lhs.  This is what the `Mul` impls
+ * of the host mirrors call.  Status codes as sprs_hip_spgemm_f64 and sprs_hip_csmat_to_other_storage. */
+int32_t sprs_hip_csmat_mul_csmat(const sprs_hip_csmat *lhs, const sprs_hip_csmat *rhs, sprs_hip_csmat **out);
 
 /* Triplet (COO) assembly: twin of TriMatBase::to_csr / to_csc (triplet.rs:262-276) = TriMatIter::into_cs
  * (triplet_iter.rs:127-224): the n triplets (row_inds[p], col_inds[p], data[p]) — arrays in DEVICE memory, indices of

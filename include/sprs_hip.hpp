@@ -163,7 +163,12 @@ inline DeviceVec operator*(const DeviceCsMat &a, const DeviceVec &x) {
 }
 
 // `&A * &B` (csmat.rs:1866-1888)
-inline DeviceCsMat operator*(const DeviceCsMat &a, const DeviceCsMat &b) { return smmp::mul_csr_csr(a, b); }
+// `&A * &B`: csmat_mul_csmat (csmat.rs:1895-1949) — the storage dispatch is done below the C ABI
+inline DeviceCsMat operator*(const DeviceCsMat &a, const DeviceCsMat &b) {
+    sprs_hip_csmat *c = nullptr;
+    check(sprs_hip_csmat_mul_csmat(a.handle(), b.handle(), &c));
+    return DeviceCsMat(c);
+}
 
 // TriMatI<f64, usize> (sparse/triplet.rs:26-48) with the device assembly of `to_csr` (triplet.rs:270-276 ->
 // triplet_iter.rs:127-224: rows sorted, duplicates summed).  No dedicated kernel: with n triplets the matrix

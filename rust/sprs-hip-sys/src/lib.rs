@@ -105,6 +105,7 @@ extern "C" {
     pub fn sprs_hip_spgemm_plan_numeric(plan: *mut sprs_hip_spgemm_plan, a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_spgemm_plan_free(plan: *mut sprs_hip_spgemm_plan) -> i32;
     pub fn sprs_hip_csmat_to_other_storage(m: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_csmat_mul_csmat(lhs: *const sprs_hip_csmat, rhs: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_triplets_to_cs(
         rows: u64, cols: u64, n: u64, row_inds_dev: *const c_void, col_inds_dev: *const c_void, in_idx_bytes: i32,
         data_dev: *const f64, storage: i32, out_idx_bytes: i32, out_iptr_bytes: i32, out: *mut *mut sprs_hip_csmat,

@@ -104,19 +104,43 @@ impl DeviceCsMat {
         n as usize
     }
 
-    /// Download as a host `CsMatI` (usize/usize handles only in this sketch).
-    pub fn to_csmat(&self) -> CsMatI<f64, usize, usize> {
-        let (rows, cols) = self.shape();
-        let nnz = self.nnz();
-        let mut indptr = vec![0usize; rows + 1];
-        let mut indices = vec![0usize; nnz];
+    /// (rows, cols, nnz, indptr bytes, index bytes, storage) as the handle reports them.
+    fn info(&self) -> (usize, usize, usize, i32, i32, i32) {
+        let (mut r, mut c, mut n) = (0u64, 0u64, 0u64);
+        let (mut pb, mut ib, mut st) = (0i32, 0i32, 0i32);
+        unsafe { check(sys::sprs_hip_csmat_info(self.h, &mut r, &mut c, &mut n, &mut pb, &mut ib, &mut st)) };
+        (r as usize, c as usize, n as usize, pb, ib, st)
+    }
+
+    /// Download as a host `CsMatI<f64, usize, usize>`.  The handle may be CSR or CSC and may hold 2-, 4- or 8-byte
+    /// indices: the buffers are sized by the OUTER dimension and by the widths the handle reports, widened to usize,
+    /// and the real storage order goes into the constructor.
+    pub fn to_csmat(&self) -> Result<CsMatI<f64, usize, usize>, String> {
+        let (rows, cols, nnz, pb, ib, st) = self.info();
+        let storage = if st == sys::SPRS_HIP_CSR { sprs::CompressedStorage::CSR } else { sprs::CompressedStorage::CSC };
+        let outer = if st == sys::SPRS_HIP_CSR { rows } else { cols };
+        if ![2, 4, 8].contains(&pb) || ![2, 4, 8].contains(&ib) {
+            return Err(format!("unsupported index widths {}/{}", pb, ib));
+        }
+        // raw byte buffers of exactly the size sprs_hip_csmat_download writes
+        let mut ip_raw = vec![0u8; (outer + 1) * pb as usize];
+        let mut ix_raw = vec![0u8; nnz * ib as usize];
         let mut data = vec![0f64; nnz];
         unsafe {
-            check(sys::sprs_hip_csmat_download(self.h, indptr.as_mut_ptr() as *mut c_void, indices.as_mut_ptr() as *mut c_void, data.as_mut_ptr()));
+            check(sys::sprs_hip_csmat_download(self.h, ip_raw.as_mut_ptr() as *mut c_void, ix_raw.as_mut_ptr() as *mut c_void, data.as_mut_ptr()));
         }
-        // rows are sorted and in range by construction (smmp.rs:126): the
-        // unchecked constructor is what `new_trusted` is inside sprs (csmat.rs:265-301)
-        unsafe { CsMatI::new_unchecked(sprs::CompressedStorage::CSR, (rows, cols), indptr, indices, data) }
+        fn widen(raw: &[u8], bytes: i32) -> Vec<usize> {
+            match bytes {
+                2 => raw.chunks_exact(2).map(|c| u16::from_ne_bytes([c[0], c[1]]) as usize).collect(),
+                4 => raw.chunks_exact(4).map(|c| u32::from_ne_bytes([c[0], c[1], c[2], c[3]]) as usize).collect(),
+                _ => raw.chunks_exact(8).map(|c| u64::from_ne_bytes([c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]]) as usize).collect(),
+            }
+        }
+        let indptr = widen(&ip_raw, pb);
+        let indices = widen(&ix_raw, ib);
+        // the checked constructor: a few passes over the host copy, and no undefined behaviour if the device side ever
+        // handed back something malformed
+        CsMatI::try_new_from_storage(storage, (rows, cols), indptr, indices, data).map_err(|e| format!("{:?}", e))
     }
 }
 
@@ -213,6 +237,9 @@ impl<'a, 'b> std::ops::Mul<&'b DeviceVec> for &'a DeviceCsMat {
 impl<'a, 'b> std::ops::Mul<&'b DeviceCsMat> for &'a DeviceCsMat {
     type Output = DeviceCsMat;
     fn mul(self, rhs: &'b DeviceCsMat) -> DeviceCsMat {
-        smmp::mul_csr_csr(self, rhs)
+        // the storage dispatch of csmat_mul_csmat (csmat.rs:1895-1949) lives below the C ABI
+        let mut h: *mut sys::sprs_hip_csmat = std::ptr::null_mut();
+        unsafe { check(sys::sprs_hip_csmat_mul_csmat(self.h, rhs.h, &mut h)) };
+        DeviceCsMat { h }
     }
 }

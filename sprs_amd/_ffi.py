@@ -66,6 +66,7 @@ SIGNATURES = {
     "sprs_hip_spmm_rowmaj_f64": (i32, [vp, vp, u64, u64, u64, vp, u64, u64, i32, vp]),
     "sprs_hip_spgemm_f64": (i32, [vp, vp, P(vp)]),
     "sprs_hip_csmat_to_other_storage": (i32, [vp, P(vp)]),
+    "sprs_hip_csmat_mul_csmat": (i32, [vp, vp, P(vp)]),
     "sprs_hip_triplets_to_cs": (i32, [u64, u64, u64, vp, vp, i32, vp, i32, i32, i32, P(vp)]),
     "sprs_hip_set_option": (i32, [C.c_char_p, i64]),
     "sprs_hip_get_option": (i32, [C.c_char_p, P(i64)]),

@@ -220,9 +220,39 @@ static bool widths_ok(int32_t iptr_bytes, int32_t idx_bytes) {
     return (iptr_bytes == 4 || iptr_bytes == 8) && (idx_bytes == 4 || idx_bytes == 8);
 }
 
+static bool host_widths_ok(int32_t iptr_bytes, int32_t idx_bytes) {     // what a host array may hold: u16 too (indexing.rs:124-130)
+    return (iptr_bytes == 2 || iptr_bytes == 4 || iptr_bytes == 8) && (idx_bytes == 2 || idx_bytes == 4 || idx_bytes == 8);
+}
+
+static uint64_t width_max(int32_t bytes) { return bytes >= 8 ? ~0ull : ((1ull << (8 * bytes)) - 1ull); }
+
+int32_t inherit_declared_widths(sprs_hip_csmat *result, const sprs_hip_csmat *from) {
+    result->decl_idx_bytes = from->decl_idx_bytes;
+    result->decl_iptr_bytes = from->decl_iptr_bytes;
+    // I::from_usize on the inner dimension / indices, Iptr::from_usize on the nnz (sparse.rs:314-324, smmp.rs:121, csmat.rs:1794)
+    if (result->inner() && result->inner() - 1 > width_max(result->user_idx_bytes()))
+        SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Index type is not large enough to hold the number of rows requested (required %llu)",
+                  (unsigned long long)result->inner());
+    if (result->nnz > width_max(result->user_iptr_bytes()))
+        SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Index type is not large enough to hold the nnz of the result (%llu)", (unsigned long long)result->nnz);
+    return SPRS_HIP_OK;
+}
+
 }  // namespace sprs_hip
 
 using namespace sprs_hip;
+
+// a freshly made result takes the declared index widths of the operand it derives from; on overflow it is released
+static int32_t finish_result(sprs_hip_csmat **res, const sprs_hip_csmat *from) {
+    const int32_t st = inherit_declared_widths(*res, from);
+    if (st != SPRS_HIP_OK) {
+        const std::string keep = sprs_hip_last_error();
+        sprs_hip_csmat_free(*res);
+        *res = nullptr;
+        set_error(st, "%s", keep.c_str());
+    }
+    return st;
+}
 
 extern "C" {
 
@@ -308,9 +338,38 @@ int32_t sprs_hip_csmat_upload(sprs_hip_csmat **out, int32_t storage, uint64_t ro
     if (!out || !indptr) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     *out = nullptr;
     if (storage != SPRS_HIP_CSR && storage != SPRS_HIP_CSC) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "bad storage tag %d", storage);
-    if (!widths_ok(iptr_bytes, idx_bytes)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "index widths must be 4 or 8 bytes");
+    if (!host_widths_ok(iptr_bytes, idx_bytes)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "index widths must be 2, 4 or 8 bytes");
     const uint64_t outer = storage == SPRS_HIP_CSR ? rows : cols;
     const uint64_t inner = storage == SPRS_HIP_CSR ? cols : rows;
+    if (iptr_bytes == 2 || idx_bytes == 2) {
+        // 2-byte index types (u16 / i16 in sprs): widened to 4 bytes for the device, the declared widths remembered
+        const uint64_t first16 = iptr_bytes == 2 ? ((const uint16_t *)indptr)[0] : iptr_bytes == 4 ? ((const uint32_t *)indptr)[0] : ((const uint64_t *)indptr)[0];
+        const uint64_t last16 = iptr_bytes == 2 ? ((const uint16_t *)indptr)[outer] : iptr_bytes == 4 ? ((const uint32_t *)indptr)[outer] : ((const uint64_t *)indptr)[outer];
+        if (last16 < first16) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Unsorted indptr");
+        const uint64_t nnz16 = last16 - first16;
+        if (inner && inner - 1 > width_max(idx_bytes)) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Index type not large enough for this matrix");
+        if (outer + 1 > width_max(iptr_bytes) && iptr_bytes == 2 && nnz16 > width_max(2)) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Iptr type not large enough for this matrix");
+        std::vector<uint32_t> ip32, ix32;
+        const void *ipp = indptr, *ixp = indices;
+        int32_t ipb = iptr_bytes, ixb = idx_bytes;
+        if (iptr_bytes == 2) {
+            ip32.resize(outer + 1);
+            for (uint64_t i = 0; i <= outer; ++i) ip32[i] = ((const uint16_t *)indptr)[i];
+            ipp = ip32.data();
+            ipb = 4;
+        }
+        if (idx_bytes == 2) {
+            ix32.resize(nnz16 ? nnz16 : 1);
+            const uint16_t *src = (const uint16_t *)indices;   // points at the element addressed by indptr[0]
+            for (uint64_t i = 0; i < nnz16; ++i) ix32[i] = src[i];
+            ixp = nnz16 ? ix32.data() : indices;
+            ixb = 4;
+        }
+        SPRS_TRY(sprs_hip_csmat_upload(out, storage, rows, cols, ipp, ipb, ixp, ixb, data, validate));
+        (*out)->decl_iptr_bytes = iptr_bytes;
+        (*out)->decl_idx_bytes = idx_bytes;
+        return SPRS_HIP_OK;
+    }
     auto ip_at = [&](uint64_t i) -> uint64_t {
         return iptr_bytes == 8 ? ((const uint64_t *)indptr)[i] : ((const uint32_t *)indptr)[i];
     };
@@ -389,8 +448,8 @@ int32_t sprs_hip_csmat_info(const sprs_hip_csmat *m, uint64_t *rows, uint64_t *c
     if (rows) *rows = m->rows;
     if (cols) *cols = m->cols;
     if (nnz) *nnz = m->nnz;
-    if (iptr_bytes) *iptr_bytes = m->iptr_bytes;
-    if (idx_bytes) *idx_bytes = m->idx_bytes;
+    if (iptr_bytes) *iptr_bytes = m->user_iptr_bytes();       // the widths the caller declared (2-byte arrays live widened on the device)
+    if (idx_bytes) *idx_bytes = m->user_idx_bytes();
     if (storage) *storage = m->storage;
     return SPRS_HIP_OK;
 }
@@ -408,8 +467,21 @@ int32_t sprs_hip_csmat_device_ptrs(const sprs_hip_csmat *m, const void **indptr,
 int32_t sprs_hip_csmat_download(const sprs_hip_csmat *m, void *indptr, void *indices, double *data) {
     clear_error();
     if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
-    if (indptr) SPRS_TRY_HIP(hipMemcpy(indptr, m->indptr, (m->outer() + 1) * (uint64_t)m->iptr_bytes, hipMemcpyDeviceToHost));
-    if (indices && m->nnz) SPRS_TRY_HIP(hipMemcpy(indices, m->indices, m->nnz * (uint64_t)m->idx_bytes, hipMemcpyDeviceToHost));
+    auto fetch = [&](void *dst, const void *src, uint64_t count, int32_t dev_bytes, int32_t user_bytes) -> int32_t {
+        if (user_bytes == dev_bytes) {
+            SPRS_TRY_HIP(hipMemcpy(dst, src, count * (uint64_t)dev_bytes, hipMemcpyDeviceToHost));
+            return SPRS_HIP_OK;
+        }
+        std::vector<uint32_t> wide(count ? count : 1);          // declared 2 bytes, device 4: narrow (every value was range-checked when made)
+        SPRS_TRY_HIP(hipMemcpy(wide.data(), src, count * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < count; ++i) {
+            if (wide[i] > 0xFFFFu) SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Index type is not large enough to hold %u", wide[i]);
+            ((uint16_t *)dst)[i] = (uint16_t)wide[i];
+        }
+        return SPRS_HIP_OK;
+    };
+    if (indptr) SPRS_TRY(fetch(indptr, m->indptr, m->outer() + 1, m->iptr_bytes, m->user_iptr_bytes()));
+    if (indices && m->nnz) SPRS_TRY(fetch(indices, m->indices, m->nnz, m->idx_bytes, m->user_idx_bytes()));
     if (data && m->nnz) SPRS_TRY_HIP(hipMemcpy(data, m->data, m->nnz * sizeof(double), hipMemcpyDeviceToHost));
     return SPRS_HIP_OK;
 }
@@ -434,9 +506,22 @@ int32_t sprs_hip_csmat_download_outer(const sprs_hip_csmat *m, uint64_t start, u
         hi = b;
     }
     if (nnz_out) *nnz_out = hi - lo;
-    if (indptr_out) SPRS_TRY_HIP(hipMemcpy(indptr_out, (const uint8_t *)m->indptr + start * pb, (end - start + 1) * pb, hipMemcpyDeviceToHost));
+    auto fetch = [&](void *dst, const void *src, uint64_t count, int32_t dev_bytes, int32_t user_bytes) -> int32_t {
+        if (user_bytes == dev_bytes) {
+            SPRS_TRY_HIP(hipMemcpy(dst, src, count * (uint64_t)dev_bytes, hipMemcpyDeviceToHost));
+            return SPRS_HIP_OK;
+        }
+        std::vector<uint32_t> wide(count ? count : 1);          // declared 2 bytes, device 4
+        SPRS_TRY_HIP(hipMemcpy(wide.data(), src, count * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < count; ++i) {
+            if (wide[i] > 0xFFFFu) SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Index type is not large enough to hold %u", wide[i]);
+            ((uint16_t *)dst)[i] = (uint16_t)wide[i];
+        }
+        return SPRS_HIP_OK;
+    };
+    if (indptr_out) SPRS_TRY(fetch(indptr_out, (const uint8_t *)m->indptr + start * pb, end - start + 1, m->iptr_bytes, m->user_iptr_bytes()));
     if (indices_out && hi > lo)
-        SPRS_TRY_HIP(hipMemcpy(indices_out, (const uint8_t *)m->indices + lo * (uint64_t)m->idx_bytes, (hi - lo) * (uint64_t)m->idx_bytes, hipMemcpyDeviceToHost));
+        SPRS_TRY(fetch(indices_out, (const uint8_t *)m->indices + lo * (uint64_t)m->idx_bytes, hi - lo, m->idx_bytes, m->user_idx_bytes()));
     if (data_out && hi > lo) SPRS_TRY_HIP(hipMemcpy(data_out, m->data + lo, (hi - lo) * sizeof(double), hipMemcpyDeviceToHost));
     return SPRS_HIP_OK;
 }
@@ -487,6 +572,8 @@ int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **
     t->nnz = m->nnz;
     t->iptr_bytes = m->iptr_bytes;
     t->idx_bytes = m->idx_bytes;
+    t->decl_iptr_bytes = m->decl_iptr_bytes;
+    t->decl_idx_bytes = m->decl_idx_bytes;
     t->indptr = m->indptr;
     t->indices = m->indices;
     t->data = m->data;
@@ -566,7 +653,7 @@ int32_t sprs_hip_spmm_rowmaj_f64(const sprs_hip_csmat *a, const double *rhs_dev,
 static int32_t spgemm_contract(const sprs_hip_csmat *a, const sprs_hip_csmat *b) {
     if (a->cols != b->rows) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");   // smmp.rs:207
     if (a->storage != SPRS_HIP_CSR || b->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
-    if (a->iptr_bytes != b->iptr_bytes || a->idx_bytes != b->idx_bytes)
+    if (a->user_iptr_bytes() != b->user_iptr_bytes() || a->user_idx_bytes() != b->user_idx_bytes())
         SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "operands must share index types (smmp.rs:196-199)");
     return SPRS_HIP_OK;
 }
@@ -575,7 +662,7 @@ static int32_t numeric_target_ok(const sprs_hip_csmat *a, const sprs_hip_csmat *
     // smmp.rs:161-166: the asserts of numeric() on the shape of c
     if (c->rows != a->rows || c->cols != b->cols) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
     if (c->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
-    if (c->iptr_bytes != a->iptr_bytes || c->idx_bytes != a->idx_bytes)
+    if (c->user_iptr_bytes() != a->user_iptr_bytes() || c->user_idx_bytes() != a->user_idx_bytes())
         SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "C must share the operands' index types");
     return SPRS_HIP_OK;
 }
@@ -585,7 +672,8 @@ int32_t sprs_hip_spgemm_symbolic(const sprs_hip_csmat *a, const sprs_hip_csmat *
     if (!a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     *c = nullptr;
     SPRS_TRY(spgemm_contract(a, b));
-    return spgemm_symbolic(a, b, c);
+    SPRS_TRY(spgemm_symbolic(a, b, c));
+    return finish_result(c, a);
 }
 
 int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat *c) {
@@ -619,7 +707,8 @@ int32_t sprs_hip_spgemm_plan_structure(sprs_hip_spgemm_plan *plan, const sprs_hi
     clear_error();
     if (!plan || !a || !b || !c_structure) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     *c_structure = nullptr;
-    return spgemm_plan_structure(plan, a, b, c_structure, false);
+    SPRS_TRY(spgemm_plan_structure(plan, a, b, c_structure, false));
+    return finish_result(c_structure, a);
 }
 
 int32_t sprs_hip_spgemm_plan_product(sprs_hip_spgemm_plan *plan, const sprs_hip_csmat *a, const sprs_hip_csmat *b,
@@ -627,7 +716,8 @@ int32_t sprs_hip_spgemm_plan_product(sprs_hip_spgemm_plan *plan, const sprs_hip_
     clear_error();
     if (!plan || !a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     *c = nullptr;
-    return spgemm_plan_structure(plan, a, b, c, true);
+    SPRS_TRY(spgemm_plan_structure(plan, a, b, c, true));
+    return finish_result(c, a);
 }
 
 int32_t sprs_hip_spgemm_plan_numeric(sprs_hip_spgemm_plan *plan, const sprs_hip_csmat *a, const sprs_hip_csmat *b,
@@ -668,16 +758,84 @@ int32_t sprs_hip_spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sp
     *c = nullptr;
     if (a->cols != b->rows) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");   // smmp.rs:207
     if (a->storage != SPRS_HIP_CSR || b->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
-    if (a->iptr_bytes != b->iptr_bytes || a->idx_bytes != b->idx_bytes)
+    if (a->user_iptr_bytes() != b->user_iptr_bytes() || a->user_idx_bytes() != b->user_idx_bytes())
         SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "operands must share index types (smmp.rs:196-199)");
-    return spgemm_f64(a, b, c);
+    SPRS_TRY(spgemm_f64(a, b, c));
+    return finish_result(c, a);
+}
+
+// to_other_storage with the index-type check of the reference on the DECLARED widths (csmat.rs:1794-1797)
+static int32_t convert_checked(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
+    if (m->rows > width_max(m->user_idx_bytes()))
+        SPRS_FAIL(SPRS_HIP_INDEX_OVERFLOW, "Index type is not large enough to hold the number of rows requested (required %llu)",
+                  (unsigned long long)m->rows);
+    SPRS_TRY(to_other_storage(m, out));
+    return finish_result(out, m);
 }
 
 int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
     clear_error();
     if (!m || !out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     *out = nullptr;
-    return to_other_storage(m, out);
+    return convert_checked(m, out);
+}
+
+// `&lhs * &rhs` for two sparse matrices: csmat_mul_csmat (csmat.rs:1895-1949) — the storage dispatch around
+// smmp::mul_csr_csr; the result has the storage of the lhs.
+int32_t sprs_hip_csmat_mul_csmat(const sprs_hip_csmat *lhs, const sprs_hip_csmat *rhs, sprs_hip_csmat **out) {
+    clear_error();
+    if (!lhs || !rhs || !out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    if (lhs->cols != rhs->rows) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if (lhs->user_iptr_bytes() != rhs->user_iptr_bytes() || lhs->user_idx_bytes() != rhs->user_idx_bytes())
+        SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "operands must share index types (smmp.rs:196-199)");
+    auto view_t = [](const sprs_hip_csmat *m, sprs_hip_csmat &t) {      // transpose_view (csmat.rs:982-991): free, flips the tag
+        t.storage = m->storage == SPRS_HIP_CSR ? SPRS_HIP_CSC : SPRS_HIP_CSR;
+        t.rows = m->cols;
+        t.cols = m->rows;
+        t.nnz = m->nnz;
+        t.iptr_bytes = m->iptr_bytes;
+        t.idx_bytes = m->idx_bytes;
+        t.decl_iptr_bytes = m->decl_iptr_bytes;
+        t.decl_idx_bytes = m->decl_idx_bytes;
+        t.indptr = m->indptr;
+        t.indices = m->indices;
+        t.data = m->data;
+        t.owns = false;
+        t.device = m->device;
+    };
+    struct Owned {
+        sprs_hip_csmat *h = nullptr;
+        ~Owned() {
+            if (h) sprs_hip_csmat_free(h);
+        }
+    };
+    const bool l_csr = lhs->storage == SPRS_HIP_CSR, r_csr = rhs->storage == SPRS_HIP_CSR;
+    if (l_csr && r_csr) {                                         // (CSR, CSR)
+        SPRS_TRY(spgemm_f64(lhs, rhs, out));
+        return finish_result(out, lhs);
+    }
+    if (l_csr) {                                                  // (CSR, CSC): rhs.to_other_storage()
+        Owned conv;
+        SPRS_TRY(convert_checked(rhs, &conv.h));
+        SPRS_TRY(spgemm_f64(lhs, conv.h, out));
+        return finish_result(out, lhs);
+    }
+    // lhs is CSC: (rhs^T * lhs^T)^T on the transpose views, which are CSR; transpose_into flips the result back
+    Owned conv;
+    const sprs_hip_csmat *r = rhs;
+    if (r_csr) {                                                  // (CSC, CSR): rhs.to_other_storage() first
+        SPRS_TRY(convert_checked(rhs, &conv.h));
+        r = conv.h;
+    }
+    sprs_hip_csmat rt, lt;
+    view_t(r, rt);
+    view_t(lhs, lt);
+    SPRS_TRY(spgemm_f64(&rt, &lt, out));
+    sprs_hip_csmat *c = *out;                                     // transpose_into: same buffers, other tag
+    c->storage = SPRS_HIP_CSC;
+    std::swap(c->rows, c->cols);
+    return finish_result(out, lhs);
 }
 
 int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end, sprs_hip_csmat **out) {
@@ -685,7 +843,8 @@ int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint
     if (!m || !out) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     *out = nullptr;
     if (start > end || end > m->outer()) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "slice_outer range out of bounds");
-    return slice_outer(m, start, end, out);
+    SPRS_TRY(slice_outer(m, start, end, out));
+    return finish_result(out, m);
 }
 
 int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const void *row_inds_dev, const void *col_inds_dev,
@@ -740,6 +899,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "pool_max_bytes")) {
         if (value < 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "pool_max_bytes must be >= 0");
         o.pool_max_bytes = value;
+    } else if (!strcmp(name, "spgemm_xcd_chunk")) {
+        if (value < -1 || value > (1 << 20)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_xcd_chunk must be -1, 0 or a run length");
+        o.spgemm_xcd_chunk = value;
     } else if (!strcmp(name, "spgemm_task_order")) {
         if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_task_order must be 0, 1 or 2");
         o.spgemm_task_order = value;
@@ -808,6 +970,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_heavy")) *value = o.spgemm_heavy;
     else if (!strcmp(name, "spgemm_minwin")) *value = o.spgemm_minwin;
     else if (!strcmp(name, "spgemm_task_order")) *value = o.spgemm_task_order;
+    else if (!strcmp(name, "spgemm_xcd_chunk")) *value = o.spgemm_xcd_chunk;
     else if (!strcmp(name, "pool")) *value = o.pool;
     else if (!strcmp(name, "pool_max_bytes")) *value = o.pool_max_bytes;
     else if (!strcmp(name, "pool_cached_bytes")) *value = (int64_t)pool_cached_bytes();

@@ -48,6 +48,7 @@ struct Options {
     int64_t spmv_relabel = 0;      // sliced plan: columns relabelled by count class, x permuted per SpMV: 0 auto (on), 1 on, 2 off
     int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
     int64_t spgemm_task_order = 0; // large-row tasks: 0/1 window-major (sorted by first column, then row), 2 row-major (A/B)
+    int64_t spgemm_xcd_chunk = 0;  // large-row task list -> XCDs: 0 round-robin, n > 0 runs of n consecutive tasks per XCD, -1 one run per XCD
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
     int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
     int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)
@@ -133,7 +134,13 @@ struct SpmmPlan {
 struct sprs_hip_csmat {
     int32_t storage = SPRS_HIP_CSR;
     uint64_t rows = 0, cols = 0, nnz = 0;
-    int32_t iptr_bytes = 8, idx_bytes = 8;
+    int32_t iptr_bytes = 8, idx_bytes = 8;       // widths of the device arrays (4 or 8)
+    // widths the CALLER declared (2, 4 or 8): sprs' SpIndex covers u16 / i16 too (indexing.rs:124-130).  2-byte arrays are
+    // widened to 4 bytes on upload and narrowed on download; every value a result could hold is checked against the
+    // declared width where the reference's I::from_usize / Iptr::from_usize would panic.  0 = same as the device width.
+    int32_t decl_iptr_bytes = 0, decl_idx_bytes = 0;
+    int32_t user_iptr_bytes() const { return decl_iptr_bytes ? decl_iptr_bytes : iptr_bytes; }
+    int32_t user_idx_bytes() const { return decl_idx_bytes ? decl_idx_bytes : idx_bytes; }
     void *indptr = nullptr;    // device, outer+1 entries, zero based
     void *indices = nullptr;   // device, nnz entries
     double *data = nullptr;    // device, nnz entries
@@ -187,5 +194,7 @@ int32_t slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end, sprs_
 // abi.hip
 int32_t alloc_csmat(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols, uint64_t nnz,
                     int32_t iptr_bytes, int32_t idx_bytes);
+// a result inherits the declared index widths of its operand; INDEX_OVERFLOW where a value would not fit them
+int32_t inherit_declared_widths(sprs_hip_csmat *result, const sprs_hip_csmat *from);
 
 }  // namespace sprs_hip

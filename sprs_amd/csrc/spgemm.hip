@@ -236,9 +236,15 @@ __global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uin
 
 // Block b runs on XCD b % 8 (observed; only speed depends on it): every XCD gets a contiguous run of the (window-major)
 // task list, so that the tasks sharing a column window of B — and its lines in the private 4 MiB L2 — stay together.
-__device__ __forceinline__ uint64_t task_of_block(uint64_t bid, uint64_t n) {
-    const uint64_t q = n >> 3, rem = n & 7, k = bid & 7, j = bid >> 3;
-    return k * q + (k < rem ? k : rem) + j;
+__device__ __forceinline__ uint64_t task_of_block(uint64_t bid, uint64_t n, uint32_t chunk) {
+    if (chunk == 0) return bid;                                  // round-robin over the XCDs
+    if (chunk == 0xFFFFFFFFu) {                                  // one contiguous run per XCD
+        const uint64_t q = n >> 3, rem = n & 7, k = bid & 7, j = bid >> 3;
+        return k * q + (k < rem ? k : rem) + j;
+    }
+    // runs of `chunk` consecutive tasks per XCD, dealt round-robin: XCD k takes runs k, k + 8, ...
+    const uint64_t k = bid & 7, j = bid >> 3, run = (j / chunk) * 8 + k, t = run * chunk + j % chunk;
+    return t < n ? t : bid;                                      // (ragged end: fall back to the identity for the last runs)
 }
 
 // ---------------------------------------------------------------------------
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, P
                                                                   const uint64_t *__restrict__ first_task,
                                                                   const uint64_t *__restrict__ ntasks,
                                                                   const uint8_t *__restrict__ wlog,
-                                                                  uint64_t *__restrict__ count) {
+                                                                  uint64_t *__restrict__ count, uint32_t xcd_chunk) {
     using Cfg = LgCfg<WL>;
     constexpr int K_CAP = Cfg::K_CAP;
     __shared__ unsigned long long bm[Cfg::WORDS];
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, P
     __shared__ uint32_t kP[K_CAP + 1];
     __shared__ uint64_t wt[16];
     __shared__ uint64_t red[LG_WAVES];
-    const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x)];
+    const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x, xcd_chunk)];
     const uint64_t r = task_row[t];
     const uint64_t w = t - first_task[r];
     const uint32_t wl = wlog[r];
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                                                                  const uint64_t *__restrict__ count,
                                                                  const uint64_t *__restrict__ off,
                                                                  IDX *__restrict__ c_indices, double *__restrict__ c_data,
-                                                                 unsigned long long *__restrict__ prof) {
+                                                                 unsigned long long *__restrict__ prof, uint32_t xcd_chunk) {
     using Cfg = LgCfg<WL>;
     constexpr int WPT = Cfg::WPT, NSUPER = Cfg::NSUPER, ACC_CAP = Cfg::ACC_CAP, K_CAP = Cfg::K_CAP;
     __shared__ unsigned long long bm[Cfg::WORDS];   // the window's structure: one bit per column
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     __shared__ double kA[K_CAP];
     __shared__ uint64_t wt[16];
     const uint32_t tid = threadIdx.x;
-    const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x)];
+    const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x, xcd_chunk)];
     const uint64_t r = task_row[t];
     const uint64_t w = t - first_task[r];
     const uint32_t wl = wlog[r];
@@ -881,6 +887,7 @@ struct sprs_hip_spgemm_plan {
     const void *a_indptr = nullptr, *a_indices = nullptr, *b_indptr = nullptr, *b_indices = nullptr;   // whose structure it describes
     uint64_t ntask_total = 0, n_small = 0, n_large = 0, n_tiny = 0, c_nnz = 0, nb = 0;
     int64_t winlog = 17;
+    uint32_t xcd_chunk = 0;        // how the launch deals the task list to the XCDs (task_of_block)
     sprs_hip::DevBuf bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, large_list, count, off;
 };
 
@@ -916,6 +923,7 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     pl->b_indptr = b->indptr;
     pl->b_indices = b->indices;
     pl->winlog = options().spgemm_winlog;
+    pl->xcd_chunk = options().spgemm_xcd_chunk < 0 ? 0xFFFFFFFFu : (uint32_t)options().spgemm_xcd_chunk;
     CsrView<IDX, PTR> A = view_of<IDX, PTR>(a), B = view_of<IDX, PTR>(b);
     // column-bucket table of B (4 bytes per 2048 columns per row): only when it stays within a small multiple of B's own
     // size and is not pointless (every row of B has at most one entry); on allocation failure: binary searches instead
@@ -1018,7 +1026,7 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
 #define SPRS_LG_SYM(WL)                                                                                              \
     hipLaunchKernelGGL((large_symbolic_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, b_cols,                       \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
-                       pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>())
+                       pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(), pl->xcd_chunk)
         switch (pl->winlog) {
             case 16: SPRS_LG_SYM(16); break;
             case 18: SPRS_LG_SYM(18); break;
@@ -1072,7 +1080,7 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     hipLaunchKernelGGL((large_numeric_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, pl->b_cols,                    \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
                        pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(),                  \
-                       pl->off.as<uint64_t>(), c_indices, c_values, prof.as<unsigned long long>())
+                       pl->off.as<uint64_t>(), c_indices, c_values, prof.as<unsigned long long>(), pl->xcd_chunk)
         switch (pl->winlog) {
             case 16: SPRS_LG_NUM(16); break;
             case 18: SPRS_LG_NUM(18); break;

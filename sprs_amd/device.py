@@ -9,7 +9,7 @@ import numpy as np
 from . import _ffi
 from ._ffi import CSC, CSR, check, lib
 
-_DT = {4: np.uint32, 8: np.uint64}
+_DT = {2: np.uint16, 4: np.uint32, 8: np.uint64}
 
 
 def _vp(a):

@@ -99,16 +99,9 @@ def csmat_mul_vec(mat, vec, out=None, stream=None):
 
 
 def csmat_mul_csmat(lhs, rhs):
-    """csmat_mul_csmat (csmat.rs:1895-1949): storage dispatch around
-    smmp::mul_csr_csr; the result has the lhs' storage order."""
-    from . import smmp
-    ls, rs = lhs.storage(), rhs.storage()
-    if (ls, rs) == (CSR, CSR):
-        return smmp.mul_csr_csr(lhs, rhs)
-    if (ls, rs) == (CSR, CSC):
-        return smmp.mul_csr_csr(lhs, rhs.to_other_storage())
-    if (ls, rs) == (CSC, CSR):
-        res = smmp.mul_csr_csr(rhs.to_other_storage().transpose_view(), lhs.transpose_view())
-        return res.transpose_view()            # transpose_into
-    res = smmp.mul_csr_csr(rhs.transpose_view(), lhs.transpose_view())
-    return res.transpose_view()
+    """csmat_mul_csmat (csmat.rs:1895-1949): storage dispatch around smmp::mul_csr_csr, done below the C ABI
+    (sprs_hip_csmat_mul_csmat); the result has the lhs' storage order."""
+    from .device import DeviceCsMat
+    h = C.c_void_p()
+    check(lib.sprs_hip_csmat_mul_csmat(lhs._h, rhs._h, C.byref(h)))
+    return DeviceCsMat(h.value)

@@ -64,6 +64,6 @@ class SpgemmPlan:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and lib is not None:       # (lib is None while the interpreter shuts down)
             lib.sprs_hip_spgemm_plan_free(h)
             self._h = C.c_void_p(0)

@@ -144,3 +144,66 @@ def test_mul_csc_vec_golden(hip, golden):
     csr = DeviceCsMat.from_host(shape, ip, ix, dt)
     with pytest.raises(hip.SprsHipError, match="Storage mismatch"):
         prod.mul_acc_mat_vec_csc(csr, x, y)
+
+
+def test_gh374_literal_u16(hip):
+    """sprs/tests/gh374.rs:10-33 with its own types (CsMatI<_, u16, usize>): X is 2^18 x 16 with one entry at
+    (2^17, 4); `&X.transpose_view() * &X` is the (CSC, CSR) case of csmat_mul_csmat, which converts the rhs to CSC —
+    row indices up to 2^17 do not fit u16: "Index type is not large enough to hold" (csmat.rs:1794-1797)."""
+    from sprs_amd.device import DeviceCsMat
+    rows, cols = 1 << 18, 1 << 4
+    ip = np.zeros(rows + 1, dtype=np.uint64)
+    ip[(1 << 17) + 1:] = 1
+    x = DeviceCsMat.from_host((rows, cols), ip, np.array([1 << 2], dtype=np.uint16), np.array([1.0]))
+    assert x.index_bytes() == 2 and x.indptr_bytes() == 8 and x.nnz() == 1
+    shape, gip, gix, gdt = x.to_host()
+    assert gix.dtype == np.uint16 and gix.tolist() == [4] and np.array_equal(gip, ip)
+    with pytest.raises(hip.SprsHipError) as e:
+        x.transpose_view() * x
+    assert e.value.status == hip._ffi.INDEX_OVERFLOW
+    assert "Index type is not large enough to hold" in str(e.value)
+    # the other way round everything fits: X * X^T is (CSR, CSC) -> 2^18 x 2^18 with one entry, u16 columns cannot hold 2^17
+    with pytest.raises(hip.SprsHipError) as e:
+        x * x.transpose_view()
+    assert e.value.status == hip._ffi.INDEX_OVERFLOW
+
+
+@pytest.mark.parametrize("idx,ptr", [(np.uint16, np.uint16), (np.uint16, np.uint64), (np.uint32, np.uint16)])
+def test_two_byte_index_types(hip, golden, idx, ptr):
+    """SpIndex covers u16 / i16 (indexing.rs:124-130): 2-byte host arrays are widened on upload and narrowed on
+    download; SpMV, the product and its storage dispatch, the conversion and slices give the golden results with
+    the declared index types; results that do not fit them are refused."""
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    a = as_csr(golden["mat1"], idx, ptr)
+    b = as_csr(golden["mat2"], idx, ptr)
+    A, B = DeviceCsMat.from_host(*a), DeviceCsMat.from_host(*b)
+    assert A.index_bytes() == np.dtype(idx).itemsize and A.indptr_bytes() == np.dtype(ptr).itemsize
+    for x, y in zip(A.to_host()[1:], a[1:]):
+        assert x.dtype == y.dtype and np.array_equal(x, y)
+    exp = as_csr(golden["mat1_matprod_mat2"], idx, ptr)
+    got = (A * B).to_host()
+    for x, y in zip(got[1:], exp[1:]):
+        assert x.dtype == y.dtype and np.array_equal(x, y)
+    # storage dispatch with a CSC rhs: same matrix, same result (prod.rs:438-458)
+    got2 = (A * B.to_other_storage()).to_host()
+    for x, y in zip(got2[1:], exp[1:]):
+        assert np.array_equal(x, y)
+    fx = golden["mul_csr_vec"]
+    shape, ip, ix, dt = as_csr(fx, idx, ptr)
+    y = (DeviceCsMat.from_host(shape, ip, ix, dt) * DeviceVec.from_host(np.array(fx["x"]))).to_host()
+    assert np.all(np.abs(y - np.array(fx["expected"])) < fx["epsilon"])
+    sl = A.slice_outer(1, 4)
+    sip, six, sdt = A.slice_outer_to_host(1, 4)
+    assert six.dtype == np.dtype(idx) and np.array_equal(sl.to_host()[2], six)
+    if np.dtype(ptr).itemsize == 2:
+        # nnz of a product above 65535 does not fit a u16 indptr (Iptr::from_usize, smmp.rs:121)
+        n, w = 1000, 40                                           # band of 41: 40 k entries fit, the product's 80 k do not
+        lens = np.minimum(w + 1, n - np.arange(n))
+        bip = np.zeros(n + 1, dtype=np.int64)
+        bip[1:] = np.cumsum(lens)
+        bix = np.concatenate([np.arange(i, i + l) for i, l in enumerate(lens)])
+        assert bip[-1] <= 0xFFFF
+        band = DeviceCsMat.from_host((n, n), bip.astype(np.uint16), bix.astype(idx), np.ones(bix.size))
+        with pytest.raises(hip.SprsHipError) as e:
+            band * band
+        assert e.value.status == hip._ffi.INDEX_OVERFLOW
