@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--workload", default="rmat10m")
     ap.add_argument("--idx-bytes", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="torch", choices=("torch", "lib"),
+                    help="N > 1: all-gather-v of y through torch.distributed (grouped send/recv on RCCL; default) or inside the "
+                         "library (sprs_hip_dist_*: sub-block pipeline, RCCL loaded by the library itself)")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the short spgemm5 object")
     ap.add_argument("--permute-cols", type=int, default=0,
                     help="experiment: relabel the columns by a random permutation (seed given) before the run")
@@ -280,6 +283,18 @@ def main():
         prod.csmat_mul_vec(handles[key], DeviceVec.borrow(xv), out=out, stream=stream)
 
     sh = RowShardedSpMV((n, n), indptr, indices, data, local_spmv)
+    libdist = None
+    if world > 1 and args.exchange == "lib":
+        from sprs_amd.dist import DistSpMV
+        rb = sh.block
+        libdist = DistSpMV((n, n), DeviceCsMat.wrap_torch((rb[0], rb[1]), rb[2], rb[3], rb[4]), sh.cuts, rank, world,
+                           unique_id=DistSpMV.broadcast_id(dev), nsub=2)
+        yv_all = DeviceVec.borrow(sh.y)
+
+        def lib_step(xv):
+            libdist.spmv(DeviceVec.borrow(xv), yv_all, stream=stream)
+            return sh.y
+        sh.step = lib_step
     del indptr, indices, data   # only the rank's block stays resident
     torch.cuda.empty_cache()
 
@@ -302,9 +317,13 @@ def main():
         if flush is not None:
             flush.add_(1.0)   # reads and writes 1 GiB: evicts L2 and the Infinity Cache; part of ms_per_step, not of the kernel events
         ev[s][0].record(stream)
-        sh.local_spmv(sh.block, x, sh.y[sh.r0:sh.r1])   # kernel(s) on `stream`, bracketed by HIP events
-        ev[s][1].record(stream)
-        sh.exchange()
+        if libdist is not None:
+            sh.step(x)                                  # multiply + exchange inside the library, pipelined
+            ev[s][1].record(stream)
+        else:
+            sh.local_spmv(sh.block, x, sh.y[sh.r0:sh.r1])   # kernel(s) on `stream`, bracketed by HIP events
+            ev[s][1].record(stream)
+            sh.exchange()
     torch.cuda.synchronize()
     barrier()
     t_total = time.perf_counter() - t_start
@@ -360,7 +379,9 @@ def main():
             "workload": name,
             "rows": n, "cols": n, "nnz": nnz_total,
             "index_bytes": args.idx_bytes, "indptr_bytes": args.idx_bytes,
-            "partition": "cost-balanced (nnz + 8/row) contiguous row blocks x%d, direct all-gather-v of y" % world if world > 1 else "single GPU",
+            "partition": ("cost-balanced (nnz + 8/row) contiguous row blocks x%d, direct all-gather-v of y (%s)" %
+                          (world, "sprs_hip_dist_*, RCCL inside the library" if args.exchange == "lib" else "torch.distributed grouped send/recv on RCCL"))
+                         if world > 1 else "single GPU",
             "generate_s": round(gen_s, 2),
         },
         "roofline": {

@@ -260,6 +260,28 @@ int32_t sprs_hip_csmat_to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat 
  * of the host mirrors call.  Status codes as sprs_hip_spgemm_f64 and sprs_hip_csmat_to_other_storage. */
 int32_t sprs_hip_csmat_mul_csmat(const sprs_hip_csmat *lhs, const sprs_hip_csmat *rhs, sprs_hip_csmat **out);
 
+/* ---- row-sharded SpMV over the GPUs of one node (one process per GPU, RCCL over xGMI) ----
+ * The reference has no distributed code; the shard is its slice_outer (slicing.rs:65-89) with a rebased indptr
+ * (indptr.rs:206-214): rank g owns rows [row_starts[g], row_starts[g+1]) and a full replica of x; one exchange, an
+ * all-gather-v of y, issued as ONE group of direct sends / receives with every peer (xGMI is a point-to-point mesh).
+ *   sprs_hip_dist_unique_id  128 bytes from ncclGetUniqueId: call on ONE rank and hand them to the others (MPI, a
+ *                            torch.distributed broadcast, a file ...), like every NCCL / RCCL program does
+ *   sprs_hip_dist_create     collective.  local_block = this rank's rows as a CSR handle with all `cols` columns and a
+ *                            zero-based indptr (sprs_hip_csmat_slice_outer makes one).  It is cut into nsub sub-blocks of
+ *                            equal cost; the exchange of a finished sub-block overlaps the multiply of the next
+ *                            (nsub = 1: multiply, then exchange).  Every rank passes the same world, row_starts, nsub.
+ *   sprs_hip_dist_spmv_f64   collective.  y (length rows, on this rank's device) = A * x (x: length cols, replicated).
+ *                            Asynchronous on `stream`; y is complete for work queued on `stream` afterwards.
+ * RCCL is loaded at run time (dlopen); world = 1 needs none.  SPRS_HIP_HIP_ERROR carries RCCL's message. */
+typedef struct sprs_hip_dist sprs_hip_dist;
+int32_t sprs_hip_dist_unique_id(void *id_128_bytes);
+int32_t sprs_hip_dist_create(sprs_hip_dist **d, const void *id_128_bytes, int32_t world, int32_t rank, uint64_t rows,
+                             uint64_t cols, const uint64_t *row_starts /* world + 1 */, const sprs_hip_csmat *local_block,
+                             int32_t nsub);
+int32_t sprs_hip_dist_spmv_f64(sprs_hip_dist *d, const double *x_dev, uint64_t x_len, double *y_dev, uint64_t y_len,
+                               void *stream);
+int32_t sprs_hip_dist_free(sprs_hip_dist *d);
+
 /* Triplet (COO) assembly: twin of TriMatBase::to_csr / to_csc (triplet.rs:262-276) = TriMatIter::into_cs
  * (triplet_iter.rs:127-224): the n triplets (row_inds[p], col_inds[p], data[p]) — arrays in DEVICE memory, indices of
  * in_idx_bytes (4 or 8) each — are sorted by (outer, inner) with a stable device radix sort, duplicates are summed in

@@ -21,6 +21,11 @@ pub struct sprs_hip_spgemm_plan {
 }
 
 #[repr(C)]
+pub struct sprs_hip_dist {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
 pub struct sprs_hip_csmat {
     _private: [u8; 0],
 }
@@ -105,6 +110,13 @@ extern "C" {
     pub fn sprs_hip_spgemm_plan_numeric(plan: *mut sprs_hip_spgemm_plan, a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_spgemm_plan_free(plan: *mut sprs_hip_spgemm_plan) -> i32;
     pub fn sprs_hip_csmat_to_other_storage(m: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_dist_unique_id(id_128_bytes: *mut c_void) -> i32;
+    pub fn sprs_hip_dist_create(
+        d: *mut *mut sprs_hip_dist, id_128_bytes: *const c_void, world: i32, rank: i32, rows: u64, cols: u64,
+        row_starts: *const u64, local_block: *const sprs_hip_csmat, nsub: i32,
+    ) -> i32;
+    pub fn sprs_hip_dist_spmv_f64(d: *mut sprs_hip_dist, x_dev: *const f64, x_len: u64, y_dev: *mut f64, y_len: u64, stream: *mut c_void) -> i32;
+    pub fn sprs_hip_dist_free(d: *mut sprs_hip_dist) -> i32;
     pub fn sprs_hip_csmat_mul_csmat(lhs: *const sprs_hip_csmat, rhs: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_triplets_to_cs(
         rows: u64, cols: u64, n: u64, row_inds_dev: *const c_void, col_inds_dev: *const c_void, in_idx_bytes: i32,

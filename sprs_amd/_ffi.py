@@ -66,6 +66,10 @@ SIGNATURES = {
     "sprs_hip_spmm_rowmaj_f64": (i32, [vp, vp, u64, u64, u64, vp, u64, u64, i32, vp]),
     "sprs_hip_spgemm_f64": (i32, [vp, vp, P(vp)]),
     "sprs_hip_csmat_to_other_storage": (i32, [vp, P(vp)]),
+    "sprs_hip_dist_unique_id": (i32, [vp]),
+    "sprs_hip_dist_create": (i32, [P(vp), vp, i32, i32, u64, u64, P(u64), vp, i32]),
+    "sprs_hip_dist_spmv_f64": (i32, [vp, vp, u64, vp, u64, vp]),
+    "sprs_hip_dist_free": (i32, [vp]),
     "sprs_hip_csmat_mul_csmat": (i32, [vp, vp, P(vp)]),
     "sprs_hip_triplets_to_cs": (i32, [u64, u64, u64, vp, vp, i32, vp, i32, i32, i32, P(vp)]),
     "sprs_hip_set_option": (i32, [C.c_char_p, i64]),

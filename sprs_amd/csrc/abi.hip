@@ -847,6 +847,34 @@ int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint
     return finish_result(out, m);
 }
 
+int32_t sprs_hip_dist_unique_id(void *id_128_bytes) {
+    clear_error();
+    if (!id_128_bytes) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    return dist_unique_id(id_128_bytes);
+}
+
+int32_t sprs_hip_dist_create(sprs_hip_dist **d, const void *id_128_bytes, int32_t world, int32_t rank, uint64_t rows,
+                             uint64_t cols, const uint64_t *row_starts, const sprs_hip_csmat *local_block, int32_t nsub) {
+    clear_error();
+    if (!d || !row_starts || !local_block || (world > 1 && !id_128_bytes)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    *d = nullptr;
+    return dist_create(d, id_128_bytes, world, rank, rows, cols, row_starts, local_block, nsub);
+}
+
+int32_t sprs_hip_dist_spmv_f64(sprs_hip_dist *d, const double *x_dev, uint64_t x_len, double *y_dev, uint64_t y_len, void *stream) {
+    clear_error();
+    if (!d) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    if (dist_cols(d) != x_len || dist_rows(d) != y_len) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if ((x_len && !x_dev) || (y_len && !y_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL vector");
+    return dist_spmv(d, x_dev, y_dev, (hipStream_t)stream);
+}
+
+int32_t sprs_hip_dist_free(sprs_hip_dist *d) {
+    clear_error();
+    dist_free(d);
+    return SPRS_HIP_OK;
+}
+
 int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const void *row_inds_dev, const void *col_inds_dev,
                                 int32_t in_idx_bytes, const double *data_dev, int32_t storage, int32_t out_idx_bytes,
                                 int32_t out_iptr_bytes, sprs_hip_csmat **out) {

@@ -12,6 +12,7 @@
 #include "../../include/sprs_hip.h"
 
 struct sprs_hip_spgemm_plan;      // spgemm.hip
+struct sprs_hip_dist;             // dist.hip
 
 namespace sprs_hip {
 
@@ -182,6 +183,14 @@ void spgemm_plan_free(sprs_hip_spgemm_plan *pl);
 // spmm.hip
 int32_t spmm_rowmaj_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, double *out,
                         uint64_t ld_out, bool accumulate, hipStream_t stream);
+// dist.hip
+int32_t dist_unique_id(void *id128);
+int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world, int32_t rank, uint64_t rows, uint64_t cols,
+                    const uint64_t *row_starts, const sprs_hip_csmat *local_block, int32_t nsub);
+int32_t dist_spmv(sprs_hip_dist *d, const double *x, double *y, hipStream_t stream);
+void dist_free(sprs_hip_dist *d);
+uint64_t dist_rows(const sprs_hip_dist *d);
+uint64_t dist_cols(const sprs_hip_dist *d);
 // triplet.hip
 int32_t triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const void *row_inds, const void *col_inds, int32_t in_idx_bytes,
                        const double *data, int32_t storage, int32_t out_idx_bytes, int32_t out_iptr_bytes, sprs_hip_csmat **out);

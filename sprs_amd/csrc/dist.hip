@@ -1,0 +1,254 @@
+// Row-sharded SpMV across the GPUs of one node, inside the library: one process per GPU, RCCL over xGMI.
+//
+// The reference has no distributed code; the shard is its own slice_outer (sprs/src/sparse/slicing.rs:65-89) with the
+// indptr rebased (to_proper, indptr.rs:206-214): rank g owns the contiguous row block [row_starts[g], row_starts[g+1]),
+// keeps a full replica of x and computes its block of y with the single-GPU kernels; ONE exchange step follows, an
+// all-gather-v of y.  xGMI is a full point-to-point mesh (7 links per GPU), so the exchange is a DIRECT one — every
+// rank sends its block to every peer at once, ncclGroupStart / ncclSend + ncclRecv / ncclGroupEnd — not a ring that
+// would be bound by one link.  The local block is cut into sub-blocks (cost-balanced, each with its own plan): the
+// sends of a finished sub-block go out on a second stream while the next sub-block is still being multiplied.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): the library has no link-time dependency on it, a process that
+// already carries a copy (PyTorch does) shares it, and single-GPU users never load it.
+#include "common.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <vector>
+
+namespace sprs_hip {
+
+namespace {
+
+// the few RCCL entry points used (rccl.h); ncclUniqueId is 128 opaque bytes, ncclFloat64 = 8
+struct NcclId {
+    char internal[128];
+};
+typedef void *ncclComm_t;
+typedef int ncclResult_t;
+constexpr int NCCL_FLOAT64 = 8;
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(NcclId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, NcclId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+int32_t rccl(Rccl **out) {
+    static Rccl r;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!r.lib) {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "multi-GPU: RCCL is not available (%s)", dlerror());
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
+        r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
+        r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv)
+            SPRS_FAIL(SPRS_HIP_INVALID_ARG, "multi-GPU: librccl lacks an expected entry point");
+        r.lib = h;
+    }
+    *out = &r;
+    return SPRS_HIP_OK;
+}
+
+#define SPRS_TRY_NCCL(R, expr)                                                                                      \
+    do {                                                                                                            \
+        const ncclResult_t r__ = (expr);                                                                            \
+        if (r__ != 0) SPRS_FAIL(SPRS_HIP_HIP_ERROR, "RCCL error %d (%s) in %s", r__,                                \
+                                (R)->GetErrorString ? (R)->GetErrorString(r__) : "?", #expr);                       \
+    } while (0)
+
+}  // namespace
+
+}  // namespace sprs_hip
+
+struct sprs_hip_dist {
+    int32_t world = 1, rank = 0;
+    uint64_t rows = 0, cols = 0;
+    std::vector<uint64_t> row_starts;                  // world + 1
+    std::vector<sprs_hip_csmat *> sub;                 // sub-blocks of the local row block (owned)
+    std::vector<uint64_t> sub_starts;                  // global first row of each sub-block, + the block's end
+    std::vector<std::vector<uint64_t>> peer_starts;    // the same table of every rank (exchanged at creation)
+    void *comm = nullptr;
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> done;                      // sub-block s multiplied (recorded on the caller's stream)
+    hipEvent_t gathered = nullptr;                     // exchange complete (recorded on comm_stream)
+};
+
+namespace sprs_hip {
+
+uint64_t dist_rows(const sprs_hip_dist *d) { return d->rows; }
+uint64_t dist_cols(const sprs_hip_dist *d) { return d->cols; }
+
+int32_t dist_unique_id(void *id128) {
+    Rccl *R = nullptr;
+    SPRS_TRY(rccl(&R));
+    SPRS_TRY_NCCL(R, R->GetUniqueId((NcclId *)id128));
+    return SPRS_HIP_OK;
+}
+
+void dist_free(sprs_hip_dist *d) {
+    if (!d) return;
+    for (auto *m : d->sub) sprs_hip_csmat_free(m);
+    for (auto e : d->done)
+        if (e) (void)hipEventDestroy(e);
+    if (d->gathered) (void)hipEventDestroy(d->gathered);
+    if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
+    if (d->comm) {
+        Rccl *R = nullptr;
+        if (rccl(&R) == SPRS_HIP_OK) (void)R->CommDestroy(d->comm);
+    }
+    delete d;
+}
+
+// local_block: the rows [row_starts[rank], row_starts[rank + 1]) of the matrix as a CSR handle with ALL the columns and a
+// zero-based indptr (what slice_outer + to_proper give).  nsub sub-blocks (>= 1) pipeline multiply and exchange.
+int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world, int32_t rank, uint64_t rows, uint64_t cols,
+                    const uint64_t *row_starts, const sprs_hip_csmat *local_block, int32_t nsub) {
+    if (world < 1 || rank < 0 || rank >= world) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "bad world size / rank");
+    if (row_starts[0] != 0 || row_starts[world] != rows) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "row_starts must run from 0 to rows");
+    for (int32_t g = 0; g < world; ++g)
+        if (row_starts[g] > row_starts[g + 1]) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "row_starts must be non-decreasing");
+    if (local_block->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    if (local_block->cols != cols || local_block->rows != row_starts[rank + 1] - row_starts[rank])
+        SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    auto *d = new sprs_hip_dist();
+    struct Guard {
+        sprs_hip_dist *p;
+        ~Guard() { dist_free(p); }
+    } guard{d};
+    d->world = world;
+    d->rank = rank;
+    d->rows = rows;
+    d->cols = cols;
+    d->row_starts.assign(row_starts, row_starts + world + 1);
+    // ---- sub-blocks of equal cost (nnz + 8 per row, as the rank split): cut points from the block's indptr -------------
+    const uint64_t lrows = local_block->rows, r0 = row_starts[rank];
+    if (nsub < 1) nsub = 1;
+    const int32_t nsub_req = nsub;                                 // the same on every rank: the exchange runs in nsub_req groups
+    if ((uint64_t)nsub > lrows) nsub = lrows ? (int32_t)lrows : 1; // (this rank may have fewer rows than that)
+    std::vector<uint64_t> cuts{0};
+    if (nsub > 1) {
+        std::vector<uint64_t> ip(lrows + 1);
+        if (local_block->iptr_bytes == 8) {
+            SPRS_TRY_HIP(hipMemcpy(ip.data(), local_block->indptr, (lrows + 1) * 8, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<uint32_t> ip32(lrows + 1);
+            SPRS_TRY_HIP(hipMemcpy(ip32.data(), local_block->indptr, (lrows + 1) * 4, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i <= lrows; ++i) ip[i] = ip32[i];
+        }
+        const double total = (double)ip[lrows] + 8.0 * (double)lrows;
+        for (int32_t s = 1; s < nsub; ++s) {
+            const double target = total * s / nsub;
+            uint64_t lo = cuts.back(), hi = lrows;                 // first row r with cost(rows < r) >= target
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if ((double)ip[mid] + 8.0 * (double)mid < target) lo = mid + 1;
+                else hi = mid;
+            }
+            cuts.push_back(lo);
+        }
+    }
+    cuts.push_back(lrows);
+    for (size_t s = 0; s + 1 < cuts.size(); ++s) {
+        sprs_hip_csmat *m = nullptr;
+        SPRS_TRY(slice_outer(local_block, cuts[s], cuts[s + 1], &m));
+        d->sub.push_back(m);
+        d->sub_starts.push_back(r0 + cuts[s]);
+    }
+    d->sub_starts.push_back(r0 + lrows);
+    // ---- communicator, second stream, events -------------------------------------------------------------------------------
+    if (world > 1) {
+        Rccl *R = nullptr;
+        SPRS_TRY(rccl(&R));
+        NcclId id;
+        memcpy(&id, unique_id128, sizeof id);
+        SPRS_TRY_NCCL(R, R->CommInitRank(&d->comm, world, id, rank));
+        SPRS_TRY_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+        d->done.assign(d->sub.size(), nullptr);
+        for (auto &e : d->done) SPRS_TRY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        SPRS_TRY_HIP(hipEventCreateWithFlags(&d->gathered, hipEventDisableTiming));
+        // every rank must know where every peer cuts its block: one small grouped exchange of the sub_starts tables
+        // (all ranks pass the same nsub; a rank with fewer rows than nsub pads its table with its block end)
+        const size_t tab = (size_t)nsub_req + 1;
+        std::vector<uint64_t> mine(tab, d->sub_starts.back());
+        for (size_t i = 0; i < d->sub_starts.size() && i < tab; ++i) mine[i] = d->sub_starts[i];
+        uint64_t *dev = nullptr;
+        SPRS_TRY_HIP(hipMalloc((void **)&dev, (size_t)world * tab * 8));
+        struct Free {
+            void *p;
+            ~Free() { (void)hipFree(p); }
+        } fr{dev};
+        SPRS_TRY_HIP(hipMemcpy(dev + (size_t)rank * tab, mine.data(), tab * 8, hipMemcpyHostToDevice));
+        SPRS_TRY_NCCL(R, R->GroupStart());
+        for (int32_t p = 0; p < world; ++p) {
+            if (p == rank) continue;
+            SPRS_TRY_NCCL(R, R->Send(dev + (size_t)rank * tab, tab, NCCL_FLOAT64, p, d->comm, d->comm_stream));   // (8-byte words)
+            SPRS_TRY_NCCL(R, R->Recv(dev + (size_t)p * tab, tab, NCCL_FLOAT64, p, d->comm, d->comm_stream));
+        }
+        SPRS_TRY_NCCL(R, R->GroupEnd());
+        SPRS_TRY_HIP(hipStreamSynchronize(d->comm_stream));
+        std::vector<uint64_t> all((size_t)world * tab);
+        SPRS_TRY_HIP(hipMemcpy(all.data(), dev, all.size() * 8, hipMemcpyDeviceToHost));
+        d->peer_starts.resize(world);
+        for (int32_t p = 0; p < world; ++p) {
+            d->peer_starts[p].assign(all.begin() + (size_t)p * tab, all.begin() + (size_t)(p + 1) * tab);
+            if (d->peer_starts[p].front() != row_starts[p] || d->peer_starts[p].back() != row_starts[p + 1])
+                SPRS_FAIL(SPRS_HIP_INVALID_ARG, "rank %d cut its block differently from the row_starts given here", p);
+        }
+    }
+    guard.p = nullptr;
+    *out = d;
+    return SPRS_HIP_OK;
+}
+
+// y (full length, on this rank's device) = A * x: the own block is multiplied sub-block by sub-block on `stream`; as soon
+// as one is done its rows go to every peer on the second stream, and the peers' blocks arrive into y; `stream` then waits
+// for the exchange.  Every rank must call this with the same sequence of calls (collective).
+int32_t dist_spmv(sprs_hip_dist *d, const double *x, double *y, hipStream_t stream) {
+    Rccl *R = nullptr;
+    if (d->world > 1) SPRS_TRY(rccl(&R));
+    const size_t groups = d->world > 1 ? d->peer_starts[0].size() - 1 : d->sub.size();
+    for (size_t s = 0; s < groups; ++s) {
+        if (s < d->sub.size()) {
+            sprs_hip_csmat *m = d->sub[s];
+            if (m->rows) SPRS_TRY(spmv_f64(m, x, y + d->sub_starts[s], false, stream));
+        }
+        if (d->world == 1) continue;
+        // sub-block s is done: its rows go to every peer, the peers' sub-block s arrives — on the second stream, while the
+        // caller's stream goes on with sub-block s + 1
+        const size_t ev = s < d->done.size() ? s : d->done.size() - 1;
+        SPRS_TRY_HIP(hipEventRecord(d->done[ev], stream));
+        SPRS_TRY_HIP(hipStreamWaitEvent(d->comm_stream, d->done[ev], 0));
+        const std::vector<uint64_t> &me = d->peer_starts[d->rank];
+        SPRS_TRY_NCCL(R, R->GroupStart());
+        for (int32_t p = 0; p < d->world; ++p) {
+            if (p == d->rank) continue;
+            const std::vector<uint64_t> &pe = d->peer_starts[p];
+            if (me[s + 1] > me[s]) SPRS_TRY_NCCL(R, R->Send(y + me[s], me[s + 1] - me[s], NCCL_FLOAT64, p, d->comm, d->comm_stream));
+            if (pe[s + 1] > pe[s]) SPRS_TRY_NCCL(R, R->Recv(y + pe[s], pe[s + 1] - pe[s], NCCL_FLOAT64, p, d->comm, d->comm_stream));
+        }
+        SPRS_TRY_NCCL(R, R->GroupEnd());
+    }
+    if (d->world > 1) {
+        SPRS_TRY_HIP(hipEventRecord(d->gathered, d->comm_stream));
+        SPRS_TRY_HIP(hipStreamWaitEvent(stream, d->gathered, 0));      // y is complete for whatever the caller queues next
+    }
+    return SPRS_HIP_OK;
+}
+
+}  // namespace sprs_hip

@@ -103,6 +103,58 @@ class RowShardedSpMV:
         return self.y
 
 
+class DistSpMV:
+    """The row-sharded SpMV INSIDE the library (sprs_hip_dist_create / _spmv_f64 / _free, sprs_amd/csrc/dist.hip): the
+    local block cut into sub-blocks, the direct RCCL exchange of a finished sub-block overlapping the multiply of the
+    next.  The 128-byte RCCL id is made on one rank (`unique_id`) and handed to the others by whatever the host
+    program has — here a torch.distributed broadcast (`broadcast_id`)."""
+
+    def __init__(self, shape, local_block, row_starts, rank, world, unique_id=None, nsub=2):
+        import ctypes as C
+        import numpy as np
+        from ._ffi import check, lib
+        self.rows, self.cols = int(shape[0]), int(shape[1])
+        self.block = local_block                      # keeps the handle alive (the library slices its own copies)
+        rs = np.ascontiguousarray(row_starts, dtype=np.uint64)
+        h = C.c_void_p()
+        idbuf = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        check(lib.sprs_hip_dist_create(C.byref(h), idbuf, world, rank, self.rows, self.cols,
+                                       rs.ctypes.data_as(C.POINTER(C.c_uint64)), local_block._h, nsub))
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from ._ffi import check, lib
+        buf = (C.c_char * 128)()
+        check(lib.sprs_hip_dist_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def broadcast_id(device, group=None, src=0):
+        """rank `src` makes the id, everybody gets it (collective)"""
+        buf = torch.zeros(128, dtype=torch.uint8, device=device)
+        if dist.get_rank(group) == src:
+            buf.copy_(torch.frombuffer(bytearray(DistSpMV.unique_id()), dtype=torch.uint8))
+        dist.broadcast(buf, src=src, group=group)
+        return bytes(buf.cpu().numpy().tobytes())
+
+    def spmv(self, x, y, stream=None):
+        """y = A * x (collective); x, y: DeviceVec of length cols / rows on this rank's device"""
+        import ctypes as C
+        from ._ffi import check, lib
+        from .prod import _stream_ptr
+        check(lib.sprs_hip_dist_spmv_f64(self._h, C.c_void_p(x.ptr), x.n, C.c_void_p(y.ptr), y.n, _stream_ptr(stream)))
+        return y
+
+    def __del__(self):
+        from ._ffi import lib
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and lib is not None:
+            lib.sprs_hip_dist_free(h)
+            self._h = None
+
+
 def hip_local_spgemm(a_block, b):
     """the HIP SpGEMM on torch-resident operands (borrowed, no copy); returns a DeviceCsMat"""
     from . import smmp
