@@ -1,0 +1,39 @@
+#!/bin/bash
+# ONE parameterised script for everything that runs on the GPU box (one `gpurun` call each; outputs under gpurun_out/<tag>/,
+# copy what should be kept into profiles/).  Usage, from the repo root on the GPU box:
+#   bash scripts/gpu_session.sh <tag> <step> [step ...]
+# Steps (any order, any subset):
+#   tests                 the driver's GPU suite (pytest -m gpu) + smoke()
+#   tests:<expr>          pytest -m gpu -k "<expr>"
+#   bench[:args]          bench.py [args]  (default workload R-MAT 10M SpMV; e.g. bench:--workload\ spgemm5)
+#   sweep:<configs>       scripts/spmv_sweep.py on R-MAT 10M; configs separated by '|', each name:opt=val,opt=val
+#   trace:<config>        rocprofv3 --kernel-trace of one sweep config, per-kernel means and the dispatch sequence
+#   stats[:args]          rocprofv3 --kernel-trace --stats of bench.py [args]
+#   pmc[:args]            rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC hit-miss-req) of bench.py [args] -> pmc_summary.txt
+#   spgemm                SpGEMM config 5: seconds, row-block parity, kernel stats (tests/spgemm_bench.py)
+#   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
+TAG=${1:?tag}; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $ROOT
+prof_db() { find "$1" -name "*.db" | head -1; }
+for step in "$@"; do
+  name=${step%%:*}; arg=""; [ "$step" != "$name" ] && arg=${step#*:}
+  echo "== $step"
+  case $name in
+    tests)
+      if [ -n "$arg" ]; then timeout 1800 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -12
+      else timeout 1800 python -m pytest tests -m gpu -x -q --durations=6 2>&1 | tail -14; timeout 300 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu | tail -3; fi ;;
+    bench)  timeout 900 python bench.py $arg 2>/dev/null | tee -a $OUT/bench.jsonl ;;
+    sweep)  IFS='|' read -ra CFG <<< "$arg"; timeout 900 python scripts/spmv_sweep.py --steps 30 --oracle "${CFG[@]}" 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tee -a $OUT/sweep.jsonl ;;
+    trace)  ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace -d /tmp/st -o s -- python $ROOT/scripts/spmv_sweep.py --steps 10 "$arg" > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_seq.py $(prof_db /tmp/st) band_ spmv_ ) 2>&1 | cut -c1-200 | tee -a $OUT/kernel_seq.txt ;;
+    stats)  ( cd /tmp && rm -rf /tmp/st && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/bench.py --no-cpu-baseline $arg > $OUT/stats_bench.json 2>/dev/null; f=$(prof_db /tmp/st); python3 $ROOT/scripts/rocprof_summary.py $f sprs_hip | grep -E "^kernel|^#|sprs_hip" | cut -c1-190; python3 $ROOT/scripts/rocprof_seq.py $f band_ | cut -c1-200 ) 2>&1 | tee -a $OUT/kernel_stats.txt ;;
+    pmc)    PMC_GROUPS=${PMC_GROUPS:-3} bash scripts/gpu_pmc.sh $TAG/pmc $arg > /dev/null 2>&1; grep -E "csrc_sha16|band_|spmv_" $OUT/pmc/pmc_summary.txt | cut -c1-200 ;;
+    spgemm) timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds" | tee -a $OUT/spgemm.jsonl
+            ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/tests/spgemm_bench.py 1000000 8 8 1 > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|sprs_hip" | cut -c1-200 | head -16 | tee -a $OUT/spgemm_kernels.txt ;;
+    py)     timeout 900 python $arg 2>&1 | grep -v amdgpu.ids | tee -a $OUT/py.log ;;
+    *)      echo "unknown step $name" ;;
+  esac
+done 2>&1 | tee $OUT/log.txt

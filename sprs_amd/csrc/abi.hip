@@ -605,6 +605,9 @@ int32_t sprs_hip_spmv_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t
     if (a->cols != x_len || a->rows != y_len) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
     if (a->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
     if ((x_len && !x_dev) || (y_len && !y_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL vector");
+    // &mut res_vec cannot alias &in_vec in the reference; here the kernels read x while they write y
+    if (x_len && y_len && x_dev < y_dev + y_len && y_dev < x_dev + x_len)
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "the result vector overlaps the input vector");
     return spmv_f64(const_cast<sprs_hip_csmat *>(a), x_dev, y_dev, accumulate != 0, (hipStream_t)stream);
 }
 

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(CV_BLOCK) void sort_small_rows_kernel(const uint64_
             keys[i] = i < n ? t_keys[s + i] : KEY_PAD;
             vals[i] = i < n ? t_vals[s + i] : 0.0;
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         for (uint32_t k2 = 2; k2 <= size; k2 <<= 1) {
             for (uint32_t jj = k2 >> 1; jj > 0; jj >>= 1) {
                 for (uint32_t i = lane; i < size; i += WAVE) {
@@ -108,14 +108,14 @@ __global__ __launch_bounds__(CV_BLOCK) void sort_small_rows_kernel(const uint64_
                         }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_sync_lds();
             }
         }
         for (uint32_t i = lane; i < n; i += WAVE) {
             o_indices[s + i] = (IDX)keys[i];
             o_data[s + i] = vals[i];
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
     }
 }
 

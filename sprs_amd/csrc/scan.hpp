@@ -39,6 +39,16 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *wa
 #endif
 __device__ __forceinline__ void lds_barrier() { SPRS_LDS_BARRIER(); }
 
+// Hand-over of LDS data between the lanes of ONE wave.  __builtin_amdgcn_wave_barrier() alone only stops the compiler from
+// moving code across it as a scheduling matter; it is not a memory fence, so LLVM could still forward or cache LDS values
+// across it.  The wavefront-scope release / acquire pair makes the ordering part of the program (no instruction is emitted
+// for it: the LDS operations of a wave execute in order anyway).
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // the same scans with LDS-only barriers
 __device__ __forceinline__ uint64_t block_excl_scan_u64_lds(uint64_t v, uint64_t *wave_tot, uint64_t *total) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

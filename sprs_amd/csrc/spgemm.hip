@@ -275,7 +275,7 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
         if (lg < 6) lg = 6;
         const uint32_t tsize = 1u << lg, mask = tsize - 1;
         for (uint32_t i = lane; i < tsize; i += WAVE) keys[i] = EMPTY;
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
         uint32_t fresh = 0;
         if (ae - as <= (uint64_t)WAVE) {
@@ -330,18 +330,18 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                     // Two lanes of this batch may hold the same column (from different k's): their products must be
                     // added in lane order = k order.  64 direct-mapped order tags: the lowest pending lane of a tag
                     // adds, the others (same column, or merely the same tag) take another turn.
-                    __builtin_amdgcn_wave_barrier();
+                    wave_sync_lds();
                     bool pend = valid;
                     uint32_t *tg = &tag_s[wave][h & (WAVE - 1)];
                     while (__ballot(pend)) {
                         if (pend) atomicMin(tg, lane);
-                        __builtin_amdgcn_wave_barrier();
+                        wave_sync_lds();
                         if (pend && *(volatile uint32_t *)tg == lane) {
                             vals[h] += pr;
                             *(volatile uint32_t *)tg = EMPTY;
                             pend = false;
                         }
-                        __builtin_amdgcn_wave_barrier();
+                        wave_sync_lds();
                     }
                 }
             }
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                         h = (h + 1) & mask;
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_sync_lds();
             }
         }
         if constexpr (!NUMERIC) {
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                             }
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
+                    wave_sync_lds();
                 }
             }
             const uint64_t o = off[t];
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                 if (c_indices) c_indices[o + i] = (IDX)keys[i];   // null: C already has its structure (numeric on a kept plan)
                 if (c_data) c_data[o + i] = vals[i];      // null: structure only (the twin of smmp::symbolic)
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_sync_lds();
         }
     }
 }

@@ -71,7 +71,7 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 #define __global__
 #define __device__
 #define __host__
-#define __forceinline__ inline
+#define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
 
