@@ -419,14 +419,6 @@ def main():
             oracle.mul_acc_mat_vec_csr((n, n), ip_h, ix_h, dt_h, x_h, y_h)
             ts.append(time.perf_counter() - t)
         serial_s = min(ts)
-        ncores = oracle.num_procs()
-        tp = []
-        for _ in range(reps):
-            y_p = np.zeros(n)
-            t = time.perf_counter()
-            oracle.mul_acc_mat_vec_csr((n, n), ip_h, ix_h, dt_h, x_h, y_p, threads=ncores)
-            tp.append(time.perf_counter() - t)
-        par_s = min(tp)
         denom = np.maximum(np.abs(y_h), np.abs(y_gpu))
         rel = np.where(denom > 0, np.abs(y_gpu - y_h) / np.where(denom > 0, denom, 1.0), 0.0)
         out["cpu_baseline"] = {
@@ -437,9 +429,6 @@ def main():
             "sample": "whole %s matrix, best of %d SpMVs; C restatement of sprs' serial prod::mul_acc_mat_vec_csr "
                       "(sprs SpMV is single-threaded; rustc is not available here)" % (wl, reps),
             "seconds": round(serial_s, 4),
-            "all_cores_value": round(2.0 * nnz_total / par_s / 1e9, 4),
-            "all_cores": ncores,
-            "all_cores_note": "OpenMP row split, NOT in the reference",
         }
         out["parity"] = {"max_rel_err_vs_oracle": float(rel.max()), "tolerance": 1e-10,
                          "ok": bool(rel.max() <= 1e-10)}

@@ -11,6 +11,7 @@
 #   stats[:args]          rocprofv3 --kernel-trace --stats of bench.py [args]
 #   pmc[:args]            rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC hit-miss-req) of bench.py [args] -> pmc_summary.txt
 #   spgemm                SpGEMM config 5: seconds, row-block parity, kernel stats (tests/spgemm_bench.py)
+#   spmm[:args]           SpMM on R-MAT 10M (scripts/spmm_bench.py [n nnz_per_row k ...]) + its kernel stats
 #   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
 TAG=${1:?tag}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -32,7 +33,10 @@ for step in "$@"; do
     stats)  ( cd /tmp && rm -rf /tmp/st && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/bench.py --no-cpu-baseline $arg > $OUT/stats_bench.json 2>/dev/null; f=$(prof_db /tmp/st); python3 $ROOT/scripts/rocprof_summary.py $f sprs_hip | grep -E "^kernel|^#|sprs_hip" | cut -c1-190; python3 $ROOT/scripts/rocprof_seq.py $f band_ | cut -c1-200 ) 2>&1 | tee -a $OUT/kernel_stats.txt ;;
     pmc)    PMC_GROUPS=${PMC_GROUPS:-3} bash scripts/gpu_pmc.sh $TAG/pmc $arg > /dev/null 2>&1; grep -E "csrc_sha16|band_|spmv_" $OUT/pmc/pmc_summary.txt | cut -c1-200 ;;
     spgemm) timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds" | tee -a $OUT/spgemm.jsonl
-            ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/tests/spgemm_bench.py 1000000 8 8 1 > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|sprs_hip" | cut -c1-200 | head -16 | tee -a $OUT/spgemm_kernels.txt ;;
+            ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/tests/spgemm_bench.py 1000000 8 8 1 > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|sprs_hip" | cut -c1-200 | head -16 | tee -a $OUT/spgemm_kernels.txt
+            SPGEMM_PROF=1 timeout 600 python tests/spgemm_bench.py 1000000 8 8 1 2>&1 | grep spgemm_prof | tee -a $OUT/spgemm_kernels.txt ;;
+    spmm)   timeout 600 python scripts/spmm_bench.py $arg 2>&1 | grep -E "^\{" | tee -a $OUT/spmm.jsonl
+            ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spmm_bench.py ${arg:-10000000 32 16} > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|spmm" | cut -c1-200 | head -8 | tee -a $OUT/spmm_kernels.txt ;;
     py)     timeout 900 python $arg 2>&1 | grep -v amdgpu.ids | tee -a $OUT/py.log ;;
     *)      echo "unknown step $name" ;;
   esac

@@ -931,7 +931,7 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         if (value < 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "pool_max_bytes must be >= 0");
         o.pool_max_bytes = value;
     } else if (!strcmp(name, "spgemm_xcd_chunk")) {
-        if (value < -1 || value > (1 << 20)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_xcd_chunk must be -1, 0 or a run length");
+        if (value < -1 || value > 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_xcd_chunk must be 0 (round-robin) or -1 (one run per XCD)");
         o.spgemm_xcd_chunk = value;
     } else if (!strcmp(name, "spgemm_task_order")) {
         if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_task_order must be 0, 1 or 2");

@@ -49,7 +49,7 @@ struct Options {
     int64_t spmv_relabel = 0;      // sliced plan: columns relabelled by count class, x permuted per SpMV: 0 auto (on), 1 on, 2 off
     int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
     int64_t spgemm_task_order = 0; // large-row tasks: 0/1 window-major (sorted by first column, then row), 2 row-major (A/B)
-    int64_t spgemm_xcd_chunk = 0;  // large-row task list -> XCDs: 0 round-robin, n > 0 runs of n consecutive tasks per XCD, -1 one run per XCD
+    int64_t spgemm_xcd_chunk = 0;  // large-row task list -> XCDs: 0 round-robin, -1 one contiguous run per XCD
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
     int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
     int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)

@@ -234,17 +234,16 @@ __global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uin
     }
 }
 
-// Block b runs on XCD b % 8 (observed; only speed depends on it): every XCD gets a contiguous run of the (window-major)
-// task list, so that the tasks sharing a column window of B — and its lines in the private 4 MiB L2 — stay together.
+// Block b runs on XCD b % 8 (observed; only speed depends on it).  Default: the task list is dealt round-robin (the
+// tasks are sorted by cost, so every XCD gets the same mix).  spgemm_xcd_chunk = -1 gives every XCD one contiguous run
+// instead (tasks sharing a column window of B stay in one L2) — measured slower on config 5: the runs differ in cost.
 __device__ __forceinline__ uint64_t task_of_block(uint64_t bid, uint64_t n, uint32_t chunk) {
     if (chunk == 0) return bid;                                  // round-robin over the XCDs
-    if (chunk == 0xFFFFFFFFu) {                                  // one contiguous run per XCD
+    if (chunk == 0xFFFFFFFFu) {                                  // one contiguous run per XCD (a bijection on [0, n))
         const uint64_t q = n >> 3, rem = n & 7, k = bid & 7, j = bid >> 3;
         return k * q + (k < rem ? k : rem) + j;
     }
-    // runs of `chunk` consecutive tasks per XCD, dealt round-robin: XCD k takes runs k, k + 8, ...
-    const uint64_t k = bid & 7, j = bid >> 3, run = (j / chunk) * 8 + k, t = run * chunk + j % chunk;
-    return t < n ? t : bid;                                      // (ragged end: fall back to the identity for the last runs)
+    return bid;
 }
 
 // ---------------------------------------------------------------------------
@@ -687,10 +686,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
     // walked in the reference's order (k ascending), 4 x 512 entries at a time, all loads independent.
     // ORDER: C(i,j) must be built by the reference's chain of additions (smmp.rs:174-181), so two
     // entries of one chunk that hit the same accumulator may not be added in arbitrary order (and
-    // float atomics are out anyway).  Each pending entry posts its position with an LDS atomicMin on the
-    // accumulator's tag; the entry whose position comes back adds its product and clears the tag, the
-    // others try again in the next round.  Rounds needed = the largest multiplicity of an output inside
-    // the chunk: 1 almost always, 2-3 in dense windows.  Deterministic and bit-exact.
+    // float atomics are out anyway): see "Ordered accumulation of the chunk" below.  Deterministic and bit-exact.
     constexpr int U = 4;
     const bool one_group = ae - as <= (uint64_t)K_CAP;
     const int nsuper = (words + SUPER_WORDS - 1) / SUPER_WORDS;
@@ -778,41 +774,67 @@ __global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PT
                     }
                     mark(12);
                     ++n_chunks;
-                    // ordered rounds; termination through three rotating LDS flags (a workgroup-wide
-                    // vote costs more instructions than the round itself)
-                    for (;; ++rd) {                     // rd keeps counting across chunks: the flag rotation never restarts
-                        ++n_rounds;
-                        bool mine_pending = false;
+                    // Ordered accumulation of the chunk (the sums must be taken in chunk order = k order, bit for bit):
+                    //  (1) every entry counts itself on its accumulator's tag; an accumulator with ONE entry in the
+                    //      chunk (most of them) takes it at once;
+                    //  (2) the others — hub columns of B — are added wave by wave: a wave's entries all precede the
+                    //      next wave's in chunk order, so each wave settles its own with wave-local rounds (the
+                    //      smallest position posted on a tag wins the round), one workgroup barrier per wave instead
+                    //      of two per round of the whole workgroup.
+                    // A tag is NO_TAG when idle, before and after.
 #pragma unroll
-                        for (int u = 0; u < U; ++u) mine_pending |= pend[u];
-                        const bool wave_pending = __ballot(mine_pending) != 0ull;     // wave-uniform
-                        if (wave_pending) {
+                    for (int u = 0; u < U; ++u)
+                        if (pend[u]) atomicSub(&tag[slot[u]], 1u);
+                    if (tid == 0) more_flag[(rd + 1) % 3] = 0;
+                    lds_barrier();
+                    {
+                        bool conflict = false;
 #pragma unroll
-                            for (int u = 0; u < U; ++u)
-                                if (pend[u]) atomicMin(&tag[slot[u]], pos_in_chunk[u]);
-                        }
-                        if (tid == 0) more_flag[(rd + 1) % 3] = 0;
-                        lds_barrier();
-                        if (wave_pending) {
-                            bool more = false;
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                if (pend[u]) {
-                                    if (tag[slot[u]] == pos_in_chunk[u]) {
-                                        acc[slot[u]] += pr[u];
-                                        tag[slot[u]] = NO_TAG;
-                                        pend[u] = false;
-                                    } else {
-                                        more = true;
-                                    }
+                        for (int u = 0; u < U; ++u) {
+                            if (pend[u]) {
+                                if (tag[slot[u]] == NO_TAG - 1u) {       // mine alone: nobody else reads this tag
+                                    acc[slot[u]] += pr[u];
+                                    tag[slot[u]] = NO_TAG;
+                                    pend[u] = false;
+                                } else {
+                                    conflict = true;
                                 }
                             }
-                            if (more) more_flag[rd % 3] = 1;
                         }
+                        if (conflict) more_flag[rd % 3] = 1;
+                    }
+                    lds_barrier();                                       // every count has been read
+                    const bool ordered_phase = more_flag[rd % 3] != 0;   // block-uniform
+                    ++rd;                                                // (keeps counting across chunks: the flag rotation never restarts)
+                    if (ordered_phase) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            if (pend[u]) tag[slot[u]] = NO_TAG;
                         lds_barrier();
-                        if (!more_flag[rd % 3]) {                                     // block-uniform
-                            ++rd;
-                            break;
+                        for (uint32_t v = 0; v < (uint32_t)LG_WAVES; ++v) {
+                            if (tid / WAVE == v) {                       // wave-uniform
+                                for (;;) {
+                                    bool mine_pending = false;
+#pragma unroll
+                                    for (int u = 0; u < U; ++u) mine_pending |= pend[u];
+                                    if (__ballot(mine_pending) == 0ull) break;
+                                    ++n_rounds;
+#pragma unroll
+                                    for (int u = 0; u < U; ++u)
+                                        if (pend[u]) atomicMin(&tag[slot[u]], pos_in_chunk[u]);
+                                    wave_sync_lds();
+#pragma unroll
+                                    for (int u = 0; u < U; ++u) {
+                                        if (pend[u] && tag[slot[u]] == pos_in_chunk[u]) {
+                                            acc[slot[u]] += pr[u];
+                                            tag[slot[u]] = NO_TAG;
+                                            pend[u] = false;
+                                        }
+                                    }
+                                    wave_sync_lds();
+                                }
+                            }
+                            lds_barrier();
                         }
                     }
                 }
@@ -925,13 +947,16 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     pl->winlog = options().spgemm_winlog;
     pl->xcd_chunk = options().spgemm_xcd_chunk < 0 ? 0xFFFFFFFFu : (uint32_t)options().spgemm_xcd_chunk;
     CsrView<IDX, PTR> A = view_of<IDX, PTR>(a), B = view_of<IDX, PTR>(b);
-    // column-bucket table of B (4 bytes per 2048 columns per row): only when it stays within a small multiple of B's own
-    // size and is not pointless (every row of B has at most one entry); on allocation failure: binary searches instead
+    // column-bucket table of B (4 bytes per 2048 columns per row; config 5: 1.96 GB): bounded — up to 4 GiB outright
+    // (1.4 % of the device), beyond that only within a small multiple of B's own size and never above 8 GiB (a
+    // 10M x 10M operand would ask for 195 GB) — and skipped when pointless (every row of B has at most one entry);
+    // on allocation failure: binary searches instead
     {
         const uint64_t nb = (b_cols >> BUCKET_LOG2) + 2;
         const uint64_t bytes = b->rows * nb * sizeof(uint32_t);
         const uint64_t b_bytes = b->nnz * (8 + sizeof(IDX)) + (b->rows + 1) * sizeof(PTR);
-        if (options().spgemm_bucket && b->rows && b->nnz > b->rows && bytes <= (8ull << 30) && bytes <= 4 * b_bytes + (64ull << 20)) {
+        if (options().spgemm_bucket && b->rows && b->nnz > b->rows && bytes <= (8ull << 30) &&
+            (bytes <= (4ull << 30) || bytes <= 4 * b_bytes + (64ull << 20))) {
             if (pl->bucket.alloc(bytes) == hipSuccess) {
                 uint64_t blocks = (b->rows + 3) / 4;
                 if (blocks > 256 * 64) blocks = 256 * 64;

@@ -6,13 +6,18 @@
 // becomes a whole ROW of the rhs — k contiguous doubles — so one L2 line access now carries
 // k/16 .. 1 full line of useful data instead of 8 bytes of it.
 //
-// Decomposition: rows are cut into CHUNKS of at most 512 entries (plan, cached in the handle).
-// One wave per chunk; the 64 lanes are 64/KP groups of KP lanes (KP = k rounded up to a power of
-// two): lane j of group g accumulates column j over entries g, g + G, ... of the chunk, the rhs row
-// of an entry is read by the KP lanes of a group as one contiguous segment.  Groups are combined
-// with xor-shuffles.  A row that fits one chunk is written directly; the chunks of longer rows go
-// to a scratch array and are added in chunk order by a second kernel (no float atomics:
-// deterministic).  Unfused multiply-add (-ffp-contract=off) like MulAcc (mul_acc.rs:28-30).
+// Decomposition (plan cached in the handle):
+//  * rows of at most LONG_ROW entries — all but a handful — belong to a GROUP of KP lanes (KP = k rounded up to a power
+//    of two, 64 / KP groups per wave).  A group walks its rows (group-stride) as a little state machine: every turn
+//    it loads the next <= 32 entries of its current row coalesced, then the 32 rhs rows they name (all in flight at
+//    once: the latency of one turn buys 32 lines per group), and adds the products IN ENTRY ORDER into one accumulator
+//    per column — the reference's own order, out[i, j] = (..(out[i, j] + a_i0 rhs[0, j]) + ..) — bit for bit, the
+//    accumulate form included.  A group whose row ends writes it and moves on while its neighbours continue: rows
+//    of different lengths cost no idle lanes.  No atomics, no scratch.
+//  * longer rows are cut into CHUNKS of 512 entries, one wave per chunk (lane j of group g takes entries g, g + G,
+//    ... of the chunk, groups combined with xor-shuffles), partials added in chunk order by a second kernel:
+//    deterministic, equal to the reference up to the summation order (tests: 1e-12 relative).
+// Unfused multiply-add (-ffp-contract=off) like MulAcc (mul_acc.rs:28-30).
 #include "common.hpp"
 #include "scan.hpp"
 
@@ -24,6 +29,7 @@ constexpr int WAVE = 64;
 constexpr int MM_BLOCK = 256;
 constexpr int MM_WAVES = MM_BLOCK / WAVE;
 constexpr uint64_t CHUNK = 512;
+constexpr uint64_t LONG_ROW = 2048;        // rows above this many entries go to the chunk kernels
 
 template <typename PTR>
 __global__ void count_chunks_kernel(const PTR *__restrict__ indptr, uint64_t rows, uint64_t *__restrict__ nchunks,
@@ -31,7 +37,7 @@ __global__ void count_chunks_kernel(const PTR *__restrict__ indptr, uint64_t row
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const uint64_t len = (uint64_t)indptr[r + 1] - (uint64_t)indptr[r];
-    const uint64_t n = (len + CHUNK - 1) / CHUNK;
+    const uint64_t n = len > LONG_ROW ? (len + CHUNK - 1) / CHUNK : 0;
     nchunks[r] = n;
     is_multi[r] = n > 1 ? 1 : 0;
 }
@@ -43,6 +49,86 @@ __global__ void fill_chunks_kernel(const uint64_t *__restrict__ first_chunk, con
     const uint64_t f = first_chunk[r], n = first_chunk[r + 1] - f;
     for (uint64_t c = 0; c < n; ++c) chunk_row[f + c] = r;
     if (n > 1) multi_rows[multi_pos[r]] = r;
+}
+
+// rows of at most LONG_ROW entries: one group of KP lanes per row at a time (see the header)
+template <typename IDX, typename PTR, int KP, bool ACC>
+__global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
+                                                             const double *__restrict__ data, uint64_t rows,
+                                                             const double *__restrict__ rhs, uint64_t ld_rhs, uint32_t k,
+                                                             double *__restrict__ out, uint64_t ld_out) {
+    constexpr int EB = KP <= 16 ? 32 / KP : 1;           // entries a lane loads per turn
+    constexpr int NB = EB * KP;                          // entries of a turn (32, or KP)
+    constexpr int UN = NB < 32 ? NB : 32;                // rhs rows in flight per group
+    const uint32_t j = threadIdx.x % KP;
+    const bool col_ok = j < k;
+    const uint64_t ng = (uint64_t)gridDim.x * (MM_BLOCK / KP);
+    uint64_t r = ((uint64_t)blockIdx.x * MM_BLOCK + threadIdx.x) / KP;
+    bool active = r < rows, mine = false;
+    uint64_t cur = 0, end = 0, ncur = 0, nend = 0;
+    double acc = 0.0;
+    if (active) {
+        cur = (uint64_t)indptr[r];
+        end = (uint64_t)indptr[r + 1];
+        mine = end - cur <= LONG_ROW;
+        if (!mine) cur = end;
+        if constexpr (ACC)
+            if (mine && col_ok) acc = out[r * ld_out + j];
+        if (r + ng < rows) {
+            ncur = (uint64_t)indptr[r + ng];
+            nend = (uint64_t)indptr[r + ng + 1];
+        }
+    }
+    while (__ballot(active) != 0ull) {
+        const uint32_t nb = active ? (uint32_t)(end - cur < (uint64_t)NB ? end - cur : (uint64_t)NB) : 0u;
+        uint64_t col[EB];
+        double val[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const uint32_t t = (uint32_t)e * KP + j;
+            const bool ok = t < nb;
+            col[e] = ok ? (uint64_t)indices[cur + t] : 0ull;
+            val[e] = ok ? data[cur + t] : 0.0;
+        }
+#pragma unroll
+        for (int t0 = 0; t0 < NB; t0 += UN) {
+            if (__ballot((uint32_t)t0 < nb) == 0ull) break;            // wave-uniform
+            double x[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int t = t0 + u;
+                // (an entry past the end reads rhs row 0 and is not added: no branch in the load sequence)
+                const uint64_t c = __shfl(col[t / KP], t % KP, KP);
+                x[u] = col_ok ? rhs[c * ld_rhs + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int t = t0 + u;
+                const double v = __shfl(val[t / KP], t % KP, KP);
+                const double sum = acc + v * x[u];
+                acc = (uint32_t)t < nb ? sum : acc;
+            }
+        }
+        cur += nb;
+        if (active && cur == end) {
+            if (mine && col_ok) out[r * ld_out + j] = acc;
+            r += ng;
+            active = r < rows;
+            cur = ncur;
+            end = nend;
+            acc = 0.0;
+            if (active) {
+                mine = end - cur <= LONG_ROW;
+                if (!mine) cur = end;
+                if constexpr (ACC)
+                    if (mine && col_ok) acc = out[r * ld_out + j];
+                if (r + ng < rows) {
+                    ncur = (uint64_t)indptr[r + ng];
+                    nend = (uint64_t)indptr[r + ng + 1];
+                }
+            }
+        }
+    }
 }
 
 template <typename IDX, typename PTR, int KP, bool ACC>
@@ -67,10 +153,22 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_chunk_kernel(const PTR *__restr
         const uint64_t e = (s + CHUNK < re) ? s + CHUNK : re;
         double acc = 0.0;
         if (j < k) {
-            for (uint64_t p = s + g; p < e; p += G) {
-                const uint64_t col = (uint64_t)indices[p];
-                const double prod = data[p] * rhs[col * ld_rhs + j];
-                acc += prod;
+            for (uint64_t p = s + g; p < e; p += 4 * G) {              // four rhs rows in flight; added in the order g, g + G, ...
+                uint64_t col[4];
+                double a[4], x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = p + (uint64_t)u * G < e;
+                    col[u] = ok ? (uint64_t)indices[p + (uint64_t)u * G] : 0ull;
+                    a[u] = ok ? data[p + (uint64_t)u * G] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = rhs[col[u] * ld_rhs + j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double sum = acc + a[u] * x[u];
+                    acc = p + (uint64_t)u * G < e ? sum : acc;
+                }
             }
         }
 #pragma unroll
@@ -144,6 +242,21 @@ template <typename IDX, typename PTR, int KP>
 int32_t launch_block(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint32_t k, double *out, uint64_t ld_out,
                      bool acc, double *partial, hipStream_t stream) {
     const SpmmPlan &pl = a->mm;
+    {
+        // short rows: groups of KP lanes, group-stride; enough workgroups to fill the chip eight deep
+        constexpr uint64_t groups_per_block = MM_BLOCK / KP;
+        uint64_t blocks = (a->rows + groups_per_block - 1) / groups_per_block;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        const dim3 grid((unsigned)blocks), block(MM_BLOCK);
+        if (acc)
+            hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, true>), grid, block, 0, stream, (const PTR *)a->indptr,
+                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, k, out, ld_out);
+        else
+            hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, false>), grid, block, 0, stream, (const PTR *)a->indptr,
+                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, k, out, ld_out);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    if (!pl.nchunks) return SPRS_HIP_OK;
     uint64_t blocks = (pl.nchunks + MM_WAVES - 1) / MM_WAVES;
     if (blocks > 256 * 64) blocks = 256 * 64;
     const dim3 grid((unsigned)blocks), block(MM_BLOCK);
@@ -190,13 +303,15 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
         }
         partial = slot.first;
     }
-    const SpmmPlan &pl = a->mm;
-    if (!acc) {
-        // rows without a chunk (empty rows) must read as zero in the operator form (csmat.rs:2004)
-        if (ld_out == k) SPRS_TRY_HIP(hipMemsetAsync(out, 0, a->rows * k * sizeof(double), stream));
-        else SPRS_TRY_HIP(hipMemset2DAsync(out, ld_out * sizeof(double), 0, k * sizeof(double), a->rows, stream));
+    if (a->nnz == 0) {
+        // nothing stored: the operator form is all zeros (csmat.rs:2004), the accumulate form leaves `out` alone
+        if (!acc) {
+            if (ld_out == k) SPRS_TRY_HIP(hipMemsetAsync(out, 0, a->rows * k * sizeof(double), stream));
+            else SPRS_TRY_HIP(hipMemset2DAsync(out, ld_out * sizeof(double), 0, k * sizeof(double), a->rows, stream));
+        }
+        return SPRS_HIP_OK;
     }
-    if (!pl.nchunks) return SPRS_HIP_OK;
+    // every row is written by exactly one kernel (an empty row as zeros): no memset of `out`
     for (uint64_t j0 = 0; j0 < k; j0 += 64) {          // column blocks of 64
         const uint32_t kb = (uint32_t)(k - j0 < 64 ? k - j0 : 64);
         const double *r = rhs + j0;

@@ -65,16 +65,50 @@ def test_rmat_vs_oracle(hip, k):
     got = (a * prod.DeviceMat.from_host(rhs)).to_host()
     ref = oracle_spmm((n, n), ip, ix, dt, rhs)
     assert rel_err(got, ref) <= TOL
+    lens = np.diff(ip.astype(np.int64))
+    short = lens <= 2048                                        # spmm.hip LONG_ROW: these rows are summed in entry order,
+    assert np.array_equal(got[short], ref[short])               # the reference's own (prod.rs:203-210): bit for bit
     empty = np.diff(ip.astype(np.int64)) == 0
     assert empty.any() and np.all(got[empty] == 0.0)
     out0 = rng.random((n, k))
     res = prod.DeviceMat.from_host(out0)
     prod.csr_mulacc_dense_rowmaj(a, prod.DeviceMat.from_host(rhs), res)
     got2 = res.to_host()
-    assert rel_err(got2, oracle_spmm((n, n), ip, ix, dt, rhs, out0)) <= TOL
+    ref2 = oracle_spmm((n, n), ip, ix, dt, rhs, out0)
+    assert rel_err(got2, ref2) <= TOL
+    assert np.array_equal(got2[short], ref2[short])             # the accumulate form starts from out[i, j], as there
     assert np.array_equal(got2[empty], out0[empty])             # empty rows untouched
     again = (a * prod.DeviceMat.from_host(rhs)).to_host()
     assert np.array_equal(got, again)                           # deterministic
+
+
+@pytest.mark.parametrize("k", [2, 16, 40])
+def test_long_rows_take_the_chunk_kernels(hip, k):
+    """rows above spmm.hip's LONG_ROW (2048 entries) are cut into 512-entry chunks: same values up to the summation order"""
+    from sprs_amd import prod
+    from sprs_amd.device import DeviceCsMat
+    rng = np.random.default_rng(100 + k)
+    n, m = 300, 9000
+    lens = rng.integers(0, 40, n)
+    lens[[3, 150, 299]] = [2049, 7000, 4096]
+    lens[[4, 151]] = [2048, 0]
+    ip = np.zeros(n + 1, np.uint64)
+    ip[1:] = np.cumsum(lens)
+    ix = np.concatenate([np.sort(rng.choice(m, int(l), replace=False)) for l in lens]).astype(np.uint64)
+    dt = rng.standard_normal(ix.size)
+    rhs = rng.standard_normal((m, k))
+    a = DeviceCsMat.from_host((n, m), ip, ix, dt)
+    got = (a * prod.DeviceMat.from_host(rhs)).to_host()
+    ref = oracle_spmm((n, m), ip, ix, dt, rhs)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-12 * scale
+    assert np.array_equal(got[lens <= 2048], ref[lens <= 2048])
+    out0 = rng.standard_normal((n, k))
+    res = prod.DeviceMat.from_host(out0)
+    prod.csr_mulacc_dense_rowmaj(a, prod.DeviceMat.from_host(rhs), res)
+    ref2 = oracle_spmm((n, m), ip, ix, dt, rhs, out0)
+    assert np.abs(res.to_host() - ref2).max() <= 1e-12 * scale
+    assert np.array_equal(res.to_host()[lens == 0], out0[lens == 0])
 
 
 def test_ragged_and_contract(hip, golden):
