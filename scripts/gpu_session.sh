@@ -4,6 +4,7 @@
 #   bash scripts/gpu_session.sh <tag> <step> [step ...]
 # Steps (any order, any subset):
 #   tests                 the driver's GPU suite (pytest -m gpu) + smoke()
+#   gate:<expr>           pytest -m gpu -k "<expr>" under a short timeout; a failure or a hang ENDS the session (first run of a new kernel)
 #   tests:<expr>          pytest -m gpu -k "<expr>"
 #   bench[:args]          bench.py [args]  (default workload R-MAT 10M SpMV; e.g. bench:--workload\ spgemm5)
 #   sweep:<configs>       scripts/spmv_sweep.py on R-MAT 10M; configs separated by '|', each name:opt=val,opt=val
@@ -11,6 +12,7 @@
 #   stats[:args]          rocprofv3 --kernel-trace --stats of bench.py [args]
 #   pmc[:args]            rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC hit-miss-req) of bench.py [args] -> pmc_summary.txt
 #   spgemm                SpGEMM config 5: seconds, row-block parity, kernel stats (tests/spgemm_bench.py)
+#   spgemm_ab:<cfgs>      SpGEMM config 5 under option sets, separated by '|': e.g. "base|SPGEMM_RETAIN=0|SPGEMM_WINLOG=16 SPGEMM_OCCUPANCY=2"
 #   spmm[:args]           SpMM on R-MAT 10M (scripts/spmm_bench.py [n nnz_per_row k ...]) + its kernel stats
 #   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
 TAG=${1:?tag}; shift
@@ -27,6 +29,8 @@ for step in "$@"; do
     tests)
       if [ -n "$arg" ]; then timeout 1800 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -12
       else timeout 1800 python -m pytest tests -m gpu -x -q --durations=6 2>&1 | tail -14; timeout 300 python __graft_entry__.py smoke 2>&1 | grep -v amdgpu | tail -3; fi ;;
+    gate)   timeout 300 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -6
+            if [ "${PIPESTATUS[0]}" != 0 ]; then echo "gate failed: session ends here"; exit 1; fi ;;
     bench)  timeout 900 python bench.py $arg 2>/dev/null | tee -a $OUT/bench.jsonl ;;
     sweep)  IFS='|' read -ra CFG <<< "$arg"; timeout 900 python scripts/spmv_sweep.py --steps 30 --oracle "${CFG[@]}" 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tee -a $OUT/sweep.jsonl ;;
     trace)  ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace -d /tmp/st -o s -- python $ROOT/scripts/spmv_sweep.py --steps 10 "$arg" > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_seq.py $(prof_db /tmp/st) band_ spmv_ ) 2>&1 | cut -c1-200 | tee -a $OUT/kernel_seq.txt ;;
@@ -35,6 +39,12 @@ for step in "$@"; do
     spgemm) timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds" | tee -a $OUT/spgemm.jsonl
             ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/tests/spgemm_bench.py 1000000 8 8 1 > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|sprs_hip" | cut -c1-200 | head -16 | tee -a $OUT/spgemm_kernels.txt
             SPGEMM_PROF=1 timeout 600 python tests/spgemm_bench.py 1000000 8 8 1 2>&1 | grep spgemm_prof | tee -a $OUT/spgemm_kernels.txt ;;
+    spgemm_ab) IFS='|' read -ra CFG <<< "$arg"
+            for c in "${CFG[@]}"; do
+              [ "$c" = base ] && c=""
+              echo "-- ${c:-defaults}" | tee -a $OUT/spgemm_ab.jsonl
+              env $c timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds" | tee -a $OUT/spgemm_ab.jsonl
+            done ;;
     spmm)   timeout 600 python scripts/spmm_bench.py $arg 2>&1 | grep -E "^\{" | tee -a $OUT/spmm.jsonl
             ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spmm_bench.py ${arg:-10000000 32 16} > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|spmm" | cut -c1-200 | head -8 | tee -a $OUT/spmm_kernels.txt ;;
     py)     timeout 900 python $arg 2>&1 | grep -v amdgpu.ids | tee -a $OUT/py.log ;;

@@ -921,6 +921,13 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         o.spgemm_bucket = value ? 1 : 0;
     } else if (!strcmp(name, "spgemm_prof")) {
         o.spgemm_prof = value ? 1 : 0;
+    } else if (!strcmp(name, "spgemm_occupancy")) {
+        if (value != 2 && value != 3) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_occupancy must be 2 or 3");
+        o.spgemm_occupancy = value;
+    } else if (!strcmp(name, "spgemm_retain")) {
+        o.spgemm_retain = value ? 1 : 0;
+    } else if (!strcmp(name, "spgemm_lds_atomic")) {
+        o.spgemm_lds_atomic = value ? 1 : 0;
     } else if (!strcmp(name, "spgemm_winlog")) {
         if (value < 16 || value > 19) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_winlog must be 16..19");
         o.spgemm_winlog = value;
@@ -965,6 +972,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "spmv_band_overlap")) {
         if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_overlap must be 0, 1 or 2");
         o.spmv_band_overlap = value;
+    } else if (!strcmp(name, "spmv_band_split_permute")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_split_permute must be 0, 1 or 2");
+        o.spmv_band_split_permute = value;
     } else if (!strcmp(name, "spmv_band_short")) {
         if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_short must be 0, 1 or 2");
         o.spmv_band_short = value;
@@ -999,6 +1009,9 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_bucket")) *value = o.spgemm_bucket;
     else if (!strcmp(name, "spgemm_prof")) *value = o.spgemm_prof;
     else if (!strcmp(name, "spgemm_heavy")) *value = o.spgemm_heavy;
+    else if (!strcmp(name, "spgemm_lds_atomic")) *value = o.spgemm_lds_atomic;
+    else if (!strcmp(name, "spgemm_retain")) *value = o.spgemm_retain;
+    else if (!strcmp(name, "spgemm_occupancy")) *value = o.spgemm_occupancy;
     else if (!strcmp(name, "spgemm_minwin")) *value = o.spgemm_minwin;
     else if (!strcmp(name, "spgemm_task_order")) *value = o.spgemm_task_order;
     else if (!strcmp(name, "spgemm_xcd_chunk")) *value = o.spgemm_xcd_chunk;
@@ -1016,6 +1029,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_band_split")) *value = o.spmv_band_split;
     else if (!strcmp(name, "spmv_band_short_group")) *value = o.spmv_band_short_group;
     else if (!strcmp(name, "spmv_band_short")) *value = o.spmv_band_short;
+    else if (!strcmp(name, "spmv_band_split_permute")) *value = o.spmv_band_split_permute;
     else if (!strcmp(name, "spmv_band_overlap")) *value = o.spmv_band_overlap;
     else if (!strcmp(name, "spmv_band_hot_threads")) *value = o.spmv_band_hot_threads;
     else if (!strcmp(name, "spmv_band_gather")) *value = o.spmv_band_gather;

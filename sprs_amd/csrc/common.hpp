@@ -48,13 +48,16 @@ struct Options {
     int64_t spmv_sort_tiles = 0;   // plan copies: entries of a tile sorted by column (measured 10 % SLOWER: profiles/r01v)
     int64_t spmv_relabel = 0;      // sliced plan: columns relabelled by count class, x permuted per SpMV: 0 auto (on), 1 on, 2 off
     int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
-    int64_t spgemm_task_order = 0; // large-row tasks: 0/1 window-major (sorted by first column, then row), 2 row-major (A/B)
+    int64_t spgemm_task_order = 0; // large-row tasks: 0/1 costliest first (stable sort by cost class), 2 row order (A/B)
     int64_t spgemm_xcd_chunk = 0;  // large-row task list -> XCDs: 0 round-robin, -1 one contiguous run per XCD
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
-    int64_t spgemm_prof = 0;       // SpGEMM: print a per-phase cycle profile of the large-row numeric kernel (debug)
+    int64_t spgemm_prof = 0;       // SpGEMM: (no longer used; accepted for old scripts)
+    int64_t spgemm_occupancy = 3;  // SpGEMM: workgroups per CU the large-row numeric kernel is compiled for: 3 (80 VGPRs) or 2 (128 VGPRs) (A/B)
+    int64_t spgemm_retain = 1;     // SpGEMM: windows of few entries keep them in registers from the bit pass to the adds (A/B)
+    int64_t spgemm_lds_atomic = 1; // SpGEMM: value adds as ds_add_f64 (1) or read / add / write (0); same order either way (A/B)
     int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)
-    int64_t spgemm_minwin = 13;    // SpGEMM: log2 of the narrowest column window of a heavy row (11..16)
-    int64_t spgemm_heavy = 65536;  // SpGEMM: target products per task of a heavy row (narrower column windows)
+    int64_t spgemm_minwin = 13;    // SpGEMM: (no longer used: heavy rows are cut into runs of whole windows)
+    int64_t spgemm_heavy = 1 << 20;   // SpGEMM: products per task above which a row is cut into several tasks (runs of windows)
     int64_t pool = 1;              // keep released result blocks (>= 1 MiB) for the next result instead of hipFree
     int64_t pool_max_bytes = 128ll << 30;   // cap on the bytes the pool may hold
     int64_t spmv_band = 0;         // banded plan (hot columns from LDS, spmv_band.hip) instead of the XCD-sliced one: 0 auto (on), 1 on, 2 off
@@ -64,6 +67,7 @@ struct Options {
     int64_t spmv_band_hot_threads = 0;    // threads per workgroup of the hot kernel: 1024 (default) or 512
     int64_t spmv_band_gather = 0;         // how the cold kernel reads x: 0 plain, 1 non-temporal, 2 device scope (L1 bypass)
     int64_t spmv_band_overlap = 0;        // cold pieces + short rows on a second stream beside the hot kernel: 0/1 on, 2 off
+    int64_t spmv_band_split_permute = 0;  // with the overlap: hot labels of x gathered first, the rest scattered on the second stream: 0/1 on, 2 off
     int64_t spmv_band_short = 0;          // short rows: 0/2 as one more gather piece, 1 tiled with the 8192 hottest x entries in LDS (measured slower)
     int64_t spmv_band_short_group = 0;    // blocks per workgroup of the tiled short-rows launch (0 = default 4)
     int64_t spmv_band_split = 0;          // rows with at least this many entries are cut into pieces (0 = default 24)

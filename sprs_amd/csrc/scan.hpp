@@ -36,6 +36,10 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *wa
 #ifndef SPRS_LDS_BARRIER   // (the CPU kernel emulator under tests/emu supplies its own two)
 #define SPRS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define SPRS_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+// the LDS operations this wave has issued so far are complete (no wait for global loads / stores in flight)
+#define SPRS_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// inside a loop that polls an LDS word another wave of the workgroup will write
+#define SPRS_POLL_PAUSE() __builtin_amdgcn_s_sleep(1)
 #endif
 __device__ __forceinline__ void lds_barrier() { SPRS_LDS_BARRIER(); }
 

@@ -54,7 +54,6 @@ constexpr int MAX_WIN_LOG2 = 19;          // widest column window of a large-row
 constexpr int LG_BLOCK = 512;             // 8 waves
 constexpr int LG_WAVES = LG_BLOCK / WAVE;
 constexpr int SUPER_WORDS = 32;           // bitmap words per superblock (2048 columns)
-constexpr uint32_t NO_TAG = 0xFFFFFFFFu;
 
 // LDS layout of the large-row kernels for windows of up to 2^WL columns.  The narrower the window
 // the more workgroups share a CU (each phase of a task ends in a barrier, so a lone workgroup
@@ -65,8 +64,8 @@ struct LgCfg {
     static constexpr int WORDS = 1 << (WL - 6);                 // 64-bit bitmap words
     static constexpr int WPT = WORDS / LG_BLOCK;                // words per thread in the popcount prefix
     static constexpr int NSUPER = WORDS / SUPER_WORDS;
-    // accumulators (+ order tags) of one pass; a superblock alone (<= 2048 outputs) must fit
-    static constexpr int ACC_CAP = WL >= 19 ? 5632 : WL == 18 ? 2304 : WL == 17 ? 2048 : 2048;
+    // accumulators of one pass; a superblock alone (<= 2048 outputs) must fit
+    static constexpr int ACC_CAP = WL >= 19 ? 6144 : WL == 18 ? 3072 : WL == 17 ? 3072 : 2048;
     static constexpr int K_CAP = WL >= 18 ? 512 : 256;          // k's staged in LDS per group (<= one per thread)
     static_assert(WL >= 16 && WL <= MAX_WIN_LOG2, "window");
     static_assert(ACC_CAP >= SUPER_WORDS * 64, "a superblock must fit one pass");
@@ -158,9 +157,8 @@ __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 3
 // ---------------------------------------------------------------------------
 template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
-                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t max_wl, uint32_t min_wl,
-                                                       uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks,
-                                                       uint8_t *__restrict__ wlog) {
+                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t wl,
+                                                       uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
@@ -174,21 +172,21 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
         acc = wave_sum_u64(acc);
         if (lane == 0) {
             ub[r] = acc;
-            // Window width of a large row: 2^max_wl columns, narrowed (down to 2^13) for heavy rows so that
-            // a hub row becomes many tasks of ~HEAVY_PRODUCTS products instead of one serial chain.
-            uint32_t wl = max_wl;
+            // A large row is ONE task that walks its column windows (2^wl columns each) one after the other; only a
+            // heavy row (hub) is cut into several tasks of consecutive windows, ~heavy_products products each, so that
+            // it does not become one serial chain at the end of the launch.  large_rows_kernel derives the same
+            // windows-per-task from ntasks[r].
+            uint64_t nt = acc ? 1 : 0;
             if (acc > SMALL_MAX) {
-                uint64_t want = acc / heavy_products;          // desired number of tasks
+                uint64_t nwin = (b_cols + (1ull << wl) - 1) >> wl;
+                if (nwin == 0) nwin = 1;
+                uint64_t want = acc / heavy_products;
                 if (want < 1) want = 1;
-                uint64_t width = b_cols / want;                // columns per task
-                wl = width <= 1 ? 0 : 63 - __clzll((long long)width);   // floor(log2)
-                if (wl > max_wl) wl = max_wl;
-                if (wl < min_wl) wl = min_wl;
-                if (wl > max_wl) wl = max_wl;
+                if (want > nwin) want = nwin;
+                const uint64_t wpt = (nwin + want - 1) / want;
+                nt = (nwin + wpt - 1) / wpt;
             }
-            wlog[r] = (uint8_t)wl;
-            const uint64_t width = 1ull << wl;
-            ntasks[r] = acc == 0 ? 0 : (acc <= SMALL_MAX ? 1 : (b_cols + width - 1) / width);
+            ntasks[r] = nt;
         }
     }
 }
@@ -205,10 +203,11 @@ __global__ void task_class_kernel(const uint64_t *__restrict__ ub, const uint64_
     n_large[r] = (n && u > SMALL_MAX) ? n : 0;
 }
 
-// lists in row order; for the large tasks also the sort key (first column of the window, row): the launch walks them
-// WINDOW-major, so that the tasks running at the same time read the same column range of B
+// lists in row order; for the large tasks also the sort key: the cost class (log2 of the products per task), costliest
+// first, so that the long tasks start early and the short ones fill the tail of the launch (the sort is stable: inside
+// a class the tasks stay in row order, and the list — with it every launch — is the same run to run)
 __global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uint64_t *__restrict__ first_task,
-                                  const uint8_t *__restrict__ wlog, uint64_t rows, const uint64_t *__restrict__ pos_tiny,
+                                  const uint64_t *__restrict__ ub, uint64_t rows, const uint64_t *__restrict__ pos_tiny,
                                   const uint64_t *__restrict__ pos_small, const uint64_t *__restrict__ pos_large,
                                   const uint64_t *__restrict__ is_tiny, const uint64_t *__restrict__ is_small,
                                   uint64_t *__restrict__ task_row, uint64_t *__restrict__ tiny_list,
@@ -226,10 +225,11 @@ __global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uin
         small_list[pos_small[r]] = f;
     } else {
         const uint64_t pos = pos_large[r];
-        const uint32_t wl = wlog[r];
+        const uint64_t cost = ub[r] / n;
+        const uint64_t key = (uint64_t)__clzll((long long)(cost | 1));     // 0 .. 63, small = costly
         for (uint64_t j = 0; j < n; ++j) {
             large_list[pos + j] = f + j;
-            large_key[pos + j] = ((j << wl) << 32) | (r & 0xFFFFFFFFull);
+            large_key[pos + j] = key;
         }
     }
 }
@@ -412,21 +412,81 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
 }
 
 // ---------------------------------------------------------------------------
-// large rows: one workgroup per (row, column window) task, LDS bitmap
-// ---------------------------------------------------------------------------
-// ---------------------------------------------------------------------------
-// large rows: one workgroup per (row, column window) task
+// large rows: one workgroup per task = (row i, a run of consecutive column windows of 2^WL columns)
 //
-// Entries are processed ENTRY-parallel, not k-step by k-step: the k's of the row are staged in
-// groups of K_CAP (their sub-range of B inside the window and the exclusive prefix of the
-// sub-range lengths, in LDS); the concatenation of those sub-ranges — the expansion of the task
-// in the reference's own order, k ascending, columns ascending inside a k — is then walked by all
-// 512 threads, each taking a run of CONSECUTIVE flat positions (one owner search per run, then a
-// step per boundary crossed): every load is independent.
-// (The first design let each wave walk "its" columns one k at a time: 332 M steps of 16 entries,
-// ~2 000 cycles of dependent LDS latency each, 56 % of the kernel — profiles/r01y.)
+// Round 1 / early round 2 made every (row, window) pair its own workgroup: 2.3 M tasks of 2 300 products on config 5,
+// each a chain of ~8 dependent memory round trips (task -> row -> A_i -> B.indptr / bucket table -> entries -> ...) plus a
+// dozen workgroup barriers — the kernels were bound by that fixed cost per task (~50 of 68 us), not by the products
+// (profiles/r02s: symbolic 46 ms, numeric 203 ms; window width 2^19, i.e. 4x fewer tasks at a third of the occupancy,
+// measured the same).  Now a task is a ROW (hub rows: a few runs of windows, option spgemm_heavy), its windows are
+// walked one after the other by the same workgroup, and for the rows whose k's fit one staged group (<= K_CAP; all but
+// ~6 000 rows of config 5) thread j keeps k_j, the bounds of B's row k_j and a_ik in REGISTERS for the whole task:
+// per window it needs ONE bucket-table load (where row k_j crosses the next window edge), issued one window ahead.
+//
+// Per window:  (1) BIT PASS — the concatenation of the k's sub-ranges (the task's expansion in the reference's own
+// order: k ascending, columns ascending inside a k) is walked in batches of 64 consecutive positions per wave
+// instruction (coalesced loads of B's column ids), every entry sets its bit in an LDS bitmap of the window (ds_or);
+// (2) a popcount prefix over the bitmap (super[] per 2048 columns + 16-bit sub[] per word) turns a column into its rank
+// in the output row — the indices come out SORTED without a sort; the symbolic kernel stops at the popcount;
+// (3) VALUES — the window's superblocks are cut greedily into passes of <= ACC_CAP outputs whose accumulators live in
+// LDS; the expansion restricted to the pass is walked again in the same batches.
+//
+// ORDER OF THE ADDITIONS.  The reference builds C(i,j) by a fixed chain (k ascending from +0.0, smmp.rs:174-181), so
+// products that meet in one accumulator must be added in position order, bit for bit.  Earlier versions settled that
+// with per-accumulator order tags and rounds (8.7 rounds and ~11 workgroup barriers per 2048 products).  Now the
+// hardware's own ordering does it: the LDS executes the instructions of ONE wave in issue order, and the lanes of one
+// ds_add_f64 that belong to the same k hit distinct accumulators (columns of a B row are distinct).  So
+//   * a wave adds the products of its batch with one ds_add_f64 per k-run (a run = the lanes of one k, contiguous in
+//     lane order; runs in ascending order) — fire and forget, no read-back, no tags;
+//   * batches are dealt to the waves round-robin and a TOKEN in LDS (the index of the batch whose turn it is) is handed
+//     from wave to wave: a wave loads its entries, computes ranks and products at its own pace, waits for its turn,
+//     issues its adds, waits for them to complete (s_waitcnt lgkmcnt(0)) and passes the token on.  Only the adds are
+//     serialised (a few instructions per batch); loads, searches and rank computations of all waves overlap.
+// No float atomics race anywhere (every accumulator sees its additions in the reference's order) => values bit-exact
+// and deterministic.  tests/test_spgemm_gpu.py compares bits with the oracle; the CPU emulator (tests/emu) runs the
+// hand-over with the waves scheduled in reversed / rotated order.
 // ---------------------------------------------------------------------------
 
+// position of the first entry of row k with column >= v; the row's entries are [row0, ..), those before `lo` are known
+// to be < v and those from `hi` on >= v.  With the bucket table a bound that is a multiple of 2048 costs one load
+// (callers round an upper bound UP past the last column instead of clamping it).
+template <typename IDX, typename PTR>
+__device__ __forceinline__ uint64_t first_ge(const CsrView<IDX, PTR> &B, uint64_t k, uint64_t row0, uint64_t lo, uint64_t hi,
+                                             uint64_t v) {
+    if (B.bucket) {
+        const uint32_t *t = B.bucket + k * B.nb;
+        const uint64_t b = v >> BUCKET_LOG2;
+        if (b >= B.nb - 1) return row0 + t[B.nb - 1];               // past the last column: the whole row
+        const uint64_t p0 = row0 + t[b];
+        if ((v & ((1ull << BUCKET_LOG2) - 1)) == 0) return p0;
+        return lower_bound_col(B.indices, p0, row0 + t[b + 1], v);
+    }
+    return lower_bound_col(B.indices, lo, hi, v);
+}
+
+// Only the k's that HAVE entries in the range are kept (most do not, in a narrow window): the walks then cross exactly
+// one boundary per k instead of idling through runs of empty k's.  One scan carries both the count of kept k's (high
+// word) and the prefix of the lengths (low word).  kP[kept] = total, sentinels behind it for the search.
+template <int K_CAP>
+__device__ __forceinline__ uint32_t stage_compact(uint32_t len, uint64_t s, double av, uint64_t *kS, uint32_t *kP, double *kA,
+                                                  uint64_t *wt) {
+    const uint32_t tid = threadIdx.x;
+    uint64_t tot;
+    const uint64_t ex = block_excl_scan_u64_lds(((uint64_t)(len ? 1u : 0u) << 32) | len, wt, &tot);
+    const uint32_t kept = (uint32_t)(tot >> 32), total = (uint32_t)tot;
+    if (len) {
+        const uint32_t j = (uint32_t)(ex >> 32);
+        kS[j] = s;
+        kP[j] = (uint32_t)ex;
+        if (kA) kA[j] = av;
+    }
+    if (tid == 0) kP[kept] = total;
+    for (uint32_t i = kept + 1 + tid; i <= (uint32_t)K_CAP; i += LG_BLOCK) kP[i] = 0xFFFFFFFFu;
+    lds_barrier();
+    return total;
+}
+
+// general form: the group's k's, their rows of B and the bounds are loaded here (rows with more than K_CAP k's)
 template <int K_CAP, typename IDX, typename PTR>
 __device__ __forceinline__ uint32_t stage_k_group(const CsrView<IDX, PTR> &A, const CsrView<IDX, PTR> &B,
                                                   uint64_t kc, uint32_t n, uint64_t wlo, uint64_t whi, bool whole_row,
@@ -440,32 +500,16 @@ __device__ __forceinline__ uint32_t stage_k_group(const CsrView<IDX, PTR> &A, co
         uint64_t e = (uint64_t)B.indptr[k + 1];
         s = (uint64_t)B.indptr[k];
         // with the bucket table the window bounds do not depend on the row bounds: the two pairs of
-        // loads go out together (one memory round trip less on the task's critical path)
+        // loads go out together (one memory round trip less on the critical path)
         if (!whole_row && (B.bucket || e > s)) row_window(B, k, wlo, whi, s, e);
         len = (uint32_t)(e - s);
         if (kA) av = A.data[kc + tid];
     }
-    // Only the k's that HAVE entries in the window are kept (most do not, in a narrow window): the
-    // walk below then crosses exactly one boundary per step instead of idling through runs of empty k's
-    // (those dependent LDS reads were 70 % of the expansion: profiles/r01z_spgemm_v3_expand_split.txt).
-    // One scan carries both the count of kept k's (high word) and the prefix of the lengths (low word).
-    uint64_t tot;
-    const uint64_t ex = block_excl_scan_u64_lds(((uint64_t)(len ? 1u : 0u) << 32) | len, wt, &tot);
-    const uint32_t kept = (uint32_t)(tot >> 32), total = (uint32_t)tot;
-    if (len) {
-        const uint32_t j = (uint32_t)(ex >> 32);
-        kS[j] = s;
-        kP[j] = (uint32_t)ex;
-        if (kA) kA[j] = av;
-    }
-    if (tid == 0) kP[kept] = total;
-    for (uint32_t i = kept + 1 + tid; i <= (uint32_t)K_CAP; i += LG_BLOCK) kP[i] = 0xFFFFFFFFu;   // sentinels for the search
-    lds_barrier();
-    return total;
+    return stage_compact<K_CAP>(len, s, av, kS, kP, kA, wt);
 }
 
 // owner of flat position t < total: the last k with kP[k] <= t.  kP[0 .. K_CAP] is non-decreasing
-// (total at [n], sentinels behind it), so a fixed-trip, branch-free descent finds it.
+// (total at [kept], sentinels behind it), so a fixed-trip, branch-free descent finds it.
 template <int K_CAP>
 __device__ __forceinline__ uint32_t flat_owner(const uint32_t *kP, uint32_t t) {
     uint32_t lo = 0;
@@ -475,385 +519,364 @@ __device__ __forceinline__ uint32_t flat_owner(const uint32_t *kP, uint32_t t) {
     return lo;
 }
 
-// A thread walks E CONSECUTIVE flat positions: one search for the first, then it only steps to the
-// next k when a position crosses the boundary (one LDS compare per entry instead of a search).
+// A lane's positions inside a batch are 64 apart: it searches its owner once and again only when a position has left
+// the owner's run (long runs — the common case where the products are — cost one LDS compare per entry).
 struct FlatWalk {
-    uint32_t o, nxt;
-    uint64_t base;            // kS[o] - kP[o]: position t lives at B entry base + t
+    uint32_t o = 0, nxt = 0;  // nxt = kP[o + 1]; 0 = nothing found yet
+    uint64_t base = 0;        // kS[o] - kP[o]: position t lives at B entry base + t
     template <int K_CAP>
-    __device__ __forceinline__ void start(const uint64_t *kS, const uint32_t *kP, uint32_t t) {
+    __device__ __forceinline__ void seek(const uint64_t *kS, const uint32_t *kP, uint32_t t) {
+        if (t < nxt) return;
         o = flat_owner<K_CAP>(kP, t);
         nxt = kP[o + 1];
         base = kS[o] - kP[o];
     }
-    // returns true when the owner changed
-    __device__ __forceinline__ bool advance(const uint64_t *kS, const uint32_t *kP, uint32_t t) {
-        if (t < nxt) return false;
-        ++o;                      // kP is strictly increasing (empty k's are not staged): one step
-        nxt = kP[o + 1];
-        base = kS[o] - kP[o];
-        return true;
-    }
 };
 
-template <int K_CAP, typename IDX, typename PTR>
-__device__ __forceinline__ void set_window_bits(const CsrView<IDX, PTR> &A, const CsrView<IDX, PTR> &B, uint64_t as,
-                                                uint64_t ae, uint64_t wlo, uint64_t whi, bool whole_row,
-                                                unsigned long long *bm, uint64_t *kS, uint32_t *kP, double *kA,
-                                                uint64_t *wt, uint32_t &fresh, uint32_t &last_total) {
-    const uint32_t tid = threadIdx.x;
-    for (uint64_t kc = as; kc < ae; kc += K_CAP) {
-        const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
-        const uint32_t tot = stage_k_group<K_CAP>(A, B, kc, n, wlo, whi, whole_row, kS, kP, kA, wt);
-        last_total = tot;
-        constexpr int EB = 8;             // consecutive entries per thread and trip
-        uint32_t *bm32 = (uint32_t *)bm;  // little endian: column c is bit (c & 31) of half-word c >> 5
-        for (uint32_t c0 = 0; c0 < tot; c0 += EB * LG_BLOCK) {
-            const uint32_t t0 = c0 + tid * EB;
-            if (t0 < tot) {
-                FlatWalk wk;
-                wk.start<K_CAP>(kS, kP, t0);
-                uint64_t pos[EB];
+constexpr int LG_U = 4;                    // wave instructions (of 64 consecutive positions) per batch, at most
+
+// batch geometry of a walk over `gtot` positions: a batch is U wave instructions of 64 consecutive positions; few positions ->
+// smaller batches, so that all waves get some.  Up to 64 LG_U LG_WAVES positions every wave has at most ONE batch.
+__device__ __forceinline__ uint32_t batch_u(uint32_t gtot) {
+    return gtot > 64u * 2 * LG_WAVES ? (uint32_t)LG_U : gtot > 64u * LG_WAVES ? 2u : 1u;
+}
+
+// the entries of one batch as a wave holds them: lane l, instruction u = position (b U + u) 64 + l
+struct Batch {
+    uint32_t cc[LG_U];        // column - first column of the window
+    uint32_t own[LG_U];       // staged k the entry belongs to (ascending with the position)
+    double pr[LG_U];          // a_ik * b_kj
+    bool val[LG_U];
+};
+
+template <int K_CAP, bool VALUES, typename IDX>
+__device__ __forceinline__ void batch_load(Batch &bt, const IDX *__restrict__ b_indices, const double *__restrict__ b_data,
+                                           uint64_t wlo, uint32_t gtot, uint32_t U, uint32_t b, const uint64_t *kS,
+                                           const uint32_t *kP, const double *kA) {
+    const uint32_t t0 = b * (64 * U) + (threadIdx.x & (WAVE - 1));
+    FlatWalk wk;
+    uint64_t pos[LG_U];
+    double av[LG_U];
 #pragma unroll
-                for (int e = 0; e < EB; ++e) {
-                    pos[e] = ~0ull;
-                    if (t0 + e < tot) {
-                        wk.advance(kS, kP, t0 + e);
-                        pos[e] = wk.base + (t0 + e);
-                    }
-                }
-                uint32_t c[EB];
+    for (int u = 0; u < LG_U; ++u) {
+        const uint32_t t = t0 + 64u * u;
+        bt.val[u] = (uint32_t)u < U && t < gtot;
+        pos[u] = 0;
+        bt.own[u] = 0;
+        av[u] = 0.0;
+        if (bt.val[u]) {
+            wk.seek<K_CAP>(kS, kP, t);
+            pos[u] = wk.base + t;
+            bt.own[u] = wk.o;
+            if constexpr (VALUES) av[u] = kA[wk.o];
+        }
+    }
+    double bv[LG_U];
 #pragma unroll
-                for (int e = 0; e < EB; ++e) c[e] = pos[e] != ~0ull ? (uint32_t)((uint64_t)B.indices[pos[e]] - wlo) : 0xFFFFFFFFu;
+    for (int u = 0; u < LG_U; ++u) {           // all loads of the batch are independent
+        bt.cc[u] = bt.val[u] ? (uint32_t)((uint64_t)b_indices[pos[u]] - wlo) : 0u;
+        bv[u] = 0.0;
+        if constexpr (VALUES) bv[u] = bt.val[u] ? b_data[pos[u]] : 0.0;
+    }
 #pragma unroll
-                for (int e = 0; e < EB; ++e) {
-                    if (c[e] != 0xFFFFFFFFu) {
-                        const uint32_t bit = 1u << (c[e] & 31);
-                        const uint32_t old = atomicOr(&bm32[c[e] >> 5], bit);
-                        fresh += (old & bit) ? 0u : 1u;
-                    }
-                }
+    for (int u = 0; u < LG_U; ++u) bt.pr[u] = av[u] * bv[u];
+}
+
+__device__ __forceinline__ void batch_bits(const Batch &bt, uint32_t *bm32) {
+#pragma unroll
+    for (int u = 0; u < LG_U; ++u)
+        if (bt.val[u]) atomicOr(&bm32[bt.cc[u] >> 5], 1u << (bt.cc[u] & 31));   // little endian: bit c & 63 of word c >> 6
+}
+
+template <int K_CAP, typename IDX>
+__device__ __forceinline__ void walk_bits(const IDX *__restrict__ b_indices, uint64_t wlo, uint32_t gtot, const uint64_t *kS,
+                                          const uint32_t *kP, uint32_t *bm32) {
+    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t U = batch_u(gtot);
+    const uint32_t nbatch = (gtot + 64 * U - 1) / (64 * U);
+    for (uint32_t b = wave; b < nbatch; b += LG_WAVES) {
+        Batch bt;
+        batch_load<K_CAP, false>(bt, b_indices, (const double *)nullptr, wlo, gtot, U, b, kS, kP, (const double *)nullptr);
+        batch_bits(bt, bm32);
+    }
+}
+
+__device__ __forceinline__ void token_wait(uint32_t *token, uint32_t turn) {
+    while (*(volatile uint32_t *)token != turn) SPRS_POLL_PAUSE();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void token_pass(uint32_t *token, uint32_t next) {
+    SPRS_LDS_FENCE();                      // this wave's adds have been performed
+    if ((threadIdx.x & (WAVE - 1)) == 0) *(volatile uint32_t *)token = next;
+}
+
+// the products of one wave instruction (64 consecutive positions, owners ascending with the lane): one add instruction
+// per k-run, runs in ascending order
+__device__ __forceinline__ void add_runs(bool val, uint32_t own, uint32_t slot, double pr, double *acc, bool lds_atomic) {
+    unsigned long long todo = __ballot(val);
+    while (todo) {
+        const int first = __ffsll((long long)todo) - 1;
+        const uint32_t oo = (uint32_t)__builtin_amdgcn_readlane((int)own, first);
+        const bool mine = val && own == oo;
+        if (mine) {
+            if (lds_atomic) {
+                atomicAdd(&acc[slot], pr);               // ds_add_f64, no return value
+            } else {
+                volatile double *a = acc + slot;         // A/B switch: read, add, write (same order, three instructions)
+                *a = *a + pr;
             }
         }
-        lds_barrier();                  // the next group overwrites kS / kP
+        todo &= ~__ballot(mine);
     }
 }
 
-template <int WL, typename IDX, typename PTR>
-__global__ __launch_bounds__(LG_BLOCK) void large_symbolic_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B,
-                                                                  uint64_t b_cols, const uint64_t *__restrict__ large_list,
-                                                                  const uint64_t *__restrict__ task_row,
-                                                                  const uint64_t *__restrict__ first_task,
-                                                                  const uint64_t *__restrict__ ntasks,
-                                                                  const uint8_t *__restrict__ wlog,
-                                                                  uint64_t *__restrict__ count, uint32_t xcd_chunk) {
-    using Cfg = LgCfg<WL>;
-    constexpr int K_CAP = Cfg::K_CAP;
-    __shared__ unsigned long long bm[Cfg::WORDS];
-    __shared__ uint64_t kS[K_CAP];
-    __shared__ uint32_t kP[K_CAP + 1];
-    __shared__ uint64_t wt[16];
-    __shared__ uint64_t red[LG_WAVES];
-    const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x, xcd_chunk)];
-    const uint64_t r = task_row[t];
-    const uint64_t w = t - first_task[r];
-    const uint32_t wl = wlog[r];
-    const int words = (int)((1ull << wl) / 64);
-    const uint64_t wlo = w << wl, whi = wlo + (1ull << wl);   // not clamped to b_cols: see row_window
-    for (int i = threadIdx.x; i < words; i += LG_BLOCK) bm[i] = 0;
-    lds_barrier();
-    uint32_t fresh = 0, unused_total = 0;
-    set_window_bits<Cfg::K_CAP>(A, B, (uint64_t)A.indptr[r], (uint64_t)A.indptr[r + 1], wlo, whi, ntasks[r] == 1, bm, kS, kP,
-                                (double *)nullptr, wt, fresh, unused_total);
-    const uint64_t ws = wave_sum_u64(fresh);
-    if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = ws;
-    lds_barrier();
-    if (threadIdx.x == 0) {
-        uint64_t tot = 0;
-        for (int i = 0; i < LG_WAVES; ++i) tot += red[i];
-        count[t] = tot;
+// ranks of the batch's columns (before the turn: only the adds are serialised), then the adds when the token arrives
+__device__ __forceinline__ void batch_add(const Batch &bt, uint32_t U, const unsigned long long *bm, const uint16_t *sub,
+                                          const uint32_t *super, uint32_t base_rank, double *acc, uint32_t *token, uint32_t turn,
+                                          bool lds_atomic) {
+    uint32_t slot[LG_U];
+#pragma unroll
+    for (int u = 0; u < LG_U; ++u) {
+        const uint32_t word = bt.cc[u] >> 6;
+        slot[u] = bt.val[u] ? super[word / SUPER_WORDS] + sub[word] +
+                                  (uint32_t)__popcll(bm[word] & ((1ull << (bt.cc[u] & 63)) - 1ull)) - base_rank
+                            : 0u;
     }
+    token_wait(token, turn);
+#pragma unroll
+    for (int u = 0; u < LG_U; ++u)
+        if ((uint32_t)u < U) add_runs(bt.val[u], bt.own[u], slot[u], bt.pr[u], acc, lds_atomic);
+    token_pass(token, turn + 1);
 }
 
-template <int WL, typename IDX, typename PTR>
-__global__ __launch_bounds__(LG_BLOCK) void large_numeric_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B,
-                                                                 uint64_t b_cols, const uint64_t *__restrict__ large_list,
-                                                                 const uint64_t *__restrict__ task_row,
-                                                                 const uint64_t *__restrict__ first_task,
-                                                                 const uint64_t *__restrict__ ntasks,
-                                                                 const uint8_t *__restrict__ wlog,
-                                                                 const uint64_t *__restrict__ count,
-                                                                 const uint64_t *__restrict__ off,
-                                                                 IDX *__restrict__ c_indices, double *__restrict__ c_data,
-                                                                 unsigned long long *__restrict__ prof, uint32_t xcd_chunk) {
+// value walk of one staged group restricted to a pass; returns the number of batches (the token advances by it)
+template <int K_CAP, typename IDX>
+__device__ __forceinline__ uint32_t walk_values(const IDX *__restrict__ b_indices, const double *__restrict__ b_data, uint64_t wlo,
+                                                uint32_t gtot, const uint64_t *kS, const uint32_t *kP, const double *kA,
+                                                const unsigned long long *bm, const uint16_t *sub, const uint32_t *super,
+                                                uint32_t base_rank, double *acc, uint32_t *token, uint32_t tok_base,
+                                                bool lds_atomic) {
+    const uint32_t wave = threadIdx.x / WAVE;
+    const uint32_t U = batch_u(gtot);
+    const uint32_t nbatch = (gtot + 64 * U - 1) / (64 * U);
+    for (uint32_t b = wave; b < nbatch; b += LG_WAVES) {
+        Batch bt;
+        batch_load<K_CAP, true>(bt, b_indices, b_data, wlo, gtot, U, b, kS, kP, kA);
+        batch_add(bt, U, bm, sub, super, base_rank, acc, token, tok_base + b, lds_atomic);
+    }
+    return nbatch;
+}
+
+// OCC = waves per SIMD the register allocation aims at: 6 = three workgroups per CU (what the LDS of the 2^16 / 2^17
+// layouts allows; 80 VGPRs, a few spills), 4 = two per CU with 128 VGPRs (option spgemm_occupancy, A/B)
+template <int WL, typename IDX, typename PTR, bool NUMERIC, int OCC>
+__global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t b_cols,
+                                                              const uint64_t *__restrict__ large_list,
+                                                              const uint64_t *__restrict__ task_row,
+                                                              const uint64_t *__restrict__ first_task,
+                                                              const uint64_t *__restrict__ ntasks,
+                                                              uint64_t *__restrict__ count,       // symbolic: out
+                                                              const uint64_t *__restrict__ off,   // numeric: in
+                                                              IDX *__restrict__ c_indices, double *__restrict__ c_data,
+                                                              uint32_t xcd_chunk, uint32_t flags) {
     using Cfg = LgCfg<WL>;
-    constexpr int WPT = Cfg::WPT, NSUPER = Cfg::NSUPER, ACC_CAP = Cfg::ACC_CAP, K_CAP = Cfg::K_CAP;
-    __shared__ unsigned long long bm[Cfg::WORDS];   // the window's structure: one bit per column
-    __shared__ uint16_t sub[Cfg::WORDS];            // outputs before a word inside its superblock
-    __shared__ uint32_t super[NSUPER + 1];          // outputs before each 2048-column superblock
-    __shared__ double acc[ACC_CAP];                 // accumulators of the current pass
-    __shared__ uint32_t tag[ACC_CAP];               // earliest pending entry per accumulator (ordering)
-    __shared__ uint32_t more_flag[3];
+    constexpr int WORDS = Cfg::WORDS, WPT = Cfg::WPT, NSUPER = Cfg::NSUPER, ACC_CAP = Cfg::ACC_CAP, K_CAP = Cfg::K_CAP;
+    __shared__ unsigned long long bm[WORDS];                 // the window's structure: one bit per column
+    __shared__ uint16_t sub[NUMERIC ? WORDS : 1];            // outputs before a word inside its superblock
+    __shared__ uint32_t super[NUMERIC ? NSUPER + 1 : 1];     // outputs before each 2048-column superblock
+    __shared__ double acc[NUMERIC ? ACC_CAP : 1];            // accumulators of the current pass
     __shared__ uint64_t kS[K_CAP];
     __shared__ uint32_t kP[K_CAP + 1];
-    __shared__ double kA[K_CAP];
+    __shared__ double kA[NUMERIC ? K_CAP : 1];
     __shared__ uint64_t wt[16];
+    __shared__ uint32_t token;
     const uint32_t tid = threadIdx.x;
     const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x, xcd_chunk)];
     const uint64_t r = task_row[t];
-    const uint64_t w = t - first_task[r];
-    const uint32_t wl = wlog[r];
-    const int words = (int)((1ull << wl) / 64);
-    const uint64_t wlo = w << wl, whi = wlo + (1ull << wl);   // not clamped to b_cols: see row_window
+    const uint64_t jt = t - first_task[r], nt = ntasks[r];
+    constexpr uint64_t W = 1ull << WL;
+    uint64_t nwin = (b_cols + W - 1) >> WL;
+    if (nwin == 0) nwin = 1;
+    const uint64_t wpt = (nwin + nt - 1) / nt;               // windows per task of this row (row_work_kernel)
+    const uint64_t w_begin = jt * wpt;
+    uint64_t w_end = w_begin + wpt;
+    if (w_end > nwin) w_end = nwin;
     const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
-    const bool whole_row = ntasks[r] == 1;
-    const uint64_t out = off[t];
-    const uint32_t cnt = (uint32_t)count[t];
-    if (cnt == 0) return;                           // window without outputs (block-uniform)
-    // optional phase profile (debug option spgemm_prof): cycles of thread 0 per phase, summed over tasks
-    long long t_prev = prof ? (long long)clock64() : 0;
-    const long long t_begin = t_prev;
-    uint32_t n_rounds = 0, n_chunks = 0;
-    // (accumulated in LDS and flushed once per task: a global atomic per mark serialises all workgroups
-    // on 16 addresses and every s_waitcnt vmcnt(0) after it then measures THAT, not the phase)
-    __shared__ unsigned long long pacc[16];
-    if (prof && tid < 16) pacc[tid] = 0;
-    auto mark = [&](int phase) {
-        if (prof && tid == 0) {
-            const long long now = (long long)clock64();
-            pacc[phase] += (unsigned long long)(now - t_prev);
-            t_prev = now;
-        }
-    };
-
-    for (int i = tid; i < words; i += LG_BLOCK) bm[i] = 0;
-    lds_barrier();
-    uint32_t fresh = 0;
-    uint32_t k_total = 0;      // entries of the (last) staged group: reused by a one-group, one-pass task
-    set_window_bits<Cfg::K_CAP>(A, B, as, ae, wlo, whi, whole_row, bm, kS, kP, kA, wt, fresh, k_total);
-    mark(0);   // clear + bits
-
-    // popcount prefix.  Words are dealt to the threads INTERLEAVED (thread tid takes words tid, tid + 512, ...):
-    // consecutive lanes read consecutive LDS words (the blocked assignment, 16 consecutive words per thread at
-    // 2^19 columns, put all 64 lanes on two bank groups — 32-way conflicts on every read), and the dense low
-    // columns of a power-law window are spread over all threads instead of a few.  A superblock is 32 words =
-    // half a wave: its inner prefix is a 32-lane shuffle scan.  (Measured neutral on config 5 — this phase is
-    // a chain of dependent LDS operations either way, profiles/r01z_spgemm_v4_experiments.txt.)
-    static_assert(SUPER_WORDS == 32, "superblock = half a wave");
-#pragma unroll 1
-    for (int i = 0; i < WPT; ++i) {
-        const int word = i * LG_BLOCK + (int)tid;
-        if (i * LG_BLOCK >= words) break;                       // block-uniform
-        const uint32_t pc = word < words ? (uint32_t)__popcll(bm[word]) : 0u;
-        uint32_t inc = pc;
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const uint32_t o = __shfl_up(inc, off, 32);
-            if ((tid & 31u) >= (uint32_t)off) inc += o;
-        }
-        if (word < words) {
-            sub[word] = (uint16_t)(inc - pc);
-            if ((tid & 31u) == 31u) super[word / SUPER_WORDS] = inc;   // superblock total, turned into a prefix below
-        }
-    }
-    lds_barrier();
-    const int nsb = (words + SUPER_WORDS - 1) / SUPER_WORDS;       // <= NSUPER <= 512 = one per thread
-    uint32_t tot;
-    const uint32_t spre = block_excl_scan_u32_lds((int)tid < nsb ? super[tid] : 0u, (uint32_t *)wt, &tot);
-    if ((int)tid < nsb) super[tid] = spre;
-    if (tid == 0) super[nsb] = tot;
-    lds_barrier();
-    // indices come out sorted: walk the set bits of each word in order
-#pragma unroll 1
-    for (int i = 0; i < WPT && c_indices; ++i) {                // (no index array: C already has its structure)
-        const int word = i * LG_BLOCK + (int)tid;
-        if (word >= words) break;
-        unsigned long long m = bm[word];
-        uint32_t run = super[word / SUPER_WORDS] + sub[word];
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            c_indices[out + run] = (IDX)(wlo + (uint64_t)word * 64 + (uint64_t)b);
-            ++run;
-        }
-    }
-    mark(1);   // prefix + emit indices
-    if (!c_data) return;   // structure only (the twin of smmp::symbolic): block-uniform
-
-    // ---- values ----------------------------------------------------------------------------------
-    // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) of at most ACC_CAP outputs,
-    // whose accumulators live in LDS.  Inside a pass the expansion restricted to the pass's columns is
-    // walked in the reference's order (k ascending), 4 x 512 entries at a time, all loads independent.
-    // ORDER: C(i,j) must be built by the reference's chain of additions (smmp.rs:174-181), so two
-    // entries of one chunk that hit the same accumulator may not be added in arbitrary order (and
-    // float atomics are out anyway): see "Ordered accumulation of the chunk" below.  Deterministic and bit-exact.
-    constexpr int U = 4;
     const bool one_group = ae - as <= (uint64_t)K_CAP;
-    const int nsuper = (words + SUPER_WORDS - 1) / SUPER_WORDS;
-    uint32_t pb = 0;
-    while (pb < (uint32_t)nsuper) {
-        uint32_t pe = pb + 1;
-        while (pe < (uint32_t)nsuper && super[pe + 1] - super[pb] <= (uint32_t)ACC_CAP) ++pe;
-        const uint32_t base_rank = super[pb];
-        const uint32_t pass_out = super[pe] - base_rank;
-        if (pass_out) {                                  // block-uniform
-            for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) {
-                acc[i] = 0.0;
-                tag[i] = NO_TAG;
+    const bool values = NUMERIC && c_data != nullptr;
+    const bool lds_atomic = (flags & 1u) != 0;
+    const bool retain_ok = values && (flags & 2u) != 0;
+    // a row whose k's fit one staged group: thread j keeps k_j, the bounds of B's row k_j and a_ik for the whole task
+    const bool mine_k = one_group && tid < (uint32_t)(ae - as) && w_begin < w_end;
+    uint64_t rk = 0, rs = 0, re = 0, cur = 0, nxt_e = 0;
+    double rav = 0.0;
+    if (mine_k) {
+        rk = (uint64_t)A.indices[as + tid];
+        rs = (uint64_t)B.indptr[rk];
+        re = (uint64_t)B.indptr[rk + 1];
+        if (values) rav = A.data[as + tid];
+        cur = w_begin == 0 ? rs : first_ge(B, rk, rs, rs, re, w_begin << WL);
+        nxt_e = w_begin + 1 >= nwin ? re : first_ge(B, rk, rs, cur, re, (w_begin + 1) << WL);
+    }
+    if (tid == 0) token = 0;
+    for (int i = tid; i < WORDS; i += LG_BLOCK) bm[i] = 0;
+    lds_barrier();
+    uint64_t out = 0;
+    if constexpr (NUMERIC) out = off[t];
+    uint32_t fresh = 0, tok_base = 0;
+    (void)tok_base;
+    for (uint64_t w = w_begin; w < w_end; ++w) {
+        const uint64_t wlo = w << WL, whi = wlo + W;         // whi is not clamped to b_cols: see first_ge
+        const uint64_t wcols = (whi < b_cols ? whi : b_cols) - wlo;
+        const int words = (int)((wcols + SUPER_WORDS * 64 - 1) / (SUPER_WORDS * 64)) * SUPER_WORDS;   // whole superblocks
+        // my k's sub-range in this window; the bound of the next window is requested now and used one window later
+        const uint64_t ws = cur, we = nxt_e;
+        if (mine_k) {
+            cur = we;
+            if (w + 1 < w_end) nxt_e = w + 2 >= nwin ? re : first_ge(B, rk, rs, we, re, (w + 2) << WL);
+        }
+        // ---- bit pass -------------------------------------------------------------------------------
+        uint32_t k_total = 0;
+        bool any = false, retain = false;
+        Batch kept;
+        for (uint64_t kc = as; kc < ae; kc += K_CAP) {
+            const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
+            const uint32_t gtot =
+                one_group ? stage_compact<K_CAP>(mine_k ? (uint32_t)(we - ws) : 0u, ws, rav, kS, kP, values ? kA : (double *)nullptr, wt)
+                          : stage_k_group<K_CAP>(A, B, kc, n, wlo, whi, nwin == 1, kS, kP, values ? kA : (double *)nullptr, wt);
+            k_total = gtot;
+            any |= gtot != 0;
+            if constexpr (NUMERIC) {
+                // A window of few entries (one batch per wave at most) is loaded ONCE: column, value and owner stay in
+                // registers from the bit pass to the adds (its outputs fit one pass: <= 64 LG_U LG_WAVES <= ACC_CAP).
+                retain = retain_ok && one_group && gtot <= 64u * LG_U * LG_WAVES;     // block-uniform
+                if (retain) {
+                    const uint32_t U = batch_u(gtot), wave = tid / WAVE;
+#pragma unroll
+                    for (int u = 0; u < LG_U; ++u) kept.val[u] = false;
+                    if (wave * 64 * U < gtot) {
+                        batch_load<K_CAP, true>(kept, B.indices, B.data, wlo, gtot, U, wave, kS, kP, kA);
+                        batch_bits(kept, (uint32_t *)bm);
+                    }
+                    continue;
+                }
             }
-            if (tid < 3) more_flag[tid] = 0;
-            uint32_t rd = 0;
-            // the tags must be in place before anyone posts on them: a late NO_TAG landing between two posts on
-            // the same accumulator would let the LATER entry win a round (seen once as a 1-ulp difference in
-            // 33 M checked values when the staging below is skipped and no other barrier intervenes)
+            walk_bits<K_CAP>(B.indices, wlo, gtot, kS, kP, (uint32_t *)bm);
+        }
+        lds_barrier();
+        if (!any) continue;                                  // block-uniform; the bitmap is still clear
+        if constexpr (!NUMERIC) {
+            for (int i = tid; i < words; i += LG_BLOCK) {
+                fresh += (uint32_t)__popcll(bm[i]);
+                bm[i] = 0;
+            }
             lds_barrier();
-            const bool single = pb == 0 && pe == (uint32_t)nsuper;
-            const uint64_t plo = wlo + (uint64_t)pb * (SUPER_WORDS * 64);
-            const uint64_t phi = wlo + (uint64_t)pe * (SUPER_WORDS * 64);
-            for (uint64_t kc = as; kc < ae; kc += K_CAP) {
-                const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
-                // a task with one group of k's and one pass finds kS / kP / kA as the bit pass left them
-                const uint32_t gtot = (single && one_group)
-                                          ? k_total
-                                          : stage_k_group<K_CAP>(A, B, kc, n, single ? wlo : plo, single ? whi : phi,
-                                                                 single && whole_row, kS, kP, kA, wt);
-                mark(8);
-                for (uint32_t c0 = 0; c0 < gtot; c0 += U * LG_BLOCK) {
-                    // thread tid takes positions c0 + U tid .. + U - 1 (order inside the chunk = U tid + u)
-                    uint32_t slot[U], pos_in_chunk[U];
-                    double pr[U];
-                    bool pend[U];
-                    const uint32_t t0 = c0 + tid * U;
-                    uint64_t pos[U];
-                    double av[U];
-                    if (t0 < gtot) {
-                        FlatWalk wk;
-                        wk.start<K_CAP>(kS, kP, t0);
-                        double a_cur = kA[wk.o];
+        } else {
+            // ---- popcount prefix ------------------------------------------------------------------------
+            // Words are dealt to the threads INTERLEAVED (thread tid takes words tid, tid + 512, ...): consecutive lanes
+            // read consecutive LDS words, and the dense low columns of a power-law window are spread over all threads.
+            // A superblock is 32 words = half a wave: its inner prefix is a 32-lane shuffle scan.
+            static_assert(SUPER_WORDS == 32, "superblock = half a wave");
+#pragma unroll 1
+            for (int i = 0; i < WPT; ++i) {
+                const int word = i * LG_BLOCK + (int)tid;
+                if (i * LG_BLOCK >= words) break;                       // block-uniform
+                const uint32_t pc = word < words ? (uint32_t)__popcll(bm[word]) : 0u;
+                uint32_t inc = pc;
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            pend[u] = t0 + u < gtot;
-                            pos[u] = 0;
-                            if (pend[u]) {
-                                if (wk.advance(kS, kP, t0 + u)) a_cur = kA[wk.o];
-                                pos[u] = wk.base + (t0 + u);
-                            }
-                            av[u] = a_cur;
-                        }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            pend[u] = false;
-                            pos[u] = 0;
-                            av[u] = 0.0;
-                        }
-                    }
-                    if (prof) {
-                        SPRS_WAIT_ALL();
-                        mark(2);   // owner search + walk (LDS only)
-                    }
-                    uint32_t cc[U];
-                    double bv[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        cc[u] = pend[u] ? (uint32_t)((uint64_t)B.indices[pos[u]] - wlo) : 0u;
-                        bv[u] = pend[u] ? B.data[pos[u]] : 0.0;
-                    }
-                    if (prof) {
-                        SPRS_WAIT_ALL();
-                        mark(4);   // the 2 U loads of B entries
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        pos_in_chunk[u] = tid * U + (uint32_t)u;
-                        pr[u] = av[u] * bv[u];
-                        const uint32_t word = cc[u] >> 6;
-                        slot[u] = pend[u] ? super[word / SUPER_WORDS] + sub[word] +
-                                                (uint32_t)__popcll(bm[word] & ((1ull << (cc[u] & 63)) - 1ull)) - base_rank
-                                          : 0u;
-                    }
-                    mark(12);
-                    ++n_chunks;
-                    // Ordered accumulation of the chunk (the sums must be taken in chunk order = k order, bit for bit):
-                    //  (1) every entry counts itself on its accumulator's tag; an accumulator with ONE entry in the
-                    //      chunk (most of them) takes it at once;
-                    //  (2) the others — hub columns of B — are added wave by wave: a wave's entries all precede the
-                    //      next wave's in chunk order, so each wave settles its own with wave-local rounds (the
-                    //      smallest position posted on a tag wins the round), one workgroup barrier per wave instead
-                    //      of two per round of the whole workgroup.
-                    // A tag is NO_TAG when idle, before and after.
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        if (pend[u]) atomicSub(&tag[slot[u]], 1u);
-                    if (tid == 0) more_flag[(rd + 1) % 3] = 0;
-                    lds_barrier();
-                    {
-                        bool conflict = false;
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            if (pend[u]) {
-                                if (tag[slot[u]] == NO_TAG - 1u) {       // mine alone: nobody else reads this tag
-                                    acc[slot[u]] += pr[u];
-                                    tag[slot[u]] = NO_TAG;
-                                    pend[u] = false;
-                                } else {
-                                    conflict = true;
-                                }
-                            }
-                        }
-                        if (conflict) more_flag[rd % 3] = 1;
-                    }
-                    lds_barrier();                                       // every count has been read
-                    const bool ordered_phase = more_flag[rd % 3] != 0;   // block-uniform
-                    ++rd;                                                // (keeps counting across chunks: the flag rotation never restarts)
-                    if (ordered_phase) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u)
-                            if (pend[u]) tag[slot[u]] = NO_TAG;
-                        lds_barrier();
-                        for (uint32_t v = 0; v < (uint32_t)LG_WAVES; ++v) {
-                            if (tid / WAVE == v) {                       // wave-uniform
-                                for (;;) {
-                                    bool mine_pending = false;
-#pragma unroll
-                                    for (int u = 0; u < U; ++u) mine_pending |= pend[u];
-                                    if (__ballot(mine_pending) == 0ull) break;
-                                    ++n_rounds;
-#pragma unroll
-                                    for (int u = 0; u < U; ++u)
-                                        if (pend[u]) atomicMin(&tag[slot[u]], pos_in_chunk[u]);
-                                    wave_sync_lds();
-#pragma unroll
-                                    for (int u = 0; u < U; ++u) {
-                                        if (pend[u] && tag[slot[u]] == pos_in_chunk[u]) {
-                                            acc[slot[u]] += pr[u];
-                                            tag[slot[u]] = NO_TAG;
-                                            pend[u] = false;
-                                        }
-                                    }
-                                    wave_sync_lds();
-                                }
-                            }
-                            lds_barrier();
-                        }
+                for (int o = 1; o < 32; o <<= 1) {
+                    const uint32_t v = __shfl_up(inc, o, 32);
+                    if ((tid & 31u) >= (uint32_t)o) inc += v;
+                }
+                if (word < words) {
+                    sub[word] = (uint16_t)(inc - pc);
+                    if ((tid & 31u) == 31u) super[word / SUPER_WORDS] = inc;   // superblock total, turned into a prefix below
+                }
+            }
+            lds_barrier();
+            const int nsb = words / SUPER_WORDS;                   // <= NSUPER <= 512 = one per thread
+            uint32_t wtot;
+            const uint32_t spre = block_excl_scan_u32_lds((int)tid < nsb ? super[tid] : 0u, (uint32_t *)wt, &wtot);
+            if ((int)tid < nsb) super[tid] = spre;
+            if (tid == 0) super[nsb] = wtot;
+            lds_barrier();
+            // indices come out sorted: walk the set bits of each word in order
+            if (c_indices) {                                        // (null: C already has its structure)
+#pragma unroll 1
+                for (int i = 0; i < WPT; ++i) {
+                    const int word = i * LG_BLOCK + (int)tid;
+                    if (word >= words) break;
+                    unsigned long long m = bm[word];
+                    uint32_t run = super[word / SUPER_WORDS] + sub[word];
+                    while (m) {
+                        const int bit = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        c_indices[out + run] = (IDX)(wlo + (uint64_t)word * 64 + (uint64_t)bit);
+                        ++run;
                     }
                 }
-                mark(9);
             }
-            for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
+            // ---- values ---------------------------------------------------------------------------------
+            // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) of at most ACC_CAP outputs
+            uint32_t pb = 0;
+            while (values && pb < (uint32_t)nsb) {
+                uint32_t pe = pb + 1;
+                while (pe < (uint32_t)nsb && super[pe + 1] - super[pb] <= (uint32_t)ACC_CAP) ++pe;
+                const uint32_t base_rank = super[pb];
+                const uint32_t pass_out = super[pe] - base_rank;
+                if (pass_out) {                                  // block-uniform
+                    for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) acc[i] = 0.0;   // tmp starts at N::zero()
+                    const bool single = pb == 0 && pe == (uint32_t)nsb;
+                    const uint64_t plo = wlo + (uint64_t)pb * (SUPER_WORDS * 64);
+                    const uint64_t phi = wlo + (uint64_t)pe * (SUPER_WORDS * 64);
+                    if (retain) {                                // (then single: see the bit pass)
+                        lds_barrier();                           // the accumulators are clear before anybody adds
+                        const uint32_t U = batch_u(k_total), wave = tid / WAVE;
+                        const uint32_t nbatch = (k_total + 64 * U - 1) / (64 * U);
+                        if (wave < nbatch) batch_add(kept, U, bm, sub, super, base_rank, acc, &token, tok_base + wave, lds_atomic);
+                        tok_base += nbatch;
+                    } else
+                    for (uint64_t kc = as; kc < ae; kc += K_CAP) {
+                        const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
+                        uint32_t gtot;
+                        if (single && one_group) {
+                            gtot = k_total;                      // kS / kP / kA as the bit pass left them
+                            lds_barrier();                       // the accumulators are clear before anybody adds
+                        } else if (one_group) {
+                            uint64_t s = ws, e = ws;
+                            if (mine_k && we > ws) {
+                                s = pb == 0 ? ws : first_ge(B, rk, rs, ws, we, plo);
+                                e = pe == (uint32_t)nsb ? we : first_ge(B, rk, rs, s, we, phi);
+                            }
+                            gtot = stage_compact<K_CAP>((uint32_t)(e - s), s, rav, kS, kP, kA, wt);
+                        } else {
+                            gtot = stage_k_group<K_CAP>(A, B, kc, n, single ? wlo : plo, single ? whi : phi, single && nwin == 1,
+                                                        kS, kP, kA, wt);
+                        }
+                        tok_base += walk_values<K_CAP>(B.indices, B.data, wlo, gtot, kS, kP, kA, bm, sub, super, base_rank, acc,
+                                                       &token, tok_base, lds_atomic);
+                    }
+                    lds_barrier();                               // every add has been performed
+                    for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
+                    lds_barrier();                               // the next pass clears the accumulators
+                }
+                pb = pe;
+            }
+            out += wtot;
+            for (int i = tid; i < words; i += LG_BLOCK) bm[i] = 0;
             lds_barrier();
-            mark(10);
-            if (prof && tid == 0) pacc[11] += 1ull;
         }
-        pb = pe;
     }
-    if (prof && tid == 0) {
-        for (int i = 0; i < 13; ++i)
-            if (i != 6 && pacc[i]) atomicAdd(&prof[i], pacc[i]);
-        atomicAdd(&prof[6], 1ull);
-        atomicAdd(&prof[13], (unsigned long long)n_chunks);
-        atomicAdd(&prof[14], (unsigned long long)n_rounds);
-        atomicMax(&prof[15], (unsigned long long)((long long)clock64() - t_begin));
+    if constexpr (!NUMERIC) {
+        const uint64_t wsum = wave_sum_u64(fresh);
+        if ((tid & (WAVE - 1)) == 0) wt[tid / WAVE] = wsum;
+        lds_barrier();
+        if (tid == 0) {
+            uint64_t tot = 0;
+            for (int i = 0; i < LG_WAVES; ++i) tot += wt[i];
+            count[t] = tot;
+        }
     }
 }
 
@@ -910,18 +933,12 @@ struct sprs_hip_spgemm_plan {
     uint64_t ntask_total = 0, n_small = 0, n_large = 0, n_tiny = 0, c_nnz = 0, nb = 0;
     int64_t winlog = 17;
     uint32_t xcd_chunk = 0;        // how the launch deals the task list to the XCDs (task_of_block)
-    sprs_hip::DevBuf bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, large_list, count, off;
+    sprs_hip::DevBuf bucket, ub, ntasks, first_task, task_row, tiny_list, small_list, large_list, count, off;
 };
 
 namespace sprs_hip {
 
 namespace {
-
-int bits_of(uint64_t n) {
-    int b = 0;
-    while (b < 32 && (1ull << b) < n) ++b;
-    return b ? b : 1;
-}
 
 template <typename IDX, typename PTR>
 CsrView<IDX, PTR> view_of(const sprs_hip_csmat *m) {
@@ -974,7 +991,6 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     B.nb = pl->nb;
 
     DevBuf is_tiny, is_small, n_large_r, pos_tiny, pos_small, pos_large, large_key;
-    SPRS_TRY_HIP(pl->wlog.alloc(rows));
     SPRS_TRY_HIP(pl->ub.alloc(rows * 8));
     SPRS_TRY_HIP(pl->ntasks.alloc(rows * 8));
     SPRS_TRY_HIP(pl->first_task.alloc((rows + 1) * 8));
@@ -989,8 +1005,8 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
-                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint32_t)options().spgemm_minwin,
-                           pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>());
+                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, pl->ub.as<uint64_t>(),
+                           pl->ntasks.as<uint64_t>());
         SPRS_TRY_HIP(hipGetLastError());
         hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), rows,
                            is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), n_large_r.as<uint64_t>());
@@ -1016,15 +1032,14 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     SPRS_TRY_HIP(pl->off.alloc((ntask_total + 1) * 8));
     if (ntask_total) {
         hipLaunchKernelGGL(make_tasks_kernel, rgrid, rblock, 0, stream, pl->ntasks.as<uint64_t>(), pl->first_task.as<uint64_t>(),
-                           pl->wlog.as<uint8_t>(), rows, pos_tiny.as<uint64_t>(), pos_small.as<uint64_t>(), pos_large.as<uint64_t>(),
+                           pl->ub.as<uint64_t>(), rows, pos_tiny.as<uint64_t>(), pos_small.as<uint64_t>(), pos_large.as<uint64_t>(),
                            is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->tiny_list.as<uint64_t>(),
                            pl->small_list.as<uint64_t>(), pl->large_list.as<uint64_t>(), large_key.as<uint64_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
-    // window-major order of the large tasks: stable sort by (first column of the window, row)
-    if (n_large > 1 && rows <= 0xFFFFFFFFull && options().spgemm_task_order != 2)
-        SPRS_TRY(radix_sort_pairs(large_key.as<uint64_t>(), pl->large_list.as<uint64_t>(), n_large,
-                                  {{0, bits_of(rows)}, {32, bits_of(b_cols)}}, stream));
+    // costliest tasks first (stable sort by cost class); option spgemm_task_order = 2 keeps the row order (A/B)
+    if (n_large > 1 && options().spgemm_task_order != 2)
+        SPRS_TRY(radix_sort_pairs(large_key.as<uint64_t>(), pl->large_list.as<uint64_t>(), n_large, {{0, 6}}, stream));
 
     auto small_grid = [&](uint64_t n_tasks) {
         uint64_t g = (n_tasks + SM_WAVES - 1) / SM_WAVES;
@@ -1043,15 +1058,14 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
                            pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
         SPRS_TRY_HIP(hipGetLastError());
     }
-    // ONE launch for all large tasks, in the LDS layout of the widest window (option spgemm_winlog).  Splitting
-    // the tasks into per-layout launches (narrow windows of heavy rows 4 per CU, wide ones 1 per CU) was
-    // measured slower: 335 ms against 179 ms (profiles/r01z_spgemm_v3_lds_class_launches_negative.txt).
+    // ONE launch for all large tasks, in the LDS layout of the window width (option spgemm_winlog)
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
 #define SPRS_LG_SYM(WL)                                                                                              \
-    hipLaunchKernelGGL((large_symbolic_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, b_cols,                       \
+    hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, false, 1>), g, blk, 0, stream, A, B, b_cols,                    \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
-                       pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(), pl->xcd_chunk)
+                       pl->ntasks.as<uint64_t>(), pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, \
+                       (double *)nullptr, pl->xcd_chunk, 0u)
         switch (pl->winlog) {
             case 16: SPRS_LG_SYM(16); break;
             case 18: SPRS_LG_SYM(18); break;
@@ -1086,11 +1100,6 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
         if (g > 256 * 32) g = 256 * 32;
         return dim3((unsigned)g);
     };
-    DevBuf prof;
-    if (options().spgemm_prof) {
-        SPRS_TRY_HIP(prof.alloc(128));
-        SPRS_TRY_HIP(hipMemsetAsync(prof.p, 0, 128, stream));
-    }
     if (n_tiny)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, stream, A,
                            B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
@@ -1101,34 +1110,24 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
                            pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
-#define SPRS_LG_NUM(WL)                                                                                              \
-    hipLaunchKernelGGL((large_numeric_kernel<WL, IDX, PTR>), g, blk, 0, stream, A, B, pl->b_cols,                    \
+        const uint32_t flags = (options().spgemm_lds_atomic ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u);
+#define SPRS_LG_NUM(WL, OCC)                                                                                         \
+    hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, true, OCC>), g, blk, 0, stream, A, B, pl->b_cols,            \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
-                       pl->ntasks.as<uint64_t>(), pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(),                  \
-                       pl->off.as<uint64_t>(), c_indices, c_values, prof.as<unsigned long long>(), pl->xcd_chunk)
+                       pl->ntasks.as<uint64_t>(), pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices,       \
+                       c_values, pl->xcd_chunk, flags)
+        const bool occ3 = options().spgemm_occupancy != 2;
         switch (pl->winlog) {
-            case 16: SPRS_LG_NUM(16); break;
-            case 18: SPRS_LG_NUM(18); break;
-            case 19: SPRS_LG_NUM(19); break;
-            default: SPRS_LG_NUM(17); break;
+            case 16: if (occ3) SPRS_LG_NUM(16, 6); else SPRS_LG_NUM(16, 4); break;
+            case 18: SPRS_LG_NUM(18, 1); break;
+            case 19: SPRS_LG_NUM(19, 1); break;
+            default: if (occ3) SPRS_LG_NUM(17, 6); else SPRS_LG_NUM(17, 4); break;
         }
 #undef SPRS_LG_NUM
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return fail_hip(e, "spgemm numeric");
-    if (prof.p) {
-        unsigned long long h[16];
-        if (hipMemcpy(h, prof.p, 128, hipMemcpyDeviceToHost) == hipSuccess) {
-            fprintf(stderr,
-                    "[spgemm_prof] inside the value passes: staging %llu, expand %llu, ordered add %llu, writeback %llu cycles; "
-                    "passes %llu, chunks %llu, rounds %llu; longest task %llu cycles; expand = search %llu + loads %llu + rank\n",
-                    h[8], h[12] + h[2] + h[4], h[9], h[10], h[11], h[13], h[14], h[15], h[2], h[4]);
-            fprintf(stderr,
-                    "[spgemm_prof] thread-0 cycles summed over large tasks: bits %llu, prefix+emit %llu; tasks %llu\n", h[0],
-                    h[1], h[6]);
-        }
-    }
     return SPRS_HIP_OK;
 }
 

@@ -419,10 +419,32 @@ __global__ __launch_bounds__(256) void band_carry_kernel(const Spill *__restrict
 
 __global__ __launch_bounds__(256) void band_permute_kernel(const double *__restrict__ x, const uint32_t *__restrict__ perm,
                                                            uint64_t cols, double *__restrict__ xp, double *__restrict__ y_zero,
-                                                           uint64_t rows) {
+                                                           uint64_t rows, uint32_t first_label) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < cols) xp[perm[j]] = x[j];
+    if (j < cols) {
+        const uint32_t l = perm[j];
+        if (l >= first_label) xp[l] = x[j];     // labels below first_label were gathered by band_gather_hot_kernel
+    }
     if (y_zero && j < rows) y_zero[j] = 0.0;
+}
+
+// The hot kernel only reads the labels of the hot slices: those are gathered first, through the inverse of the labelling
+// (a few MB), so that the hot kernel starts a few us into the SpMV while the scatter of the other 90 % of x (and the clearing
+// of y) runs beside it on the second stream, in front of the cold launch that needs them.
+__global__ __launch_bounds__(256) void band_gather_hot_kernel(const double *__restrict__ x, const uint32_t *__restrict__ inv_hot,
+                                                              uint32_t hot_labels, double *__restrict__ xp) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= hot_labels) return;
+    const uint32_t j = inv_hot[l];
+    xp[l] = j != 0xFFFFFFFFu ? x[j] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void bp_inverse_hot_kernel(const uint32_t *__restrict__ perm, uint64_t cols, uint32_t hot_labels,
+                                                             uint32_t *__restrict__ inv_hot) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    const uint32_t l = perm[j];
+    if (l < hot_labels) inv_hot[l] = (uint32_t)j;
 }
 
 // y[long_rows[j]] (+)= sum of the row's partials.  One WORKGROUP per 64 consecutive long rows; its eight waves
@@ -771,6 +793,8 @@ struct BandPlan {
     uint32_t hot_threads = 1024, hot_block = 8192; // threads of a hot workgroup; entries it advances per iteration
     uint64_t cols = 0, cols_pad = 0;
     uint32_t *perm = nullptr, *long_rows = nullptr;
+    uint32_t *inv_hot = nullptr;                   // column of each hot label (0xFFFFFFFF: label not in use)
+    uint32_t hot_labels = 0;                       // nh * 8192, at most cols_pad
     double *vals_hot = nullptr, *vals_cold = nullptr;
     uint16_t *cid_hot = nullptr;
     uint32_t *cid_cold = nullptr;
@@ -799,6 +823,7 @@ void band_free(BandPlan *bp) {
         if (p) (void)hipFree(p);
     };
     drop(bp->perm);
+    drop(bp->inv_hot);
     drop(bp->long_rows);
     drop(bp->vals_hot);
     drop(bp->vals_cold);
@@ -894,6 +919,13 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
 
     // ---- labels ---------------------------------------------------------------------------
     SPRS_TRY(build_column_labels<IDX>(ix, nnz, cols, stream, &bp->perm));
+    bp->hot_labels = (uint32_t)(map.hot_labels < bp->cols_pad ? map.hot_labels : bp->cols_pad);
+    SPRS_TRY_HIP(hipMalloc((void **)&bp->inv_hot, ((uint64_t)bp->hot_labels + 1) * 4));
+    SPRS_TRY_HIP(hipMemsetAsync(bp->inv_hot, 0xFF, ((uint64_t)bp->hot_labels + 1) * 4, stream));
+    hipLaunchKernelGGL(bp_inverse_hot_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, (const uint32_t *)bp->perm,
+                       cols, bp->hot_labels, bp->inv_hot);
+    SPRS_TRY_HIP(hipGetLastError());
+    bp->bytes += ((uint64_t)bp->hot_labels + 1) * 4;
 
     // ---- short piece + list of long rows ------------------------------------------------------
     // cold arrays: [short piece | cold pieces], every piece starting at a multiple of 4 entries
@@ -1186,20 +1218,33 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         std::lock_guard<std::mutex> lock(a->mu);
         SPRS_TRY(band_scratch(bp, stream, &sc));
     }
-    // x into the plan's labelling; the same launch clears y (empty rows; the others are overwritten) unless accumulating
-    const uint64_t span = acc ? bp->cols : (bp->cols > a->rows ? bp->cols : a->rows);
-    hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, stream, x,
-                       (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows);
-    SPRS_TRY_HIP(hipGetLastError());
+    // x into the plan's labelling; the same launch clears y (empty rows; the others are overwritten) unless accumulating.
     // The gather-bound launch (cold pieces + short rows: L2 -> L1 line fills) runs on a second stream beside the
     // HBM-bound hot slices (option spmv_band_overlap, 2 = off).  The two kernels do run concurrently and mostly trade
     // time one for one (1145 vs 1153 us, profiles/r02h), but the gather workgroups fill the start-up and tail bubbles
     // of the one-workgroup-per-CU hot kernel: 1.12 vs 1.16 ms per SpMV over repeated A/B runs (profiles/r02j, r02l).
+    // With the overlap the permutation is split as well (option spmv_band_split_permute, 2 = off): the hot labels are
+    // gathered first (a few us), the hot kernel starts, and the scatter of the rest + the clearing of y go to the second
+    // stream in front of the cold launch — 47 us less on the critical path.
     const bool overlap = options().spmv_band_overlap != 2 && bp->hot_wgs && bp->cold_blocks;
+    const bool split_permute = overlap && options().spmv_band_split_permute != 2 && bp->hot_labels;
+    const uint64_t span = acc ? bp->cols : (bp->cols > a->rows ? bp->cols : a->rows);
     hipStream_t cstream = overlap ? sc->aux : stream;
+    if (split_permute)
+        hipLaunchKernelGGL(band_gather_hot_kernel, dim3((bp->hot_labels + 255) / 256), dim3(256), 0, stream, x,
+                           (const uint32_t *)bp->inv_hot, bp->hot_labels, sc->xp);
+    else
+        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, stream, x,
+                           (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, 0u);
+    SPRS_TRY_HIP(hipGetLastError());
     if (overlap) {
-        SPRS_TRY_HIP(hipEventRecord(sc->fork, stream));           // xp (and the cleared y) are ready
+        SPRS_TRY_HIP(hipEventRecord(sc->fork, stream));           // the hot labels of xp (or all of it, and the cleared y) are ready
         SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux, sc->fork, 0));
+    }
+    if (split_permute) {
+        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, cstream, x,
+                           (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, bp->hot_labels);
+        SPRS_TRY_HIP(hipGetLastError());
     }
     // the short rows: with the hottest x entries in LDS (band_hot_kernel<.., true, ..>, default) or as one more gather piece
     const bool short_tiled = options().spmv_band_short == 1 && bp->short_wgs != 0;   // measured slower than the gather piece (profiles/r02k, r02l): opt-in

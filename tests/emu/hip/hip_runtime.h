@@ -90,6 +90,9 @@ enum Op { OP_BALLOT, OP_SHFL, OP_SHFL_UP, OP_SHFL_DOWN, OP_SHFL_XOR, OP_BARRIER 
 // would split the lanes of one logical collective over two call sites)
 uint64_t collective(Op op, uint64_t val, int arg, int width) __attribute__((noinline, convergent, noduplicate));
 void syncthreads() __attribute__((noinline, convergent, noduplicate));
+// a wave spinning on an LDS word written by another wave of the block (spgemm.hip, token hand-over): the fiber steps
+// aside and is resumed on the scheduler's next sweep over the block
+void poll_yield() __attribute__((noinline));
 
 struct Launcher {
     virtual void call() = 0;
@@ -165,6 +168,8 @@ inline void __threadfence_block() {}
 // the kernels' hand-written waits / LDS-only barriers (scan.hpp, spgemm.hip) map onto these
 #define SPRS_LDS_BARRIER() hipemu::syncthreads()
 #define SPRS_WAIT_ALL() ((void)0)
+#define SPRS_LDS_FENCE() ((void)0)
+#define SPRS_POLL_PAUSE() hipemu::poll_yield()
 
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4

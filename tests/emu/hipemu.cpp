@@ -12,7 +12,7 @@
 
 namespace hipemu {
 
-enum State { READY, AT_BARRIER, AT_COLLECTIVE, DONE };
+enum State { READY, AT_BARRIER, AT_COLLECTIVE, AT_POLL, DONE };
 
 struct Fiber {
     void *sp = nullptr;      // saved stack pointer while the fiber is not running
@@ -72,6 +72,11 @@ static void yield_to_scheduler() {
 
 void syncthreads() {
     cur->state = AT_BARRIER;
+    yield_to_scheduler();
+}
+
+void poll_yield() {
+    cur->state = AT_POLL;
     yield_to_scheduler();
 }
 
@@ -165,21 +170,53 @@ static void run_block(size_t nthreads) {
         f.sp = (void *)(top - 8);
         f.state = READY;
     }
+    // HIPEMU_WAVE_ORDER=reverse|rotate: the order in which the waves of a block get their turn (the hardware promises
+    // none; kernels that hand work from wave to wave must not depend on it)
+    static const char *order_env = getenv("HIPEMU_WAVE_ORDER");
+    static const int order = !order_env ? 0 : order_env[0] == 'r' && order_env[1] == 'e' ? 1 : 2;
+    const size_t nwaves = (nthreads + 63) / 64;
+    size_t mult = 1;                                    // a multiplier coprime with the number of waves: wi -> wave is a bijection
+    for (size_t m : {7, 5, 3, 11, 13}) {
+        size_t a = m, b = nwaves;
+        while (b) { const size_t t = a % b; a = b; b = t; }
+        if (a == 1) { mult = m; break; }
+    }
+    size_t sweep = 0, idle_sweeps = 0;
     for (;;) {
-        for (size_t w0 = 0; w0 < nthreads; w0 += 64) {
+        bool progressed = false;
+        for (size_t wi = 0; wi < nwaves; ++wi) {
+            const size_t wv = order == 0 ? wi : order == 1 ? nwaves - 1 - wi : (wi * mult + sweep * 3 + 1) % nwaves;
+            const size_t w0 = wv * 64;
             const size_t w1 = w0 + 64 < nthreads ? w0 + 64 : nthreads;
             for (;;) {
                 for (size_t i = w0; i < w1; ++i)
-                    if (g_fibers[i].state == READY) resume(g_fibers[i]);
+                    if (g_fibers[i].state == READY) {
+                        resume(g_fibers[i]);
+                        if (g_fibers[i].state != AT_POLL) progressed = true;
+                    }
                 if (!resolve_one(w0, w1)) break;
+                progressed = true;
             }
         }
-        size_t done = 0, waiting = 0;
+        ++sweep;
+        size_t done = 0, waiting = 0, polling = 0;
         for (size_t i = 0; i < nthreads; ++i) {
             done += g_fibers[i].state == DONE;
             waiting += g_fibers[i].state == AT_BARRIER;
+            polling += g_fibers[i].state == AT_POLL;
         }
         if (done == nthreads) return;
+        if (polling) {
+            // pollers go again; barrier waiters stay put until nobody polls any more (the pollers have not arrived yet)
+            idle_sweeps = progressed ? 0 : idle_sweeps + 1;
+            if (idle_sweeps > 4) {
+                fprintf(stderr, "hipemu: kernel %s: block %u stuck (%zu threads poll a word nobody writes)\n", g_kernel, g_blockIdx.x, polling);
+                abort();
+            }
+            for (size_t i = 0; i < nthreads; ++i)
+                if (g_fibers[i].state == AT_POLL) g_fibers[i].state = READY;
+            continue;
+        }
         if (!waiting) {
             fprintf(stderr, "hipemu: kernel %s: block stuck (no thread runnable)\n", g_kernel);
             abort();

@@ -1,0 +1,32 @@
+"""Kernel LOGIC on the CPU: the SpGEMM kernels compiled for the host and run by the fiber emulator of tests/emu, with the
+waves of a workgroup scheduled in three different orders.  The large-row value kernel hands a token from wave to wave
+(spgemm.hip, "ORDER OF THE ADDITIONS"); its results must not depend on which wave runs first.  This is test
+infrastructure: the emulator is never loaded by the product and says nothing about speed; parity on the real gfx950
+build is the job of the -m gpu tests."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang++ of the ROCm toolchain here")
+    r = subprocess.run(["make", "-C", EMU, "-j8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return os.path.join(EMU, "libsprs_hip_emu.so")
+
+
+@pytest.mark.parametrize("order", ["default", "reverse", "rotate"])
+def test_spgemm_kernels_under_wave_orders(emu_lib, order):
+    env = dict(os.environ, SPRS_HIP_LIBRARY=emu_lib, HIPEMU_WAVE_ORDER=order)
+    sel = "golden_mul_csr_csr or zero_rows or structural_zeros or rectangular or multi_window or order_of_additions"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_spgemm_gpu.py"), "-x", "-q", "-m", "gpu",
+                        "-k", sel, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

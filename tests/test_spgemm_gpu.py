@@ -190,6 +190,55 @@ def test_multi_window_columns(hip):
     check_against_oracle(A2, B2, exact_values=True)
 
 
+def _order_stress_cases():
+    """Inputs on which ANY reordering of the additions into one C(i,j) changes the bits: many k's per row whose B rows
+    are short and crowd onto few columns (every wave instruction of the value walk holds many k-runs, every accumulator a
+    long chain), magnitudes spread over 12 decades, mixed signs.  The four shapes take the four routes of the large-row
+    kernel: one staged group with the window kept in registers (<= 2048 products), one group with a second walk,
+    several staged groups (> 256 k's), several passes (> 3072 outputs in a window)."""
+    cases = []
+    rng = np.random.default_rng(77)
+    u = lambda v: np.asarray(v, dtype=np.uint64)
+    def crowd(n_k, per_row, cols, hot):
+        # B: n_k rows of `per_row` distinct columns, most of them among the first `hot`
+        ip = [0]; ix = []; dt = []
+        for _ in range(n_k):
+            n_hot = min(hot, max(1, int(per_row * 0.8)))
+            c = set(rng.choice(hot, size=n_hot, replace=False).tolist())
+            while len(c) < per_row:
+                c.add(int(rng.integers(0, cols)))
+            c = sorted(c)
+            ix += c
+            dt += list(rng.standard_normal(len(c)) * 10.0 ** rng.integers(-6, 7, size=len(c)))
+            ip.append(len(ix))
+        return (n_k, cols), u(ip), u(ix), np.asarray(dt)
+    def rows_over(n_rows, n_k, density):
+        m = rng.random((n_rows, n_k)) < density
+        m[:, 0] = True
+        ip = np.concatenate([[0], np.cumsum(m.sum(1))])
+        ix = np.concatenate([np.nonzero(r)[0] for r in m])
+        dt = rng.standard_normal(ix.size) * 10.0 ** rng.integers(-3, 4, size=ix.size)
+        return (n_rows, n_k), u(ip), u(ix), dt
+    cases.append((rows_over(6, 200, 0.9), crowd(200, 8, 5000, 24)))         # ~1 400 products a row: kept in registers
+    cases.append((rows_over(6, 250, 0.95), crowd(250, 30, 5000, 60)))       # ~7 000 products: second walk, one pass
+    cases.append((rows_over(4, 700, 0.9), crowd(700, 6, 200_000, 16)))      # three staged groups, two windows
+    cases.append((rows_over(3, 240, 0.95), crowd(240, 900, 40_000, 4000)))  # ~4 000+ outputs in the window: passes
+    return cases
+
+
+def test_order_of_additions_stress(hip):
+    for a, b in _order_stress_cases():
+        for retain in (1, 0):
+            for atomic in (1, 0):
+                hip.set_option("spgemm_retain", retain)
+                hip.set_option("spgemm_lds_atomic", atomic)
+                try:
+                    check_against_oracle(a, b, exact_values=True)
+                finally:
+                    hip.set_option("spgemm_retain", 1)
+                    hip.set_option("spgemm_lds_atomic", 1)
+
+
 _DENSE_CASE = []
 
 
@@ -235,7 +284,7 @@ def test_window_sizes_and_dense_outputs(hip, winlog):
         assert np.diff(ip.astype(np.int64)).max() > 100_000
     finally:
         hip.set_option("spgemm_winlog", 17)
-        hip.set_option("spgemm_heavy", 65536)
+        hip.set_option("spgemm_heavy", 1 << 20)
         hip.set_option("spgemm_bucket", 1)
 
 
