@@ -43,7 +43,7 @@ for step in "$@"; do
             for c in "${CFG[@]}"; do
               [ "$c" = base ] && c=""
               echo "-- ${c:-defaults}" | tee -a $OUT/spgemm_ab.jsonl
-              env $c timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds" | tee -a $OUT/spgemm_ab.jsonl
+              env $c timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds|spgemm_prof" | cut -c1-260 | tee -a $OUT/spgemm_ab.jsonl
             done ;;
     spmm)   timeout 600 python scripts/spmm_bench.py $arg 2>&1 | grep -E "^\{" | tee -a $OUT/spmm.jsonl
             ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spmm_bench.py ${arg:-10000000 32 16} > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|spmm" | cut -c1-200 | head -8 | tee -a $OUT/spmm_kernels.txt ;;

@@ -921,6 +921,14 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         o.spgemm_bucket = value ? 1 : 0;
     } else if (!strcmp(name, "spgemm_prof")) {
         o.spgemm_prof = value ? 1 : 0;
+    } else if (!strcmp(name, "spgemm_midwin")) {
+        if (value < 13 || value > 14) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_midwin must be 13 or 14");
+        o.spgemm_midwin = value;
+    } else if (!strcmp(name, "spgemm_mid")) {
+        if (value < 0 || value > (1ll << 31)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_mid must be 0 .. 2^31");
+        o.spgemm_mid = value;
+    } else if (!strcmp(name, "spgemm_debug")) {
+        o.spgemm_debug = value & 3;
     } else if (!strcmp(name, "spgemm_occupancy")) {
         if (value != 2 && value != 3) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_occupancy must be 2 or 3");
         o.spgemm_occupancy = value;
@@ -1012,6 +1020,8 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_lds_atomic")) *value = o.spgemm_lds_atomic;
     else if (!strcmp(name, "spgemm_retain")) *value = o.spgemm_retain;
     else if (!strcmp(name, "spgemm_occupancy")) *value = o.spgemm_occupancy;
+    else if (!strcmp(name, "spgemm_mid")) *value = o.spgemm_mid;
+    else if (!strcmp(name, "spgemm_midwin")) *value = o.spgemm_midwin;
     else if (!strcmp(name, "spgemm_minwin")) *value = o.spgemm_minwin;
     else if (!strcmp(name, "spgemm_task_order")) *value = o.spgemm_task_order;
     else if (!strcmp(name, "spgemm_xcd_chunk")) *value = o.spgemm_xcd_chunk;

@@ -51,13 +51,16 @@ struct Options {
     int64_t spgemm_task_order = 0; // large-row tasks: 0/1 costliest first (stable sort by cost class), 2 row order (A/B)
     int64_t spgemm_xcd_chunk = 0;  // large-row task list -> XCDs: 0 round-robin, -1 one contiguous run per XCD
     int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
-    int64_t spgemm_prof = 0;       // SpGEMM: (no longer used; accepted for old scripts)
+    int64_t spgemm_prof = 0;       // SpGEMM: print the time of the large-row numeric tasks by class and the longest ones (debug)
+    int64_t spgemm_midwin = 14;    // SpGEMM: log2 of the column window of the wave-per-row kernel (13 or 14)
+    int64_t spgemm_mid = 65536;    // SpGEMM: rows of <= 64 k's and at most this many products run one wave per row (0: none)
+    int64_t spgemm_debug = 0;      // SpGEMM TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission
     int64_t spgemm_occupancy = 3;  // SpGEMM: workgroups per CU the large-row numeric kernel is compiled for: 3 (80 VGPRs) or 2 (128 VGPRs) (A/B)
     int64_t spgemm_retain = 1;     // SpGEMM: windows of few entries keep them in registers from the bit pass to the adds (A/B)
     int64_t spgemm_lds_atomic = 1; // SpGEMM: value adds as ds_add_f64 (1) or read / add / write (0); same order either way (A/B)
     int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)
     int64_t spgemm_minwin = 13;    // SpGEMM: (no longer used: heavy rows are cut into runs of whole windows)
-    int64_t spgemm_heavy = 1 << 20;   // SpGEMM: products per task above which a row is cut into several tasks (runs of windows)
+    int64_t spgemm_heavy = 131072;    // SpGEMM: a row of more products is cut into one task per (narrower) column window, about this many products each
     int64_t pool = 1;              // keep released result blocks (>= 1 MiB) for the next result instead of hipFree
     int64_t pool_max_bytes = 128ll << 30;   // cap on the bytes the pool may hold
     int64_t spmv_band = 0;         // banded plan (hot columns from LDS, spmv_band.hip) instead of the XCD-sliced one: 0 auto (on), 1 on, 2 off

@@ -36,6 +36,7 @@
 #include "common.hpp"
 #include "scan.hpp"
 
+#include <algorithm>
 #include <vector>
 
 namespace sprs_hip {
@@ -157,8 +158,9 @@ __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 3
 // ---------------------------------------------------------------------------
 template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
-                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t wl,
-                                                       uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks) {
+                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t wl, uint64_t mid_max,
+                                                       uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks,
+                                                       uint8_t *__restrict__ cls, uint8_t *__restrict__ wlog) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
@@ -172,20 +174,23 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
         acc = wave_sum_u64(acc);
         if (lane == 0) {
             ub[r] = acc;
-            // A large row is ONE task that walks its column windows (2^wl columns each) one after the other; only a
-            // heavy row (hub) is cut into several tasks of consecutive windows, ~heavy_products products each, so that
-            // it does not become one serial chain at the end of the launch.  large_rows_kernel derives the same
-            // windows-per-task from ntasks[r].
+            // A large row is ONE task that walks its column windows (2^wl columns each) one after the other.
             uint64_t nt = acc ? 1 : 0;
-            if (acc > SMALL_MAX) {
-                uint64_t nwin = (b_cols + (1ull << wl) - 1) >> wl;
-                if (nwin == 0) nwin = 1;
-                uint64_t want = acc / heavy_products;
-                if (want < 1) want = 1;
-                if (want > nwin) want = nwin;
-                const uint64_t wpt = (nwin + want - 1) / want;
-                nt = (nwin + wpt - 1) / wpt;
+            // classes: 1 tiny and 2 small (one wave, hash table), 3 mid (one wave, column windows), 4 large (a workgroup)
+            const uint8_t c = !acc ? 0 : acc <= TINY_MAX ? 1 : acc <= SMALL_MAX ? 2 : (e - s <= 64 && acc <= mid_max) ? 3 : 4;
+            cls[r] = c;
+            uint32_t wl_r = wl;
+            if (c == 4 && acc > heavy_products) {
+                // a heavy row (hub): narrower windows, one task per window, ~heavy_products products each on average, so that
+                // it is not one serial chain at the end of the launch (its window 0 still is the longest task)
+                uint64_t width = b_cols / (acc / heavy_products);
+                wl_r = width <= 1 ? 0 : 63 - __clzll((long long)width);       // floor(log2)
+                if (wl_r < 13) wl_r = 13;
+                if (wl_r > wl) wl_r = wl;
+                nt = (b_cols + (1ull << wl_r) - 1) >> wl_r;
+                if (nt == 0) nt = 1;
             }
+            wlog[r] = (uint8_t)wl_r;
             ntasks[r] = nt;
         }
     }
@@ -193,14 +198,16 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
 
 // Task lists, deterministic (first version: atomicAdd tickets, i.e. an arbitrary order that changed from call to call).
 // Classes of a row: tiny (<= 64 products), small (<= 512), large (one task per column window).
-__global__ void task_class_kernel(const uint64_t *__restrict__ ub, const uint64_t *__restrict__ ntasks, uint64_t rows,
-                                  uint64_t *__restrict__ is_tiny, uint64_t *__restrict__ is_small, uint64_t *__restrict__ n_large) {
+__global__ void task_class_kernel(const uint8_t *__restrict__ cls, const uint64_t *__restrict__ ntasks, uint64_t rows,
+                                  uint64_t *__restrict__ is_tiny, uint64_t *__restrict__ is_small, uint64_t *__restrict__ is_mid,
+                                  uint64_t *__restrict__ n_large) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    const uint64_t n = ntasks[r], u = ub[r];
-    is_tiny[r] = (n && u <= TINY_MAX) ? 1 : 0;
-    is_small[r] = (n && u > TINY_MAX && u <= SMALL_MAX) ? 1 : 0;
-    n_large[r] = (n && u > SMALL_MAX) ? n : 0;
+    const uint8_t c = cls[r];
+    is_tiny[r] = c == 1;
+    is_small[r] = c == 2;
+    is_mid[r] = c == 3;
+    n_large[r] = c == 4 ? ntasks[r] : 0;
 }
 
 // lists in row order; for the large tasks also the sort key: the cost class (log2 of the products per task), costliest
@@ -208,21 +215,26 @@ __global__ void task_class_kernel(const uint64_t *__restrict__ ub, const uint64_
 // a class the tasks stay in row order, and the list — with it every launch — is the same run to run)
 __global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uint64_t *__restrict__ first_task,
                                   const uint64_t *__restrict__ ub, uint64_t rows, const uint64_t *__restrict__ pos_tiny,
-                                  const uint64_t *__restrict__ pos_small, const uint64_t *__restrict__ pos_large,
-                                  const uint64_t *__restrict__ is_tiny, const uint64_t *__restrict__ is_small,
+                                  const uint64_t *__restrict__ pos_small, const uint64_t *__restrict__ pos_mid,
+                                  const uint64_t *__restrict__ pos_large, const uint8_t *__restrict__ cls,
                                   uint64_t *__restrict__ task_row, uint64_t *__restrict__ tiny_list,
-                                  uint64_t *__restrict__ small_list, uint64_t *__restrict__ large_list,
-                                  uint64_t *__restrict__ large_key) {
+                                  uint64_t *__restrict__ small_list, uint64_t *__restrict__ mid_list,
+                                  uint64_t *__restrict__ large_list, uint64_t *__restrict__ large_key,
+                                  uint64_t *__restrict__ mid_key) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const uint64_t n = ntasks[r];
     if (!n) return;
     const uint64_t f = first_task[r];
     for (uint64_t j = 0; j < n; ++j) task_row[f + j] = r;
-    if (is_tiny[r]) {
+    const uint8_t c = cls[r];
+    if (c == 1) {
         tiny_list[pos_tiny[r]] = f;
-    } else if (is_small[r]) {
+    } else if (c == 2) {
         small_list[pos_small[r]] = f;
+    } else if (c == 3) {
+        mid_list[pos_mid[r]] = f;
+        mid_key[pos_mid[r]] = (uint64_t)__clzll((long long)(ub[r] | 1));
     } else {
         const uint64_t pos = pos_large[r];
         const uint64_t cost = ub[r] / n;
@@ -601,14 +613,34 @@ __device__ __forceinline__ void walk_bits(const IDX *__restrict__ b_indices, uin
     }
 }
 
+// Volatile accesses to LDS words through explicitly LDS-qualified pointers: a volatile access through a GENERIC pointer is
+// not narrowed by the compiler and becomes a flat load with system scope followed by s_waitcnt vmcnt(0) — every poll of
+// the token then waited for all the global stores the wave had in flight (the index emission), first measured as 60 % of
+// the kernel (profiles/r02u).
+#ifdef SPRS_HIP_EMU
+__device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p) { return *(const volatile uint32_t *)p; }
+__device__ __forceinline__ void lds_store_u32(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
+__device__ __forceinline__ double lds_load_f64(const double *p) { return *(const volatile double *)p; }
+__device__ __forceinline__ void lds_store_f64(double *p, double v) { *(volatile double *)p = v; }
+#else
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) volatile double lds_vf64;
+__device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p) { return *(const lds_vu32 *)p; }
+__device__ __forceinline__ void lds_store_u32(uint32_t *p, uint32_t v) { *(lds_vu32 *)p = v; }
+__device__ __forceinline__ double lds_load_f64(const double *p) { return *(const lds_vf64 *)p; }
+__device__ __forceinline__ void lds_store_f64(double *p, double v) { *(lds_vf64 *)p = v; }
+#endif
+
 __device__ __forceinline__ void token_wait(uint32_t *token, uint32_t turn) {
-    while (*(volatile uint32_t *)token != turn) SPRS_POLL_PAUSE();
+    if (turn == 0xFFFFFFFFu) return;       // timing experiments only (option spgemm_debug & 1): no ordering
+    while (lds_load_u32(token) != turn) SPRS_POLL_PAUSE();
     asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ void token_pass(uint32_t *token, uint32_t next) {
+    if (next == 0u) return;                // (turn 0xFFFFFFFF + 1: the experiment above)
     SPRS_LDS_FENCE();                      // this wave's adds have been performed
-    if ((threadIdx.x & (WAVE - 1)) == 0) *(volatile uint32_t *)token = next;
+    if ((threadIdx.x & (WAVE - 1)) == 0) lds_store_u32(token, next);
 }
 
 // the products of one wave instruction (64 consecutive positions, owners ascending with the lane): one add instruction
@@ -623,11 +655,296 @@ __device__ __forceinline__ void add_runs(bool val, uint32_t own, uint32_t slot, 
             if (lds_atomic) {
                 atomicAdd(&acc[slot], pr);               // ds_add_f64, no return value
             } else {
-                volatile double *a = acc + slot;         // A/B switch: read, add, write (same order, three instructions)
-                *a = *a + pr;
+                lds_store_f64(acc + slot, lds_load_f64(acc + slot) + pr);   // A/B switch: read, add, write (same order)
             }
         }
         todo &= ~__ballot(mine);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// mid rows: ONE WAVE per row, no workgroup barrier anywhere
+//
+// Rows of at most 64 k's and at most `mid_max` products (config 5: 257 000 of the 290 000 rows above the hash path, a
+// third of the products).  As workgroup tasks they paid ~23 us per column window in barriers and dependent LDS round trips
+// for a few hundred products (profiles/r02w: 57 of 99 s of workgroup time).  A wave needs no barrier: lane j keeps k_j, the
+// bounds of B's row k_j and a_ik in registers; the row is walked in windows of 2^13 columns (128 bitmap words, 2 per lane;
+// the bound of the next window comes from the bucket table one window ahead); a window is the bit pass, a popcount prefix
+// by wave scans, the sorted indices, and the values in passes of 512 accumulators — windows of up to 256 entries keep them
+// in registers in between.  The order of the additions is the LDS's own (one wave, instructions in order, one ds_add_f64
+// per k-run: see large rows below).  24 independent waves per CU hide each other's memory round trips.
+// ---------------------------------------------------------------------------
+constexpr int MID_BLOCK = 128;
+constexpr int MID_WAVES = MID_BLOCK / WAVE;
+constexpr int MID_ACC = 512;                      // accumulators of one pass
+constexpr int MID_K = 64;                         // k's per row: one per lane
+constexpr int MID_KEEP = 4;                       // wave instructions of a window that stay in registers
+
+// inclusive scan over the 64 lanes without the LDS: four row_shr steps inside the rows of 16 lanes, then row_bcast 15 and 31
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+#ifdef SPRS_HIP_EMU
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, WAVE);
+        if (lane >= (uint32_t)off) v += o;
+    }
+    return v;
+#else
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);     // row_shr:1 (zeros shifted in)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+#endif
+}
+
+template <typename IDX, typename PTR, bool NUMERIC, int MID_WL>
+__global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t b_cols,
+                                                             const uint64_t *__restrict__ mid_list, uint64_t n_mid,
+                                                             const uint64_t *__restrict__ task_row,
+                                                             uint64_t *__restrict__ count,        // symbolic: out
+                                                             const uint64_t *__restrict__ off,    // numeric: in
+                                                             IDX *__restrict__ c_indices, double *__restrict__ c_data,
+                                                             unsigned long long *__restrict__ prof,
+                                                             const uint64_t *__restrict__ ub_dbg,
+                                                             unsigned int *__restrict__ next_row) {
+    long long t_prev = prof ? (long long)wall_clock64() : 0;
+    const long long t_kernel = t_prev;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto mark = [&](int phase) {                                        // lane 0's view of the phases (debug option spgemm_prof)
+        if (prof && (threadIdx.x & (WAVE - 1)) == 0) {
+            const long long now = (long long)wall_clock64();
+            ph[phase] += (unsigned long long)(now - t_prev);
+            t_prev = now;
+        }
+    };
+    constexpr int MID_WORDS = 1 << (MID_WL - 6);      // bitmap words of a window; lane l takes words l, l + 64, ...
+    constexpr int WPL = MID_WORDS / WAVE;             // words per lane (2^13 columns: 2, 2^14: 4, 2^15: 8)
+    static_assert(MID_WL >= 13 && MID_WL <= 14, "window of the wave-per-row kernel");   // (ranks must fit the 16-bit sub[])
+    __shared__ unsigned long long bm_s[MID_WAVES][MID_WORDS];
+    __shared__ uint16_t sub_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_WORDS : 1];
+    __shared__ double acc_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_ACC : 1];
+    __shared__ uint64_t kS_s[MID_WAVES][MID_K];
+    __shared__ uint32_t kP_s[MID_WAVES][MID_K + 1];
+    __shared__ double kA_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_K : 1];
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    unsigned long long *bm = bm_s[wave];
+    uint32_t *bm32 = (uint32_t *)bm;
+    uint16_t *sub = sub_s[NUMERIC ? wave : 0];
+    double *acc = acc_s[NUMERIC ? wave : 0];
+    uint64_t *kS = kS_s[wave];
+    uint32_t *kP = kP_s[wave];
+    double *kA = kA_s[NUMERIC ? wave : 0];
+    const bool values = NUMERIC && c_data != nullptr;
+    uint64_t nwin = (b_cols + (1ull << MID_WL) - 1) >> MID_WL;
+    if (nwin == 0) nwin = 1;
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) bm[i * WAVE + lane] = 0;
+    wave_sync_lds();
+    // The waves draw rows from a counter (the list is sorted by cost, costliest first): which wave takes which row changes
+    // nothing in the result — every row is computed by one wave on its own, into its own piece of C.
+    for (;;) {
+        unsigned int qq = 0;
+        if (lane == 0) qq = atomicAdd(next_row, 1u);
+        const uint64_t q = (uint64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)qq);
+        if (q >= n_mid) break;
+        const uint64_t t = mid_list[q];
+        const uint64_t r = task_row[t];
+        const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
+        const uint32_t nk = (uint32_t)(ae - as);                     // <= 64 (row_work_kernel)
+        const bool has = lane < nk;
+        // positions inside B's row k_j as 32-bit offsets from its start (a row has fewer than 2^32 entries: b_cols < 2^32)
+        uint64_t rk = 0, rs = 0;
+        uint32_t re = 0, cur = 0, nxt_e = 0;
+        double rav = 0.0;
+        auto edge = [&](uint32_t lo, uint32_t hi, uint64_t col) -> uint32_t {      // first entry of my row in [lo, hi) with column >= col
+            return (uint32_t)(first_ge(B, rk, rs, rs + lo, rs + hi, col) - rs);
+        };
+        if (has) {
+            rk = (uint64_t)A.indices[as + lane];
+            rs = (uint64_t)B.indptr[rk];
+            re = (uint32_t)((uint64_t)B.indptr[rk + 1] - rs);
+            if (values) rav = A.data[as + lane];
+            cur = 0;
+            nxt_e = nwin <= 1 ? re : edge(0, re, 1ull << MID_WL);
+        }
+        uint64_t out = 0;
+        if constexpr (NUMERIC) out = off[t];
+        uint32_t fresh = 0;
+        mark(0);
+        const long long t_row = prof ? (long long)wall_clock64() : 0;
+        for (uint64_t w = 0; w < nwin; ++w) {
+            const uint64_t win_lo = w << MID_WL;
+            const uint32_t win_s = cur, win_e = nxt_e;
+            if (has) {
+                cur = win_e;
+                if (w + 1 < nwin) nxt_e = w + 2 >= nwin ? re : edge(win_e, re, (w + 2) << MID_WL);
+            }
+            const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(has ? win_e - win_s : 0u), WAVE - 1);
+            mark(1);
+            if (wtotal == 0) continue;                                // wave-uniform: nothing of the row in this window
+            // A window of more entries than the registers keep (the dense low columns of a power-law row) is taken bucket by
+            // bucket, 2048 columns at a time: its outputs then fit one pass of accumulators nearly always, instead of every
+            // pass walking the whole window again (first version: 74 of 152 s of wave time, profiles/r02y).
+            constexpr uint32_t SEG_COLS = 1u << BUCKET_LOG2;
+            const uint32_t nseg = wtotal > (uint32_t)(WAVE * MID_KEEP) ? (1u << (MID_WL - BUCKET_LOG2)) : 1u;
+            uint32_t seg_s = win_s, seg_nxt = win_e;
+            if (nseg > 1 && has) seg_nxt = edge(win_s, win_e, win_lo + SEG_COLS);
+            for (uint32_t seg = 0; seg < nseg; ++seg) {
+            const uint64_t wlo = win_lo + (nseg > 1 ? (uint64_t)seg * SEG_COLS : 0ull);
+            const uint32_t ws = seg_s, we = seg + 1 == nseg ? win_e : seg_nxt;
+            if (nseg > 1 && has) {
+                seg_s = we;
+                if (seg + 2 < nseg) seg_nxt = edge(we, win_e, wlo + 2 * (uint64_t)SEG_COLS);
+            }
+            const uint32_t len = has ? we - ws : 0u;
+            const uint32_t inc = wave_incl_scan_u32(len);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+            if (total == 0) continue;                                 // wave-uniform
+            kP[lane] = inc - len;                                     // lanes without a k: = total (the search never passes them)
+            if (lane == WAVE - 1) kP[MID_K] = total;
+            kS[lane] = rs + ws;
+            if (values) kA[lane] = rav;
+            wave_sync_lds();
+            const uint32_t nb = (total + WAVE - 1) / WAVE;
+            const bool keep = values && nb <= (uint32_t)MID_KEEP;     // wave-uniform
+            uint32_t kco[MID_KEEP];                                   // column offset (< 2^15) | owner << 16; 0xFFFFFFFF: no entry
+            double kpr[MID_KEEP];
+            // one wave instruction of the expansion: owner, column, (product)
+            auto entry = [&](uint32_t b, bool with_value, uint32_t &cc, uint32_t &own, double &pr) -> bool {
+                const uint32_t tpos = b * WAVE + lane;
+                const bool valid = tpos < total;
+                cc = 0;
+                own = 0;
+                pr = 0.0;
+                if (nk <= 16) {
+                    // few k's (most rows): count the k's that end at or before the position — scalar compares, no LDS round trips
+                    for (uint32_t j = 0; j + 1 < nk; ++j)
+                        own += tpos >= (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)j) ? 1u : 0u;
+                } else if (valid) {
+                    own = flat_owner<MID_K>(kP, tpos);
+                }
+                if (valid) {
+                    const uint64_t pos = kS[own] + (uint64_t)(tpos - kP[own]);
+                    cc = (uint32_t)((uint64_t)B.indices[pos] - wlo);
+                    if (with_value) pr = kA[own] * B.data[pos];
+                }
+                return valid;
+            };
+            // ---- bit pass ----
+            if (keep) {
+#pragma unroll
+                for (int b = 0; b < MID_KEEP; ++b) {
+                    kco[b] = 0xFFFFFFFFu;
+                    kpr[b] = 0.0;
+                    if ((uint32_t)b < nb) {
+                        uint32_t cc, own;
+                        if (entry((uint32_t)b, true, cc, own, kpr[b])) kco[b] = cc | (own << 16);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < MID_KEEP; ++b)
+                    if (kco[b] != 0xFFFFFFFFu) atomicOr(&bm32[(kco[b] & 0xFFFFu) >> 5], 1u << (kco[b] & 31));
+            } else {
+                for (uint32_t b = 0; b < nb; ++b) {
+                    uint32_t cc, own;
+                    double pr;
+                    if (entry(b, false, cc, own, pr)) atomicOr(&bm32[cc >> 5], 1u << (cc & 31));
+                }
+            }
+            wave_sync_lds();
+            mark(2);
+            uint32_t pc[WPL];
+#pragma unroll
+            for (int i = 0; i < WPL; ++i) pc[i] = (uint32_t)__popcll(bm[i * WAVE + lane]);
+            if constexpr (!NUMERIC) {
+#pragma unroll
+                for (int i = 0; i < WPL; ++i) fresh += pc[i];
+            } else {
+                // ---- popcount prefix: outputs before each word (words i * 64 + lane: one wave scan per i) ----
+                uint32_t wtot = 0;
+#pragma unroll
+                for (int i = 0; i < WPL; ++i) {
+                    const uint32_t in = wave_incl_scan_u32(pc[i]);
+                    sub[i * WAVE + lane] = (uint16_t)(wtot + in - pc[i]);
+                    wtot += (uint32_t)__builtin_amdgcn_readlane((int)in, WAVE - 1);
+                }
+                wave_sync_lds();
+                mark(3);
+                // ---- indices: sorted for free ----
+                if (c_indices) {
+#pragma unroll
+                    for (int i = 0; i < WPL; ++i) {
+                        unsigned long long m = bm[i * WAVE + lane];
+                        uint32_t run = sub[i * WAVE + lane];
+                        while (m) {
+                            const int bit = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            c_indices[out + run++] = (IDX)(wlo + (uint64_t)(i * WAVE + lane) * 64 + (uint64_t)bit);
+                        }
+                    }
+                }
+                mark(4);
+                // ---- values: passes of MID_ACC outputs; every pass walks the window's entries and takes its own ----
+                for (uint32_t p0 = 0; values && p0 < wtot; p0 += MID_ACC) {
+                    const uint32_t n_out = wtot - p0 < (uint32_t)MID_ACC ? wtot - p0 : (uint32_t)MID_ACC;
+                    for (uint32_t i = lane; i < n_out; i += WAVE) acc[i] = 0.0;        // tmp starts at N::zero()
+                    wave_sync_lds();
+                    auto slot_of = [&](uint32_t cc) -> uint32_t {
+                        const uint32_t word = cc >> 6;
+                        return (uint32_t)sub[word] + (uint32_t)__popcll(bm[word] & ((1ull << (cc & 63)) - 1ull)) - p0;
+                    };
+                    if (keep) {
+#pragma unroll
+                        for (int b = 0; b < MID_KEEP; ++b) {
+                            if ((uint32_t)b < nb) {
+                                const bool kv = kco[b] != 0xFFFFFFFFu;
+                                const uint32_t slot = kv ? slot_of(kco[b] & 0xFFFFu) : 0xFFFFFFFFu;
+                                add_runs(kv && slot < n_out, kco[b] >> 16, slot, kpr[b], acc, true);
+                            }
+                        }
+                    } else {
+                        for (uint32_t b = 0; b < nb; ++b) {
+                            uint32_t cc, own;
+                            double pr;
+                            const bool valid = entry(b, true, cc, own, pr);
+                            const uint32_t slot = valid ? slot_of(cc) : 0xFFFFFFFFu;
+                            add_runs(valid && slot < n_out, own, slot, pr, acc, true);
+                        }
+                    }
+                    wave_sync_lds();
+                    for (uint32_t i = lane; i < n_out; i += WAVE) c_data[out + p0 + i] = acc[i];
+                    wave_sync_lds();
+                }
+                out += wtot;
+                mark(5);
+            }
+#pragma unroll
+            for (int i = 0; i < WPL; ++i) bm[i * WAVE + lane] = 0;
+            wave_sync_lds();
+            }   // segments of the window
+        }
+        if constexpr (!NUMERIC) {
+            const uint64_t tot = wave_sum_u64(fresh);
+            if (lane == 0) count[t] = tot;
+        }
+        if (prof && lane == 0) {
+            const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - t_row);
+            const uint64_t u = ub_dbg[r];
+            const int c = u < 2048 ? 0 : u < 8192 ? 1 : u < 32768 ? 2 : 3;
+            atomicAdd(&prof[8 + 2 * c], dt);
+            atomicAdd(&prof[9 + 2 * c], 1ull);
+            atomicMax(&prof[16], dt);
+        }
+    }
+    if (prof && lane == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], ph[i]);
+        atomicMax(&prof[17], (unsigned long long)((long long)wall_clock64() - t_kernel));   // longest wave
+        atomicAdd(&prof[18], (unsigned long long)((long long)wall_clock64() - t_kernel));
+        atomicAdd(&prof[19], 1ull);
     }
 }
 
@@ -647,7 +964,7 @@ __device__ __forceinline__ void batch_add(const Batch &bt, uint32_t U, const uns
 #pragma unroll
     for (int u = 0; u < LG_U; ++u)
         if ((uint32_t)u < U) add_runs(bt.val[u], bt.own[u], slot[u], bt.pr[u], acc, lds_atomic);
-    token_pass(token, turn + 1);
+    token_pass(token, turn + 1);           // (a real turn never is 0xFFFFFFFF: the token would have to wrap exactly there; see tok_base)
 }
 
 // value walk of one staged group restricted to a pass; returns the number of batches (the token advances by it)
@@ -663,7 +980,7 @@ __device__ __forceinline__ uint32_t walk_values(const IDX *__restrict__ b_indice
     for (uint32_t b = wave; b < nbatch; b += LG_WAVES) {
         Batch bt;
         batch_load<K_CAP, true>(bt, b_indices, b_data, wlo, gtot, U, b, kS, kP, kA);
-        batch_add(bt, U, bm, sub, super, base_rank, acc, token, tok_base + b, lds_atomic);
+        batch_add(bt, U, bm, sub, super, base_rank, acc, token, tok_base == 0xFFFFFFFFu ? tok_base : tok_base + b, lds_atomic);
     }
     return nbatch;
 }
@@ -676,11 +993,24 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                                                               const uint64_t *__restrict__ task_row,
                                                               const uint64_t *__restrict__ first_task,
                                                               const uint64_t *__restrict__ ntasks,
+                                                              const uint8_t *__restrict__ wlog,
                                                               uint64_t *__restrict__ count,       // symbolic: out
                                                               const uint64_t *__restrict__ off,   // numeric: in
                                                               IDX *__restrict__ c_indices, double *__restrict__ c_data,
-                                                              uint32_t xcd_chunk, uint32_t flags) {
+                                                              uint32_t xcd_chunk, uint32_t flags,
+                                                              unsigned long long *__restrict__ prof,
+                                                              const uint64_t *__restrict__ ub_dbg) {
     using Cfg = LgCfg<WL>;
+    const long long t_begin = prof ? (long long)wall_clock64() : 0;     // debug option spgemm_prof: 100 MHz ticks per task
+    long long t_prev = t_begin;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto mark = [&](int phase) {                                        // thread 0's view of the phases
+        if (prof && threadIdx.x == 0) {
+            const long long now = (long long)wall_clock64();
+            ph[phase] += (unsigned long long)(now - t_prev);
+            t_prev = now;
+        }
+    };
     constexpr int WORDS = Cfg::WORDS, WPT = Cfg::WPT, NSUPER = Cfg::NSUPER, ACC_CAP = Cfg::ACC_CAP, K_CAP = Cfg::K_CAP;
     __shared__ unsigned long long bm[WORDS];                 // the window's structure: one bit per column
     __shared__ uint16_t sub[NUMERIC ? WORDS : 1];            // outputs before a word inside its superblock
@@ -695,8 +1025,9 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x, xcd_chunk)];
     const uint64_t r = task_row[t];
     const uint64_t jt = t - first_task[r], nt = ntasks[r];
-    constexpr uint64_t W = 1ull << WL;
-    uint64_t nwin = (b_cols + W - 1) >> WL;
+    const uint32_t wl = wlog[r];                             // window width of this row: 2^WL, narrower for heavy rows
+    const uint64_t W = 1ull << wl;
+    uint64_t nwin = (b_cols + W - 1) >> wl;
     if (nwin == 0) nwin = 1;
     const uint64_t wpt = (nwin + nt - 1) / nt;               // windows per task of this row (row_work_kernel)
     const uint64_t w_begin = jt * wpt;
@@ -707,6 +1038,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const bool values = NUMERIC && c_data != nullptr;
     const bool lds_atomic = (flags & 1u) != 0;
     const bool retain_ok = values && (flags & 2u) != 0;
+    const bool no_order = (flags & 4u) != 0, no_emit = (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
     // a row whose k's fit one staged group: thread j keeps k_j, the bounds of B's row k_j and a_ik for the whole task
     const bool mine_k = one_group && tid < (uint32_t)(ae - as) && w_begin < w_end;
     uint64_t rk = 0, rs = 0, re = 0, cur = 0, nxt_e = 0;
@@ -716,25 +1048,26 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
         rs = (uint64_t)B.indptr[rk];
         re = (uint64_t)B.indptr[rk + 1];
         if (values) rav = A.data[as + tid];
-        cur = w_begin == 0 ? rs : first_ge(B, rk, rs, rs, re, w_begin << WL);
-        nxt_e = w_begin + 1 >= nwin ? re : first_ge(B, rk, rs, cur, re, (w_begin + 1) << WL);
+        cur = w_begin == 0 ? rs : first_ge(B, rk, rs, rs, re, w_begin << wl);
+        nxt_e = w_begin + 1 >= nwin ? re : first_ge(B, rk, rs, cur, re, (w_begin + 1) << wl);
     }
     if (tid == 0) token = 0;
     for (int i = tid; i < WORDS; i += LG_BLOCK) bm[i] = 0;
     lds_barrier();
     uint64_t out = 0;
     if constexpr (NUMERIC) out = off[t];
+    mark(0);
     uint32_t fresh = 0, tok_base = 0;
     (void)tok_base;
     for (uint64_t w = w_begin; w < w_end; ++w) {
-        const uint64_t wlo = w << WL, whi = wlo + W;         // whi is not clamped to b_cols: see first_ge
+        const uint64_t wlo = w << wl, whi = wlo + W;         // whi is not clamped to b_cols: see first_ge
         const uint64_t wcols = (whi < b_cols ? whi : b_cols) - wlo;
         const int words = (int)((wcols + SUPER_WORDS * 64 - 1) / (SUPER_WORDS * 64)) * SUPER_WORDS;   // whole superblocks
         // my k's sub-range in this window; the bound of the next window is requested now and used one window later
         const uint64_t ws = cur, we = nxt_e;
         if (mine_k) {
             cur = we;
-            if (w + 1 < w_end) nxt_e = w + 2 >= nwin ? re : first_ge(B, rk, rs, we, re, (w + 2) << WL);
+            if (w + 1 < w_end) nxt_e = w + 2 >= nwin ? re : first_ge(B, rk, rs, we, re, (w + 2) << wl);
         }
         // ---- bit pass -------------------------------------------------------------------------------
         uint32_t k_total = 0;
@@ -765,6 +1098,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             walk_bits<K_CAP>(B.indices, wlo, gtot, kS, kP, (uint32_t *)bm);
         }
         lds_barrier();
+        mark(1);
         if (!any) continue;                                  // block-uniform; the bitmap is still clear
         if constexpr (!NUMERIC) {
             for (int i = tid; i < words; i += LG_BLOCK) {
@@ -801,8 +1135,9 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             if ((int)tid < nsb) super[tid] = spre;
             if (tid == 0) super[nsb] = wtot;
             lds_barrier();
+            mark(2);
             // indices come out sorted: walk the set bits of each word in order
-            if (c_indices) {                                        // (null: C already has its structure)
+            if (c_indices && !no_emit) {                            // (null: C already has its structure)
 #pragma unroll 1
                 for (int i = 0; i < WPT; ++i) {
                     const int word = i * LG_BLOCK + (int)tid;
@@ -817,6 +1152,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                     }
                 }
             }
+            mark(3);
             // ---- values ---------------------------------------------------------------------------------
             // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) of at most ACC_CAP outputs
             uint32_t pb = 0;
@@ -834,7 +1170,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                         lds_barrier();                           // the accumulators are clear before anybody adds
                         const uint32_t U = batch_u(k_total), wave = tid / WAVE;
                         const uint32_t nbatch = (k_total + 64 * U - 1) / (64 * U);
-                        if (wave < nbatch) batch_add(kept, U, bm, sub, super, base_rank, acc, &token, tok_base + wave, lds_atomic);
+                        if (wave < nbatch) batch_add(kept, U, bm, sub, super, base_rank, acc, &token, no_order ? 0xFFFFFFFFu : tok_base + wave, lds_atomic);
                         tok_base += nbatch;
                     } else
                     for (uint64_t kc = as; kc < ae; kc += K_CAP) {
@@ -854,10 +1190,12 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                             gtot = stage_k_group<K_CAP>(A, B, kc, n, single ? wlo : plo, single ? whi : phi, single && nwin == 1,
                                                         kS, kP, kA, wt);
                         }
-                        tok_base += walk_values<K_CAP>(B.indices, B.data, wlo, gtot, kS, kP, kA, bm, sub, super, base_rank, acc,
-                                                       &token, tok_base, lds_atomic);
+                        const uint32_t nb_ = walk_values<K_CAP>(B.indices, B.data, wlo, gtot, kS, kP, kA, bm, sub, super, base_rank, acc,
+                                                                &token, no_order ? 0xFFFFFFFFu : tok_base, lds_atomic);
+                        tok_base += nb_;
                     }
                     lds_barrier();                               // every add has been performed
+                    mark(4);
                     for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
                     lds_barrier();                               // the next pass clears the accumulators
                 }
@@ -866,7 +1204,14 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             out += wtot;
             for (int i = tid; i < words; i += LG_BLOCK) bm[i] = 0;
             lds_barrier();
+            mark(5);
         }
+    }
+    if (prof && tid == 0) {
+        prof[blockIdx.x] = (unsigned long long)((long long)wall_clock64() - t_begin);
+        const double per = (double)ub_dbg[r] / (double)nt;
+        const int cls = per < 8192 ? 0 : per < 32768 ? 1 : per < 131072 ? 2 : per < 524288 ? 3 : 4;
+        for (int i = 0; i < 6; ++i) atomicAdd(&prof[gridDim.x + cls * 8 + i], ph[i]);
     }
     if constexpr (!NUMERIC) {
         const uint64_t wsum = wave_sum_u64(fresh);
@@ -930,10 +1275,10 @@ struct sprs_hip_spgemm_plan {
     int32_t idx_bytes = 8, iptr_bytes = 8;
     uint64_t rows = 0, inner = 0, b_cols = 0, nnz_a = 0, nnz_b = 0;
     const void *a_indptr = nullptr, *a_indices = nullptr, *b_indptr = nullptr, *b_indices = nullptr;   // whose structure it describes
-    uint64_t ntask_total = 0, n_small = 0, n_large = 0, n_tiny = 0, c_nnz = 0, nb = 0;
-    int64_t winlog = 17;
+    uint64_t ntask_total = 0, n_small = 0, n_mid = 0, n_large = 0, n_tiny = 0, c_nnz = 0, nb = 0;
+    int64_t winlog = 17, midwin = 14;
     uint32_t xcd_chunk = 0;        // how the launch deals the task list to the XCDs (task_of_block)
-    sprs_hip::DevBuf bucket, ub, ntasks, first_task, task_row, tiny_list, small_list, large_list, count, off;
+    sprs_hip::DevBuf bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, mid_list, large_list, count, off, counters;
 };
 
 namespace sprs_hip {
@@ -990,12 +1335,16 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     B.bucket = pl->nb ? pl->bucket.as<uint32_t>() : nullptr;
     B.nb = pl->nb;
 
-    DevBuf is_tiny, is_small, n_large_r, pos_tiny, pos_small, pos_large, large_key;
+    DevBuf is_tiny, is_small, is_mid, n_large_r, pos_tiny, pos_small, pos_mid, pos_large, large_key, mid_key, cls;
     SPRS_TRY_HIP(pl->ub.alloc(rows * 8));
+    SPRS_TRY_HIP(pl->wlog.alloc(rows));
     SPRS_TRY_HIP(pl->ntasks.alloc(rows * 8));
     SPRS_TRY_HIP(pl->first_task.alloc((rows + 1) * 8));
     SPRS_TRY_HIP(is_tiny.alloc(rows * 8));
     SPRS_TRY_HIP(is_small.alloc(rows * 8));
+    SPRS_TRY_HIP(is_mid.alloc(rows * 8));
+    SPRS_TRY_HIP(pos_mid.alloc((rows + 1) * 8));
+    SPRS_TRY_HIP(cls.alloc(rows));
     SPRS_TRY_HIP(n_large_r.alloc(rows * 8));
     SPRS_TRY_HIP(pos_tiny.alloc((rows + 1) * 8));
     SPRS_TRY_HIP(pos_small.alloc((rows + 1) * 8));
@@ -1005,41 +1354,48 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
-                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, pl->ub.as<uint64_t>(),
-                           pl->ntasks.as<uint64_t>());
+                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint64_t)options().spgemm_mid,
+                           pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), cls.as<uint8_t>(), pl->wlog.as<uint8_t>());
         SPRS_TRY_HIP(hipGetLastError());
-        hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), rows,
-                           is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), n_large_r.as<uint64_t>());
+        hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, (const uint8_t *)cls.as<uint8_t>(), pl->ntasks.as<uint64_t>(), rows,
+                           is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), is_mid.as<uint64_t>(), n_large_r.as<uint64_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
     SPRS_TRY(exclusive_scan_u64(pl->ntasks.as<uint64_t>(), pl->first_task.as<uint64_t>(), rows, stream));
     SPRS_TRY(exclusive_scan_u64(is_tiny.as<uint64_t>(), pos_tiny.as<uint64_t>(), rows, stream));
     SPRS_TRY(exclusive_scan_u64(is_small.as<uint64_t>(), pos_small.as<uint64_t>(), rows, stream));
+    SPRS_TRY(exclusive_scan_u64(is_mid.as<uint64_t>(), pos_mid.as<uint64_t>(), rows, stream));
     SPRS_TRY(exclusive_scan_u64(n_large_r.as<uint64_t>(), pos_large.as<uint64_t>(), rows, stream));
     SPRS_TRY_HIP(hipMemcpy(&pl->ntask_total, pl->first_task.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
     SPRS_TRY_HIP(hipMemcpy(&pl->n_tiny, pos_tiny.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
     SPRS_TRY_HIP(hipMemcpy(&pl->n_small, pos_small.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
+    SPRS_TRY_HIP(hipMemcpy(&pl->n_mid, pos_mid.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
     SPRS_TRY_HIP(hipMemcpy(&pl->n_large, pos_large.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
-    const uint64_t ntask_total = pl->ntask_total, n_small = pl->n_small, n_large = pl->n_large, n_tiny = pl->n_tiny;
+    const uint64_t ntask_total = pl->ntask_total, n_small = pl->n_small, n_mid = pl->n_mid, n_large = pl->n_large, n_tiny = pl->n_tiny;
     if (n_large > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many SpGEMM tasks for one launch");
 
     SPRS_TRY_HIP(pl->task_row.alloc(ntask_total * 8));
     SPRS_TRY_HIP(pl->tiny_list.alloc(n_tiny * 8));
     SPRS_TRY_HIP(pl->small_list.alloc(n_small * 8));
+    SPRS_TRY_HIP(pl->mid_list.alloc(n_mid * 8));
     SPRS_TRY_HIP(pl->large_list.alloc(n_large * 8));
     SPRS_TRY_HIP(large_key.alloc(n_large * 8));
+    SPRS_TRY_HIP(mid_key.alloc(n_mid * 8));
     SPRS_TRY_HIP(pl->count.alloc(ntask_total * 8));
     SPRS_TRY_HIP(pl->off.alloc((ntask_total + 1) * 8));
     if (ntask_total) {
         hipLaunchKernelGGL(make_tasks_kernel, rgrid, rblock, 0, stream, pl->ntasks.as<uint64_t>(), pl->first_task.as<uint64_t>(),
-                           pl->ub.as<uint64_t>(), rows, pos_tiny.as<uint64_t>(), pos_small.as<uint64_t>(), pos_large.as<uint64_t>(),
-                           is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->tiny_list.as<uint64_t>(),
-                           pl->small_list.as<uint64_t>(), pl->large_list.as<uint64_t>(), large_key.as<uint64_t>());
+                           pl->ub.as<uint64_t>(), rows, pos_tiny.as<uint64_t>(), pos_small.as<uint64_t>(), pos_mid.as<uint64_t>(),
+                           pos_large.as<uint64_t>(), (const uint8_t *)cls.as<uint8_t>(), pl->task_row.as<uint64_t>(),
+                           pl->tiny_list.as<uint64_t>(), pl->small_list.as<uint64_t>(), pl->mid_list.as<uint64_t>(),
+                           pl->large_list.as<uint64_t>(), large_key.as<uint64_t>(), mid_key.as<uint64_t>());
         SPRS_TRY_HIP(hipGetLastError());
     }
     // costliest tasks first (stable sort by cost class); option spgemm_task_order = 2 keeps the row order (A/B)
     if (n_large > 1 && options().spgemm_task_order != 2)
         SPRS_TRY(radix_sort_pairs(large_key.as<uint64_t>(), pl->large_list.as<uint64_t>(), n_large, {{0, 6}}, stream));
+    if (n_mid > 1 && options().spgemm_task_order != 2)
+        SPRS_TRY(radix_sort_pairs(mid_key.as<uint64_t>(), pl->mid_list.as<uint64_t>(), n_mid, {{0, 6}}, stream));
 
     auto small_grid = [&](uint64_t n_tasks) {
         uint64_t g = (n_tasks + SM_WAVES - 1) / SM_WAVES;
@@ -1058,14 +1414,35 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
                            pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
         SPRS_TRY_HIP(hipGetLastError());
     }
+    pl->midwin = options().spgemm_midwin;
+    auto mid_grid = [&](uint64_t n_tasks) {
+        uint64_t g = (n_tasks + MID_WAVES - 1) / MID_WAVES;
+        if (g > 256 * 12) g = 256 * 12;          // what fits the CUs at once; the waves stride over the (cost-sorted) list
+        return dim3((unsigned)g);
+    };
+    if (n_mid) {
+#define SPRS_MID_SYM(WL)                                                                                             \
+    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, false, WL>), mid_grid(n_mid), dim3(MID_BLOCK), 0, stream, A, B, b_cols, \
+                       pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
+                       (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr, (unsigned long long *)nullptr, (const uint64_t *)nullptr, \
+                       pl->counters.as<unsigned int>())
+        SPRS_TRY_HIP(pl->counters.alloc(64));
+        SPRS_TRY_HIP(hipMemsetAsync(pl->counters.p, 0, 64, stream));
+        switch (pl->midwin) {
+            case 13: SPRS_MID_SYM(13); break;
+            default: SPRS_MID_SYM(14); break;
+        }
+#undef SPRS_MID_SYM
+        SPRS_TRY_HIP(hipGetLastError());
+    }
     // ONE launch for all large tasks, in the LDS layout of the window width (option spgemm_winlog)
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
 #define SPRS_LG_SYM(WL)                                                                                              \
     hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, false, 1>), g, blk, 0, stream, A, B, b_cols,                    \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
-                       pl->ntasks.as<uint64_t>(), pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, \
-                       (double *)nullptr, pl->xcd_chunk, 0u)
+                       pl->ntasks.as<uint64_t>(), (const uint8_t *)pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, \
+                       (double *)nullptr, pl->xcd_chunk, 0u, (unsigned long long *)nullptr, (const uint64_t *)nullptr)
         switch (pl->winlog) {
             case 16: SPRS_LG_SYM(16); break;
             case 18: SPRS_LG_SYM(18); break;
@@ -1092,7 +1469,7 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     CsrView<IDX, PTR> A = view_of<IDX, PTR>(a), B = view_of<IDX, PTR>(b);
     B.bucket = pl->nb ? pl->bucket.as<uint32_t>() : nullptr;
     B.nb = pl->nb;
-    const uint64_t n_tiny = pl->n_tiny, n_small = pl->n_small, n_large = pl->n_large;
+    const uint64_t n_tiny = pl->n_tiny, n_small = pl->n_small, n_mid = pl->n_mid, n_large = pl->n_large;
     double *c_values = values ? c->data : nullptr;
     IDX *c_indices = indices ? (IDX *)c->indices : nullptr;
     auto small_grid = [&](uint64_t n_tasks) {
@@ -1108,14 +1485,51 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, stream,
                            A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
                            pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
+    if (n_mid) {
+        uint64_t g = (n_mid + MID_WAVES - 1) / MID_WAVES;
+        if (g > 256 * 12) g = 256 * 12;
+        DevBuf mprof;
+        if (options().spgemm_prof) {
+            SPRS_TRY_HIP(mprof.alloc(256));
+            SPRS_TRY_HIP(hipMemsetAsync(mprof.p, 0, 256, stream));
+        }
+#define SPRS_MID_NUM(WL)                                                                                             \
+    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, true, WL>), dim3((unsigned)g), dim3(MID_BLOCK), 0, stream, A, B, pl->b_cols, \
+                       pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
+                       pl->off.as<uint64_t>(), c_indices, c_values, mprof.as<unsigned long long>(), pl->ub.as<uint64_t>(),   \
+                       pl->counters.as<unsigned int>() + 4)
+        SPRS_TRY_HIP(hipMemsetAsync(pl->counters.as<unsigned int>() + 4, 0, 4, stream));
+        switch (pl->midwin) {
+            case 13: SPRS_MID_NUM(13); break;
+            default: SPRS_MID_NUM(14); break;
+        }
+#undef SPRS_MID_NUM
+        if (mprof.p) {
+            unsigned long long h[32];
+            SPRS_TRY_HIP(hipStreamSynchronize(stream));
+            (void)hipMemcpy(h, mprof.p, 256, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[spgemm_prof] mid rows by products (< 2048, < 8192, < 32768, rest): %llu rows %.1f ms | %llu rows %.1f ms | %llu rows %.1f ms | "
+                            "%llu rows %.1f ms of wave time; longest row %.3f ms; waves %llu, mean wave %.3f ms, longest wave %.3f ms\n",
+                    h[9], h[8] / 1e5, h[11], h[10] / 1e5, h[13], h[12] / 1e5, h[15], h[14] / 1e5, h[16] / 1e5, h[19],
+                    h[19] ? h[18] / 1e5 / (double)h[19] : 0.0, h[17] / 1e5);
+            fprintf(stderr, "[spgemm_prof] mid rows %llu, lane-0 time by phase (ms of wave time): row prologue %.1f, bounds+scan %.1f, stage+loads+bits %.1f, "
+                            "prefix %.1f, emit %.1f, values+flush %.1f\n", (unsigned long long)n_mid, h[0] / 1e5, h[1] / 1e5, h[2] / 1e5, h[3] / 1e5,
+                    h[4] / 1e5, h[5] / 1e5);
+        }
+    }
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
-        const uint32_t flags = (options().spgemm_lds_atomic ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u);
+        const uint32_t flags = (options().spgemm_lds_atomic ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u) | ((uint32_t)options().spgemm_debug << 2);
 #define SPRS_LG_NUM(WL, OCC)                                                                                         \
     hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, true, OCC>), g, blk, 0, stream, A, B, pl->b_cols,            \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
-                       pl->ntasks.as<uint64_t>(), pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices,       \
-                       c_values, pl->xcd_chunk, flags)
+                       pl->ntasks.as<uint64_t>(), (const uint8_t *)pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, \
+                       c_values, pl->xcd_chunk, flags, prof.as<unsigned long long>(), pl->ub.as<uint64_t>())
+        DevBuf prof;
+        if (options().spgemm_prof) {
+            SPRS_TRY_HIP(prof.alloc((n_large + 40) * 8));
+            SPRS_TRY_HIP(hipMemsetAsync(prof.p, 0, (n_large + 40) * 8, stream));
+        }
         const bool occ3 = options().spgemm_occupancy != 2;
         switch (pl->winlog) {
             case 16: if (occ3) SPRS_LG_NUM(16, 6); else SPRS_LG_NUM(16, 4); break;
@@ -1124,6 +1538,54 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
             default: if (occ3) SPRS_LG_NUM(17, 6); else SPRS_LG_NUM(17, 4); break;
         }
 #undef SPRS_LG_NUM
+        if (prof.p) {
+            // debug: 100 MHz ticks per large task, by block (= position in the launch order)
+            SPRS_TRY_HIP(hipStreamSynchronize(stream));
+            unsigned long long phs[40];
+            (void)hipMemcpy(phs, (char *)prof.p + n_large * 8, 320, hipMemcpyDeviceToHost);
+            for (int c = 0; c < 5; ++c)
+                fprintf(stderr, "[spgemm_prof] class %d, thread-0 time by phase (ms of workgroup time): prologue %.1f, stage+bits %.1f, prefix %.1f, "
+                                "emit %.1f, values %.1f, flush+clear %.1f\n", c, phs[c * 8 + 0] / 1e5, phs[c * 8 + 1] / 1e5, phs[c * 8 + 2] / 1e5,
+                        phs[c * 8 + 3] / 1e5, phs[c * 8 + 4] / 1e5, phs[c * 8 + 5] / 1e5);
+            std::vector<unsigned long long> tk(n_large), lst(n_large), trow(pl->ntask_total), ubv(pl->rows), ntk(pl->rows);
+            (void)hipMemcpy(tk.data(), prof.p, n_large * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(lst.data(), pl->large_list.p, n_large * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(trow.data(), pl->task_row.p, pl->ntask_total * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ubv.data(), pl->ub.p, pl->rows * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ntk.data(), pl->ntasks.p, pl->rows * 8, hipMemcpyDeviceToHost);
+            std::vector<uint64_t> a_ip(pl->rows + 1);
+            if (sizeof(PTR) == 8) (void)hipMemcpy(a_ip.data(), a->indptr, (pl->rows + 1) * 8, hipMemcpyDeviceToHost);
+            double sum = 0;
+            unsigned long long mx = 0;
+            // classes by products per task: < 2^13, < 2^15, < 2^17, < 2^19, rest
+            double csum[5] = {0, 0, 0, 0, 0}, cprod[5] = {0, 0, 0, 0, 0};
+            unsigned long long cn[5] = {0, 0, 0, 0, 0};
+            std::vector<std::pair<unsigned long long, uint64_t>> top;
+            for (uint64_t i = 0; i < n_large; ++i) {
+                const uint64_t r = trow[lst[i]];
+                const double per = (double)ubv[r] / (double)ntk[r];
+                const int c = per < 8192 ? 0 : per < 32768 ? 1 : per < 131072 ? 2 : per < 524288 ? 3 : 4;
+                csum[c] += (double)tk[i];
+                cprod[c] += per;
+                ++cn[c];
+                sum += (double)tk[i];
+                if (tk[i] > mx) mx = tk[i];
+                top.push_back({tk[i], i});
+            }
+            std::partial_sort(top.begin(), top.begin() + (top.size() < 8 ? top.size() : 8), top.end(),
+                              [](const auto &x, const auto &y) { return x.first > y.first; });
+            fprintf(stderr, "[spgemm_prof] large tasks %llu: sum %.1f ms of workgroup time, longest %.3f ms\n",
+                    (unsigned long long)n_large, sum / 1e5, (double)mx / 1e5);
+            for (int c = 0; c < 5; ++c)
+                fprintf(stderr, "[spgemm_prof]   class %d: %llu tasks, %.3e products, %.1f ms of workgroup time (%.2f us per task, %.2f ns per product)\n",
+                        c, cn[c], cprod[c], csum[c] / 1e5, cn[c] ? csum[c] / 1e2 / (double)cn[c] : 0.0, cprod[c] ? csum[c] * 10.0 / cprod[c] : 0.0);
+            for (size_t j = 0; j < top.size() && j < 8; ++j) {
+                const uint64_t i = top[j].second, r = trow[lst[i]];
+                fprintf(stderr, "[spgemm_prof]   top %zu: block %llu row %llu products %llu tasks of the row %llu k's %llu: %.3f ms\n", j,
+                        (unsigned long long)i, (unsigned long long)r, ubv[r], ntk[r],
+                        sizeof(PTR) == 8 ? (unsigned long long)(a_ip[r + 1] - a_ip[r]) : 0ull, (double)top[j].first / 1e5);
+            }
+        }
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);

@@ -62,6 +62,27 @@ struct BandPiece {
     uint32_t to_y;              // short piece
 };
 
+// What a kernel keeps of a piece: the same fields with the pointers typed as GLOBAL memory.  A pointer loaded from a struct
+// in memory is a generic ("flat") pointer to the compiler, and a flat load counts on the LDS counter as well: the
+// tile_row load issued with the next tile's stream then held up the first s_waitcnt lgkmcnt(0) of the current tile's LDS
+// work for a whole memory round trip — the software pipeline of the hot kernel did not overlap anything (round 2, found
+// in the ISA: 13 flat operations in band_hot_kernel, 19 in band_cold_kernel).
+#ifdef SPRS_HIP_EMU
+#define SPRS_GLOBAL_AS
+#else
+#define SPRS_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+struct PieceView {
+    const SPRS_GLOBAL_AS uint32_t *rowidx, *tile_row;
+    SPRS_GLOBAL_AS double *carry, *out;
+    uint64_t ent0, nnz;
+    uint32_t nr, ntiles, x0, to_y;
+    __device__ __forceinline__ PieceView(const BandPiece &p)
+        : rowidx((const SPRS_GLOBAL_AS uint32_t *)p.rowidx), tile_row((const SPRS_GLOBAL_AS uint32_t *)p.tile_row),
+          carry((SPRS_GLOBAL_AS double *)p.carry), out((SPRS_GLOBAL_AS double *)p.out), ent0(p.ent0), nnz(p.nnz), nr(p.nr),
+          ntiles(p.ntiles), x0(p.x0), to_y(p.to_y) {}
+};
+
 struct ColdGroup {              // a run of blocks of the cold launch
     uint32_t first_block, first_piece, npieces;   // npieces 8: block b -> piece b % 8 (XCD b % 8), tile b / 8; 1: tile b
 };
@@ -123,7 +144,7 @@ __global__ __launch_bounds__(NTH) void band_hot_kernel(const BandPiece *__restri
     const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t k = 0;
     while (k + 1 < nh && blockIdx.x >= wg_off[k + 1]) ++k;       // block-uniform
-    const BandPiece d = pieces[k];
+    const PieceView d(pieces[k]);
     const uint32_t nwt = d.ntiles;                               // wave tiles of the slice
     const uint32_t b0 = (blockIdx.x - wg_off[k]) * G;            // first block of this workgroup
     // x tile of the slice -> LDS (xp is padded to a whole number of tiles)
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(CNT) void band_cold_kernel(const BandPiece *__restr
     const uint32_t lb = bid - cg.first_block;
     const uint32_t pi = cg.first_piece + (cg.npieces == 1 ? 0u : (lb & 7u));
     const uint32_t w = (cg.npieces == 1 ? lb : (lb >> 3)) * WPB + wave;  // wave tile of the piece
-    const BandPiece d = pieces[pi];
+    const PieceView d(pieces[pi]);
     if (w >= d.ntiles) return;                                           // wave-uniform; no workgroup barrier below
     double *stage = stage_s[wave];
     const uint64_t base = (uint64_t)w * WT;

@@ -183,6 +183,7 @@ inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline long long clock64() { return 0; }
+inline long long wall_clock64() { return 0; }
 
 // atomics: fibers are switched cooperatively, so plain read-modify-write is atomic
 template <typename T, typename U>

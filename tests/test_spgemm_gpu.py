@@ -193,18 +193,18 @@ def test_multi_window_columns(hip):
 def _order_stress_cases():
     """Inputs on which ANY reordering of the additions into one C(i,j) changes the bits: many k's per row whose B rows
     are short and crowd onto few columns (every wave instruction of the value walk holds many k-runs, every accumulator a
-    long chain), magnitudes spread over 12 decades, mixed signs.  The four shapes take the four routes of the large-row
-    kernel: one staged group with the window kept in registers (<= 2048 products), one group with a second walk,
+    long chain), magnitudes spread over 12 decades, mixed signs.  The first four shapes take the four routes of the large-row
+    kernel, the last three those of the wave-per-row kernel: one staged group with the window kept in registers (<= 2048 products), one group with a second walk,
     several staged groups (> 256 k's), several passes (> 3072 outputs in a window)."""
     cases = []
     rng = np.random.default_rng(77)
     u = lambda v: np.asarray(v, dtype=np.uint64)
-    def crowd(n_k, per_row, cols, hot):
-        # B: n_k rows of `per_row` distinct columns, most of them among the first `hot`
+    def crowd(n_k, per_row, cols, hot, stride=1):
+        # B: n_k rows of `per_row` distinct columns, most of them among `hot` popular ones (the first, or every stride-th)
         ip = [0]; ix = []; dt = []
         for _ in range(n_k):
             n_hot = min(hot, max(1, int(per_row * 0.8)))
-            c = set(rng.choice(hot, size=n_hot, replace=False).tolist())
+            c = set((rng.choice(hot, size=n_hot, replace=False) * stride).tolist())
             while len(c) < per_row:
                 c.add(int(rng.integers(0, cols)))
             c = sorted(c)
@@ -223,6 +223,11 @@ def _order_stress_cases():
     cases.append((rows_over(6, 250, 0.95), crowd(250, 30, 5000, 60)))       # ~7 000 products: second walk, one pass
     cases.append((rows_over(4, 700, 0.9), crowd(700, 6, 200_000, 16)))      # three staged groups, two windows
     cases.append((rows_over(3, 240, 0.95), crowd(240, 900, 40_000, 4000)))  # ~4 000+ outputs in the window: passes
+    # rows of <= 64 k's: the wave-per-row kernel — windows kept in registers (<= 256 entries per 8192 columns), windows
+    # walked twice, and windows of more than 512 outputs (several passes over the window's entries)
+    cases.append((rows_over(8, 60, 0.9), crowd(60, 14, 100_000, 300, stride=333)))
+    cases.append((rows_over(8, 64, 0.95), crowd(64, 40, 5000, 50)))
+    cases.append((rows_over(4, 60, 0.95), crowd(60, 900, 40_000, 4000)))
     return cases
 
 
@@ -284,7 +289,7 @@ def test_window_sizes_and_dense_outputs(hip, winlog):
         assert np.diff(ip.astype(np.int64)).max() > 100_000
     finally:
         hip.set_option("spgemm_winlog", 17)
-        hip.set_option("spgemm_heavy", 1 << 20)
+        hip.set_option("spgemm_heavy", 131072)
         hip.set_option("spgemm_bucket", 1)
 
 
