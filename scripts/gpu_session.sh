@@ -13,6 +13,7 @@
 #   pmc[:args]            rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC hit-miss-req) of bench.py [args] -> pmc_summary.txt
 #   spgemm                SpGEMM config 5: seconds, row-block parity, kernel stats (tests/spgemm_bench.py)
 #   spgemm_ab:<cfgs>      SpGEMM config 5 under option sets, separated by '|': e.g. "base|SPGEMM_RETAIN=0|SPGEMM_WINLOG=16 SPGEMM_OCCUPANCY=2"
+#   spgemm_pmc[:env]      SQ / TCC counter passes over SpGEMM config 5 (per kernel means) -> spgemm_pmc.txt
 #   spmm[:args]           SpMM on R-MAT 10M (scripts/spmm_bench.py [n nnz_per_row k ...]) + its kernel stats
 #   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
 TAG=${1:?tag}; shift
@@ -44,6 +45,17 @@ for step in "$@"; do
               [ "$c" = base ] && c=""
               echo "-- ${c:-defaults}" | tee -a $OUT/spgemm_ab.jsonl
               env $c timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds|spgemm_prof" | cut -c1-260 | tee -a $OUT/spgemm_ab.jsonl
+            done ;;
+    spgemm_pmc) i=0
+            for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+                       "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT" \
+                       "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" \
+                       "FETCH_SIZE WRITE_SIZE TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+              i=$((i+1)); rm -rf /tmp/pm_$i
+              ( cd /tmp && env $arg timeout 600 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pm_$i -o pmc -- python $ROOT/tests/spgemm_bench.py 1000000 8 8 1 > /dev/null 2>&1 )
+              f=$(find /tmp/pm_$i -name "*.db" | head -1)
+              echo "== group $i: $grp" | tee -a $OUT/spgemm_pmc.txt
+              if [ -n "$f" ]; then python3 $ROOT/scripts/rocprof_summary.py "$f" sprs_hip | sed -n '/PMC counters/,$p' | grep -E "rows_kernel|PMC|kernel " | cut -c1-250 | tee -a $OUT/spgemm_pmc.txt; fi
             done ;;
     spmm)   timeout 600 python scripts/spmm_bench.py $arg 2>&1 | grep -E "^\{" | tee -a $OUT/spmm.jsonl
             ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spmm_bench.py ${arg:-10000000 32 16} > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|spmm" | cut -c1-200 | head -8 | tee -a $OUT/spmm_kernels.txt ;;

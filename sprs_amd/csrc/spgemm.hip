@@ -758,7 +758,8 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
         const bool has = lane < nk;
         // positions inside B's row k_j as 32-bit offsets from its start (a row has fewer than 2^32 entries: b_cols < 2^32)
         uint64_t rk = 0, rs = 0;
-        uint32_t re = 0, cur = 0, nxt_e = 0;
+        uint32_t re = 0, cur = 0;
+        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;       // where my row leaves windows w .. w + 3: loaded four windows ahead
         double rav = 0.0;
         auto edge = [&](uint32_t lo, uint32_t hi, uint64_t col) -> uint32_t {      // first entry of my row in [lo, hi) with column >= col
             return (uint32_t)(first_ge(B, rk, rs, rs + lo, rs + hi, col) - rs);
@@ -769,7 +770,10 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             re = (uint32_t)((uint64_t)B.indptr[rk + 1] - rs);
             if (values) rav = A.data[as + lane];
             cur = 0;
-            nxt_e = nwin <= 1 ? re : edge(0, re, 1ull << MID_WL);
+            q0 = nwin <= 1 ? re : edge(0, re, 1ull << MID_WL);
+            q1 = nwin <= 2 ? re : edge(0, re, 2ull << MID_WL);
+            q2 = nwin <= 3 ? re : edge(0, re, 3ull << MID_WL);
+            q3 = nwin <= 4 ? re : edge(0, re, 4ull << MID_WL);
         }
         uint64_t out = 0;
         if constexpr (NUMERIC) out = off[t];
@@ -778,10 +782,13 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
         const long long t_row = prof ? (long long)wall_clock64() : 0;
         for (uint64_t w = 0; w < nwin; ++w) {
             const uint64_t win_lo = w << MID_WL;
-            const uint32_t win_s = cur, win_e = nxt_e;
+            const uint32_t win_s = cur, win_e = q0;
             if (has) {
                 cur = win_e;
-                if (w + 1 < nwin) nxt_e = w + 2 >= nwin ? re : edge(win_e, re, (w + 2) << MID_WL);
+                q0 = q1;
+                q1 = q2;
+                q2 = q3;
+                if (w + 4 < nwin) q3 = w + 5 >= nwin ? re : edge(q2, re, (w + 5) << MID_WL);
             }
             const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(has ? win_e - win_s : 0u), WAVE - 1);
             mark(1);
@@ -813,46 +820,55 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             const bool keep = values && nb <= (uint32_t)MID_KEEP;     // wave-uniform
             uint32_t kco[MID_KEEP];                                   // column offset (< 2^15) | owner << 16; 0xFFFFFFFF: no entry
             double kpr[MID_KEEP];
-            // one wave instruction of the expansion: owner, column, (product)
-            auto entry = [&](uint32_t b, bool with_value, uint32_t &cc, uint32_t &own, double &pr) -> bool {
-                const uint32_t tpos = b * WAVE + lane;
-                const bool valid = tpos < total;
-                cc = 0;
-                own = 0;
-                pr = 0.0;
-                if (nk <= 16) {
-                    // few k's (most rows): count the k's that end at or before the position — scalar compares, no LDS round trips
-                    for (uint32_t j = 0; j + 1 < nk; ++j)
-                        own += tpos >= (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)j) ? 1u : 0u;
-                } else if (valid) {
-                    own = flat_owner<MID_K>(kP, tpos);
-                }
-                if (valid) {
-                    const uint64_t pos = kS[own] + (uint64_t)(tpos - kP[own]);
-                    cc = (uint32_t)((uint64_t)B.indices[pos] - wlo);
-                    if (with_value) pr = kA[own] * B.data[pos];
-                }
-                return valid;
-            };
-            // ---- bit pass ----
-            if (keep) {
+            // MID_KEEP wave instructions of the expansion at once (owner, column, product): the loads of all of them are in
+            // flight together — one memory round trip per MID_KEEP * 64 entries, not one per 64
+            auto load_batches = [&](uint32_t b0, bool with_value) {
+                uint64_t pos[MID_KEEP];
+                uint32_t own[MID_KEEP];
+                bool valid[MID_KEEP];
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b) {
-                    kco[b] = 0xFFFFFFFFu;
-                    kpr[b] = 0.0;
-                    if ((uint32_t)b < nb) {
-                        uint32_t cc, own;
-                        if (entry((uint32_t)b, true, cc, own, kpr[b])) kco[b] = cc | (own << 16);
+                    const uint32_t tpos = (b0 + (uint32_t)b) * WAVE + lane;
+                    valid[b] = tpos < total;
+                    own[b] = 0;
+                    pos[b] = 0;
+                    if (b0 + (uint32_t)b < nb) {                      // wave-uniform
+                        if (nk <= 16) {
+                            // few k's (most rows): count the k's that end at or before the position — scalar compares, no LDS
+                            for (uint32_t j = 0; j + 1 < nk; ++j)
+                                own[b] += tpos >= (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)j) ? 1u : 0u;
+                        } else if (valid[b]) {
+                            own[b] = flat_owner<MID_K>(kP, tpos);
+                        }
+                        if (valid[b]) pos[b] = kS[own[b]] + (uint64_t)(tpos - kP[own[b]]);
                     }
                 }
+                uint32_t cc[MID_KEEP];
+                double bv[MID_KEEP];
+#pragma unroll
+                for (int b = 0; b < MID_KEEP; ++b) {
+                    cc[b] = valid[b] ? (uint32_t)((uint64_t)B.indices[pos[b]] - wlo) : 0u;
+                    bv[b] = valid[b] && with_value ? B.data[pos[b]] : 0.0;
+                }
+#pragma unroll
+                for (int b = 0; b < MID_KEEP; ++b) {
+                    kco[b] = valid[b] ? cc[b] | (own[b] << 16) : 0xFFFFFFFFu;
+                    kpr[b] = valid[b] && with_value ? kA[own[b]] * bv[b] : 0.0;
+                }
+            };
+            auto set_bits = [&]() {
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b)
                     if (kco[b] != 0xFFFFFFFFu) atomicOr(&bm32[(kco[b] & 0xFFFFu) >> 5], 1u << (kco[b] & 31));
+            };
+            // ---- bit pass ----
+            if (keep) {
+                load_batches(0, true);
+                set_bits();
             } else {
-                for (uint32_t b = 0; b < nb; ++b) {
-                    uint32_t cc, own;
-                    double pr;
-                    if (entry(b, false, cc, own, pr)) atomicOr(&bm32[cc >> 5], 1u << (cc & 31));
+                for (uint32_t b0 = 0; b0 < nb; b0 += MID_KEEP) {
+                    load_batches(b0, false);
+                    set_bits();
                 }
             }
             wave_sync_lds();
@@ -874,49 +890,40 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                 }
                 wave_sync_lds();
                 mark(3);
-                // ---- indices: sorted for free ----
-                if (c_indices) {
-#pragma unroll
-                    for (int i = 0; i < WPL; ++i) {
-                        unsigned long long m = bm[i * WAVE + lane];
-                        uint32_t run = sub[i * WAVE + lane];
-                        while (m) {
-                            const int bit = __ffsll((long long)m) - 1;
-                            m &= m - 1;
-                            c_indices[out + run++] = (IDX)(wlo + (uint64_t)(i * WAVE + lane) * 64 + (uint64_t)bit);
-                        }
-                    }
-                }
                 mark(4);
                 // ---- values: passes of MID_ACC outputs; every pass walks the window's entries and takes its own ----
-                for (uint32_t p0 = 0; values && p0 < wtot; p0 += MID_ACC) {
+                // The indices come out sorted for free — the rank of a column IS its place in the row — and are written entry by
+                // entry in the first pass (several entries of one column write the same value to the same place).
+                for (uint32_t p0 = 0; (values || c_indices) && p0 < wtot; p0 += MID_ACC) {
                     const uint32_t n_out = wtot - p0 < (uint32_t)MID_ACC ? wtot - p0 : (uint32_t)MID_ACC;
-                    for (uint32_t i = lane; i < n_out; i += WAVE) acc[i] = 0.0;        // tmp starts at N::zero()
+                    if (!values && p0) break;                                          // structure only: one walk
+                    for (uint32_t i = lane; values && i < n_out; i += WAVE) acc[i] = 0.0;   // tmp starts at N::zero()
                     wave_sync_lds();
                     auto slot_of = [&](uint32_t cc) -> uint32_t {
                         const uint32_t word = cc >> 6;
                         return (uint32_t)sub[word] + (uint32_t)__popcll(bm[word] & ((1ull << (cc & 63)) - 1ull)) - p0;
                     };
-                    if (keep) {
+                    auto add_batches = [&](uint32_t b0) {
 #pragma unroll
                         for (int b = 0; b < MID_KEEP; ++b) {
-                            if ((uint32_t)b < nb) {
+                            if (b0 + (uint32_t)b < nb) {                  // wave-uniform
                                 const bool kv = kco[b] != 0xFFFFFFFFu;
                                 const uint32_t slot = kv ? slot_of(kco[b] & 0xFFFFu) : 0xFFFFFFFFu;
-                                add_runs(kv && slot < n_out, kco[b] >> 16, slot, kpr[b], acc, true);
+                                if (kv && c_indices && p0 == 0) c_indices[out + slot] = (IDX)(wlo + (kco[b] & 0xFFFFu));
+                                if (values) add_runs(kv && slot < n_out, kco[b] >> 16, slot, kpr[b], acc, true);
                             }
                         }
+                    };
+                    if (keep) {
+                        add_batches(0);
                     } else {
-                        for (uint32_t b = 0; b < nb; ++b) {
-                            uint32_t cc, own;
-                            double pr;
-                            const bool valid = entry(b, true, cc, own, pr);
-                            const uint32_t slot = valid ? slot_of(cc) : 0xFFFFFFFFu;
-                            add_runs(valid && slot < n_out, own, slot, pr, acc, true);
+                        for (uint32_t b0 = 0; b0 < nb; b0 += MID_KEEP) {
+                            load_batches(b0, values);
+                            add_batches(b0);
                         }
                     }
                     wave_sync_lds();
-                    for (uint32_t i = lane; i < n_out; i += WAVE) c_data[out + p0 + i] = acc[i];
+                    for (uint32_t i = lane; values && i < n_out; i += WAVE) c_data[out + p0 + i] = acc[i];
                     wave_sync_lds();
                 }
                 out += wtot;
@@ -1290,6 +1297,30 @@ CsrView<IDX, PTR> view_of(const sprs_hip_csmat *m) {
     return CsrView<IDX, PTR>{(const PTR *)m->indptr, (const IDX *)m->indices, m->data, nullptr, 0};
 }
 
+// Option spgemm_overlap = 1: the wave kernels (hash rows, wave-per-row rows) run on a second stream beside the workgroup
+// kernel of the large rows.  Measured on config 5: 0.1165 s against 0.1123 s on one stream (profiles/r03e) — the kernels
+// are throughput bound and only trade time — so the default is one stream.
+struct AuxStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+};
+AuxStream *aux_stream() {
+    static std::mutex mu;
+    static std::unordered_map<int, AuxStream> per_device;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    AuxStream &a = per_device[dev];
+    if (!a.ok) {
+        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        a.ok = true;
+    }
+    return &a;
+}
+
 // ---- symbolic phase: counts, offsets, task lists ---------------------------------------------------------
 template <typename IDX, typename PTR>
 int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_spgemm_plan *pl) {
@@ -1397,43 +1428,12 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     if (n_mid > 1 && options().spgemm_task_order != 2)
         SPRS_TRY(radix_sort_pairs(mid_key.as<uint64_t>(), pl->mid_list.as<uint64_t>(), n_mid, {{0, 6}}, stream));
 
-    auto small_grid = [&](uint64_t n_tasks) {
-        uint64_t g = (n_tasks + SM_WAVES - 1) / SM_WAVES;
-        if (g > 256 * 32) g = 256 * 32;
-        return dim3((unsigned)g);
-    };
-    if (n_tiny) {
-        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, stream,
-                           A, B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
-                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
-        SPRS_TRY_HIP(hipGetLastError());
-    }
-    if (n_small) {
-        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, stream,
-                           A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
-                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
-        SPRS_TRY_HIP(hipGetLastError());
-    }
-    pl->midwin = options().spgemm_midwin;
-    auto mid_grid = [&](uint64_t n_tasks) {
-        uint64_t g = (n_tasks + MID_WAVES - 1) / MID_WAVES;
-        if (g > 256 * 12) g = 256 * 12;          // what fits the CUs at once; the waves stride over the (cost-sorted) list
-        return dim3((unsigned)g);
-    };
-    if (n_mid) {
-#define SPRS_MID_SYM(WL)                                                                                             \
-    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, false, WL>), mid_grid(n_mid), dim3(MID_BLOCK), 0, stream, A, B, b_cols, \
-                       pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
-                       (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr, (unsigned long long *)nullptr, (const uint64_t *)nullptr, \
-                       pl->counters.as<unsigned int>())
-        SPRS_TRY_HIP(pl->counters.alloc(64));
-        SPRS_TRY_HIP(hipMemsetAsync(pl->counters.p, 0, 64, stream));
-        switch (pl->midwin) {
-            case 13: SPRS_MID_SYM(13); break;
-            default: SPRS_MID_SYM(14); break;
-        }
-#undef SPRS_MID_SYM
-        SPRS_TRY_HIP(hipGetLastError());
+    // large rows first on the main stream (the long tasks start at once), the wave kernels beside them on the second stream
+    AuxStream *aux = options().spgemm_overlap && !options().spgemm_prof ? aux_stream() : nullptr;
+    hipStream_t wstream = aux ? aux->s : stream;
+    if (aux) {
+        SPRS_TRY_HIP(hipEventRecord(aux->fork, stream));
+        SPRS_TRY_HIP(hipStreamWaitEvent(aux->s, aux->fork, 0));
     }
     // ONE launch for all large tasks, in the LDS layout of the window width (option spgemm_winlog)
     if (n_large) {
@@ -1451,6 +1451,48 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         }
 #undef SPRS_LG_SYM
         SPRS_TRY_HIP(hipGetLastError());
+    }
+    auto small_grid = [&](uint64_t n_tasks) {
+        uint64_t g = (n_tasks + SM_WAVES - 1) / SM_WAVES;
+        if (g > 256 * 32) g = 256 * 32;
+        return dim3((unsigned)g);
+    };
+    if (n_tiny) {
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, wstream,
+                           A, B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
+                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    if (n_small) {
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, wstream,
+                           A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
+                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    pl->midwin = options().spgemm_midwin;
+    auto mid_grid = [&](uint64_t n_tasks) {
+        uint64_t g = (n_tasks + MID_WAVES - 1) / MID_WAVES;
+        if (g > 256 * 12) g = 256 * 12;          // what fits the CUs at once; the waves stride over the (cost-sorted) list
+        return dim3((unsigned)g);
+    };
+    if (n_mid) {
+#define SPRS_MID_SYM(WL)                                                                                             \
+    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, false, WL>), mid_grid(n_mid), dim3(MID_BLOCK), 0, wstream, A, B, b_cols, \
+                       pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
+                       (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr, (unsigned long long *)nullptr, (const uint64_t *)nullptr, \
+                       pl->counters.as<unsigned int>())
+        SPRS_TRY_HIP(pl->counters.alloc(64));
+        SPRS_TRY_HIP(hipMemsetAsync(pl->counters.p, 0, 64, wstream));
+        switch (pl->midwin) {
+            case 13: SPRS_MID_SYM(13); break;
+            default: SPRS_MID_SYM(14); break;
+        }
+#undef SPRS_MID_SYM
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    if (aux) {
+        SPRS_TRY_HIP(hipEventRecord(aux->join, aux->s));
+        SPRS_TRY_HIP(hipStreamWaitEvent(stream, aux->join, 0));
     }
     // ---- prefix sum of the counts -> offsets, C.indptr (smmp.rs:320-331) ----
     SPRS_TRY(exclusive_scan_u64(pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), ntask_total, stream));
@@ -1477,45 +1519,11 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
         if (g > 256 * 32) g = 256 * 32;
         return dim3((unsigned)g);
     };
-    if (n_tiny)
-        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, stream, A,
-                           B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
-                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
-    if (n_small)
-        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, stream,
-                           A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
-                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
-    if (n_mid) {
-        uint64_t g = (n_mid + MID_WAVES - 1) / MID_WAVES;
-        if (g > 256 * 12) g = 256 * 12;
-        DevBuf mprof;
-        if (options().spgemm_prof) {
-            SPRS_TRY_HIP(mprof.alloc(256));
-            SPRS_TRY_HIP(hipMemsetAsync(mprof.p, 0, 256, stream));
-        }
-#define SPRS_MID_NUM(WL)                                                                                             \
-    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, true, WL>), dim3((unsigned)g), dim3(MID_BLOCK), 0, stream, A, B, pl->b_cols, \
-                       pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
-                       pl->off.as<uint64_t>(), c_indices, c_values, mprof.as<unsigned long long>(), pl->ub.as<uint64_t>(),   \
-                       pl->counters.as<unsigned int>() + 4)
-        SPRS_TRY_HIP(hipMemsetAsync(pl->counters.as<unsigned int>() + 4, 0, 4, stream));
-        switch (pl->midwin) {
-            case 13: SPRS_MID_NUM(13); break;
-            default: SPRS_MID_NUM(14); break;
-        }
-#undef SPRS_MID_NUM
-        if (mprof.p) {
-            unsigned long long h[32];
-            SPRS_TRY_HIP(hipStreamSynchronize(stream));
-            (void)hipMemcpy(h, mprof.p, 256, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[spgemm_prof] mid rows by products (< 2048, < 8192, < 32768, rest): %llu rows %.1f ms | %llu rows %.1f ms | %llu rows %.1f ms | "
-                            "%llu rows %.1f ms of wave time; longest row %.3f ms; waves %llu, mean wave %.3f ms, longest wave %.3f ms\n",
-                    h[9], h[8] / 1e5, h[11], h[10] / 1e5, h[13], h[12] / 1e5, h[15], h[14] / 1e5, h[16] / 1e5, h[19],
-                    h[19] ? h[18] / 1e5 / (double)h[19] : 0.0, h[17] / 1e5);
-            fprintf(stderr, "[spgemm_prof] mid rows %llu, lane-0 time by phase (ms of wave time): row prologue %.1f, bounds+scan %.1f, stage+loads+bits %.1f, "
-                            "prefix %.1f, emit %.1f, values+flush %.1f\n", (unsigned long long)n_mid, h[0] / 1e5, h[1] / 1e5, h[2] / 1e5, h[3] / 1e5,
-                    h[4] / 1e5, h[5] / 1e5);
-        }
+    AuxStream *aux = options().spgemm_overlap && !options().spgemm_prof ? aux_stream() : nullptr;
+    hipStream_t wstream = aux ? aux->s : stream;
+    if (aux) {
+        SPRS_TRY_HIP(hipEventRecord(aux->fork, stream));
+        SPRS_TRY_HIP(hipStreamWaitEvent(aux->s, aux->fork, 0));
     }
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
@@ -1586,6 +1594,50 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
                         sizeof(PTR) == 8 ? (unsigned long long)(a_ip[r + 1] - a_ip[r]) : 0ull, (double)top[j].first / 1e5);
             }
         }
+    }
+    if (n_tiny)
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, wstream, A,
+                           B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
+                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
+    if (n_small)
+        hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, wstream,
+                           A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
+                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
+    if (n_mid) {
+        uint64_t g = (n_mid + MID_WAVES - 1) / MID_WAVES;
+        if (g > 256 * 12) g = 256 * 12;
+        DevBuf mprof;
+        if (options().spgemm_prof) {
+            SPRS_TRY_HIP(mprof.alloc(256));
+            SPRS_TRY_HIP(hipMemsetAsync(mprof.p, 0, 256, stream));
+        }
+#define SPRS_MID_NUM(WL)                                                                                             \
+    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, true, WL>), dim3((unsigned)g), dim3(MID_BLOCK), 0, wstream, A, B, pl->b_cols, \
+                       pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
+                       pl->off.as<uint64_t>(), c_indices, c_values, mprof.as<unsigned long long>(), pl->ub.as<uint64_t>(),   \
+                       pl->counters.as<unsigned int>() + 4)
+        SPRS_TRY_HIP(hipMemsetAsync(pl->counters.as<unsigned int>() + 4, 0, 4, wstream));
+        switch (pl->midwin) {
+            case 13: SPRS_MID_NUM(13); break;
+            default: SPRS_MID_NUM(14); break;
+        }
+#undef SPRS_MID_NUM
+        if (mprof.p) {
+            unsigned long long h[32];
+            SPRS_TRY_HIP(hipStreamSynchronize(stream));
+            (void)hipMemcpy(h, mprof.p, 256, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[spgemm_prof] mid rows by products (< 2048, < 8192, < 32768, rest): %llu rows %.1f ms | %llu rows %.1f ms | %llu rows %.1f ms | "
+                            "%llu rows %.1f ms of wave time; longest row %.3f ms; waves %llu, mean wave %.3f ms, longest wave %.3f ms\n",
+                    h[9], h[8] / 1e5, h[11], h[10] / 1e5, h[13], h[12] / 1e5, h[15], h[14] / 1e5, h[16] / 1e5, h[19],
+                    h[19] ? h[18] / 1e5 / (double)h[19] : 0.0, h[17] / 1e5);
+            fprintf(stderr, "[spgemm_prof] mid rows %llu, lane-0 time by phase (ms of wave time): row prologue %.1f, bounds+scan %.1f, stage+loads+bits %.1f, "
+                            "prefix %.1f, emit %.1f, values+flush %.1f\n", (unsigned long long)n_mid, h[0] / 1e5, h[1] / 1e5, h[2] / 1e5, h[3] / 1e5,
+                    h[4] / 1e5, h[5] / 1e5);
+        }
+    }
+    if (aux) {
+        SPRS_TRY_HIP(hipEventRecord(aux->join, aux->s));
+        SPRS_TRY_HIP(hipStreamWaitEvent(stream, aux->join, 0));
     }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
