@@ -13,6 +13,7 @@
 #   pmc[:args]            rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / TCC hit-miss-req) of bench.py [args] -> pmc_summary.txt
 #   spgemm                SpGEMM config 5: seconds, row-block parity, kernel stats (tests/spgemm_bench.py)
 #   spgemm_ab:<cfgs>      SpGEMM config 5 under option sets, separated by '|': e.g. "base|SPGEMM_RETAIN=0|SPGEMM_WINLOG=16 SPGEMM_OCCUPANCY=2"
+#   spmm_ab:<cfgs>        SpMM (k = 8, 16 on R-MAT 10M) under option sets, e.g. "base|SPMM_LONG_ROW=0"
 #   spgemm_pmc[:env]      SQ / TCC counter passes over SpGEMM config 5 (per kernel means) -> spgemm_pmc.txt
 #   spmm[:args]           SpMM on R-MAT 10M (scripts/spmm_bench.py [n nnz_per_row k ...]) + its kernel stats
 #   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
@@ -45,6 +46,12 @@ for step in "$@"; do
               [ "$c" = base ] && c=""
               echo "-- ${c:-defaults}" | tee -a $OUT/spgemm_ab.jsonl
               env $c timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds|spgemm_prof" | cut -c1-260 | tee -a $OUT/spgemm_ab.jsonl
+            done ;;
+    spmm_ab) IFS='|' read -ra CFG <<< "$arg"
+            for c in "${CFG[@]}"; do
+              [ "$c" = base ] && c=""
+              echo "-- ${c:-defaults}" | tee -a $OUT/spmm_ab.jsonl
+              env $c timeout 600 python scripts/spmm_bench.py 10000000 32 8 16 2>&1 | grep -E "^\{" | tee -a $OUT/spmm_ab.jsonl
             done ;;
     spgemm_pmc) i=0
             for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \

@@ -20,6 +20,9 @@ def main():
     nzr = float(sys.argv[2]) if len(sys.argv) > 2 else 32
     ks = [int(v) for v in sys.argv[3:]] or [8, 16, 32]
     dev = torch.device("cuda", 0)
+    if os.environ.get("SPMM_LONG_ROW"):
+        import sprs_amd
+        sprs_amd.set_option("spmm_long_row", int(os.environ["SPMM_LONG_ROW"]))
     indptr, indices, data = gen.rmat_csr(n, nzr, device=dev)
     a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
     nnz = indices.numel()

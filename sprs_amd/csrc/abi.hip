@@ -921,6 +921,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         o.spgemm_bucket = value ? 1 : 0;
     } else if (!strcmp(name, "spgemm_prof")) {
         o.spgemm_prof = value ? 1 : 0;
+    } else if (!strcmp(name, "spmm_long_row")) {
+        if (value < -1) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmm_long_row must be >= -1");
+        o.spmm_long_row = value;
     } else if (!strcmp(name, "spgemm_overlap")) {
         o.spgemm_overlap = value ? 1 : 0;
     } else if (!strcmp(name, "spgemm_midwin")) {
@@ -1025,6 +1028,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_mid")) *value = o.spgemm_mid;
     else if (!strcmp(name, "spgemm_midwin")) *value = o.spgemm_midwin;
     else if (!strcmp(name, "spgemm_overlap")) *value = o.spgemm_overlap;
+    else if (!strcmp(name, "spmm_long_row")) *value = o.spmm_long_row;
     else if (!strcmp(name, "spgemm_minwin")) *value = o.spgemm_minwin;
     else if (!strcmp(name, "spgemm_task_order")) *value = o.spgemm_task_order;
     else if (!strcmp(name, "spgemm_xcd_chunk")) *value = o.spgemm_xcd_chunk;

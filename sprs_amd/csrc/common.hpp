@@ -76,6 +76,7 @@ struct Options {
     int64_t spmv_band_short_group = 0;    // blocks per workgroup of the tiled short-rows launch (0 = default 4)
     int64_t spmv_band_split = 0;          // rows with at least this many entries are cut into pieces (0 = default 24)
     int64_t spmv_band_group = 0;   // blocks of 8192 entries per workgroup of the hot kernel (0 = default 16)
+    int64_t spmm_long_row = -1;    // SpMM: rows of more entries go to the chunk kernels (summation by chunks); -1 = default (0: all rows); L > 0: rows of <= L entries are summed in entry order by lane groups (the reference's bits, 3x slower)
     int64_t spmv_lds_pad = 0;      // extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning)
     int64_t spmv_xmask = -1;       // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
 };
@@ -129,7 +130,7 @@ int32_t exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, hipStr
 // ---- SpMM plan: rows cut into chunks of <= 512 entries (spmm.hip) -------------------------------
 struct SpmmPlan {
     bool built = false;
-    uint64_t nchunks = 0, n_multi = 0;
+    uint64_t nchunks = 0, n_multi = 0, long_row = 0;
     uint64_t *first_chunk = nullptr;   // device, rows + 1
     uint64_t *chunk_row = nullptr;     // device, nchunks
     uint64_t *multi_rows = nullptr;    // device, rows spanning several chunks

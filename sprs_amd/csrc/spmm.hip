@@ -7,16 +7,16 @@
 // k/16 .. 1 full line of useful data instead of 8 bytes of it.
 //
 // Decomposition (plan cached in the handle):
-//  * rows of at most LONG_ROW entries — all but a handful — belong to a GROUP of KP lanes (KP = k rounded up to a power
-//    of two, 64 / KP groups per wave).  A group walks its rows (group-stride) as a little state machine: every turn
-//    it loads the next <= 32 entries of its current row coalesced, then the 32 rhs rows they name (all in flight at
-//    once: the latency of one turn buys 32 lines per group), and adds the products IN ENTRY ORDER into one accumulator
-//    per column — the reference's own order, out[i, j] = (..(out[i, j] + a_i0 rhs[0, j]) + ..) — bit for bit, the
-//    accumulate form included.  A group whose row ends writes it and moves on while its neighbours continue: rows
-//    of different lengths cost no idle lanes.  No atomics, no scratch.
-//  * longer rows are cut into CHUNKS of 512 entries, one wave per chunk (lane j of group g takes entries g, g + G,
-//    ... of the chunk, groups combined with xor-shuffles), partials added in chunk order by a second kernel:
-//    deterministic, equal to the reference up to the summation order (tests: 1e-12 relative).
+//  * DEFAULT: every row is cut into CHUNKS of 512 entries, one wave per chunk (lane j of group g takes entries g, g + G,
+//    ... of the chunk, groups of KP lanes — KP = k rounded up to a power of two — combined with xor-shuffles), partials of
+//    multi-chunk rows added in chunk order by a second kernel: deterministic, equal to the reference up to the summation
+//    order (tests: 1e-12 relative).  All 64 lanes stream entries and every lane has its gathers in flight: 12.1 ms at
+//    k = 16 on R-MAT 10M (3.4 TB/s of rhs-row gathers — the bound: 41 GB of 128-byte rows from a 1.28 GB operand).
+//  * option spmm_long_row = L > 0: rows of at most L entries instead belong to a GROUP of KP lanes that walks its rows
+//    as a little state machine (32 entries and their rhs rows in flight per turn) and adds the products IN ENTRY ORDER
+//    into one accumulator per column — the reference's own order, bit for bit, the accumulate form included.  Measured
+//    3.4x slower (41 ms at k = 16, profiles/r03f: the serial chains and 64-bit shuffles leave the gathers idle), hence
+//    opt-in for callers that need the reference's bits.
 // Unfused multiply-add (-ffp-contract=off) like MulAcc (mul_acc.rs:28-30).
 #include "common.hpp"
 #include "scan.hpp"
@@ -29,15 +29,15 @@ constexpr int WAVE = 64;
 constexpr int MM_BLOCK = 256;
 constexpr int MM_WAVES = MM_BLOCK / WAVE;
 constexpr uint64_t CHUNK = 512;
-constexpr uint64_t LONG_ROW = 2048;        // rows above this many entries go to the chunk kernels
+constexpr uint64_t LONG_ROW = 0;           // default of option spmm_long_row: rows above this many entries go to the chunk kernels (0: all)
 
 template <typename PTR>
-__global__ void count_chunks_kernel(const PTR *__restrict__ indptr, uint64_t rows, uint64_t *__restrict__ nchunks,
+__global__ void count_chunks_kernel(const PTR *__restrict__ indptr, uint64_t rows, uint64_t long_row, uint64_t *__restrict__ nchunks,
                                     uint64_t *__restrict__ is_multi) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const uint64_t len = (uint64_t)indptr[r + 1] - (uint64_t)indptr[r];
-    const uint64_t n = len > LONG_ROW ? (len + CHUNK - 1) / CHUNK : 0;
+    const uint64_t n = len > long_row ? (len + CHUNK - 1) / CHUNK : 0;
     nchunks[r] = n;
     is_multi[r] = n > 1 ? 1 : 0;
 }
@@ -56,7 +56,7 @@ template <typename IDX, typename PTR, int KP, bool ACC>
 __global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
                                                              const double *__restrict__ data, uint64_t rows,
                                                              const double *__restrict__ rhs, uint64_t ld_rhs, uint32_t k,
-                                                             double *__restrict__ out, uint64_t ld_out) {
+                                                             double *__restrict__ out, uint64_t ld_out, uint64_t long_row) {
     constexpr int EB = KP <= 16 ? 32 / KP : 1;           // entries a lane loads per turn
     constexpr int NB = EB * KP;                          // entries of a turn (32, or KP)
     constexpr int UN = NB < 32 ? NB : 32;                // rhs rows in flight per group
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restri
     if (active) {
         cur = (uint64_t)indptr[r];
         end = (uint64_t)indptr[r + 1];
-        mine = end - cur <= LONG_ROW;
+        mine = end - cur <= long_row;
         if (!mine) cur = end;
         if constexpr (ACC)
             if (mine && col_ok) acc = out[r * ld_out + j];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restri
             end = nend;
             acc = 0.0;
             if (active) {
-                mine = end - cur <= LONG_ROW;
+                mine = end - cur <= long_row;
                 if (!mine) cur = end;
                 if constexpr (ACC)
                     if (mine && col_ok) acc = out[r * ld_out + j];
@@ -215,6 +215,7 @@ template <typename PTR>
 int32_t build_spmm_plan(sprs_hip_csmat *a, hipStream_t stream) {
     SpmmPlan &pl = a->mm;
     pl.release();
+    pl.long_row = options().spmm_long_row >= 0 ? (uint64_t)options().spmm_long_row : LONG_ROW;
     const uint64_t rows = a->rows;
     Tmp nch, mflag, mpos;
     SPRS_TRY_HIP(nch.alloc(rows * 8));
@@ -222,7 +223,7 @@ int32_t build_spmm_plan(sprs_hip_csmat *a, hipStream_t stream) {
     SPRS_TRY_HIP(mpos.alloc((rows + 1) * 8));
     SPRS_TRY_HIP(hipMalloc((void **)&pl.first_chunk, (rows + 1) * 8));
     hipLaunchKernelGGL(count_chunks_kernel<PTR>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream,
-                       (const PTR *)a->indptr, rows, nch.u64(), mflag.u64());
+                       (const PTR *)a->indptr, rows, pl.long_row, nch.u64(), mflag.u64());
     SPRS_TRY_HIP(hipGetLastError());
     SPRS_TRY(exclusive_scan_u64(nch.u64(), pl.first_chunk, rows, stream));
     SPRS_TRY(exclusive_scan_u64(mflag.u64(), mpos.u64(), rows, stream));
@@ -250,10 +251,10 @@ int32_t launch_block(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint
         const dim3 grid((unsigned)blocks), block(MM_BLOCK);
         if (acc)
             hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, true>), grid, block, 0, stream, (const PTR *)a->indptr,
-                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, k, out, ld_out);
+                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, k, out, ld_out, pl.long_row);
         else
             hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, false>), grid, block, 0, stream, (const PTR *)a->indptr,
-                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, k, out, ld_out);
+                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, k, out, ld_out, pl.long_row);
         SPRS_TRY_HIP(hipGetLastError());
     }
     if (!pl.nchunks) return SPRS_HIP_OK;
@@ -289,7 +290,8 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
     double *partial = nullptr;
     {
         std::lock_guard<std::mutex> lock(a->mu);
-        if (!a->mm.built) SPRS_TRY(build_spmm_plan<PTR>(a, stream));
+        const uint64_t want_long = options().spmm_long_row >= 0 ? (uint64_t)options().spmm_long_row : LONG_ROW;
+        if (!a->mm.built || a->mm.long_row != want_long) SPRS_TRY(build_spmm_plan<PTR>(a, stream));
         SpmmPlan &pl = a->mm;
         const uint64_t kb = k < 64 ? k : 64;
         const uint64_t need = (pl.n_multi ? pl.nchunks : 0) * kb * sizeof(double);

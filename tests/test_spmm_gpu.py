@@ -51,8 +51,17 @@ def test_golden_mul_csr_dense_rowmaj(hip, golden, idx, ptr):
         assert np.all(np.abs(res.to_host() - 2 * exp) <= 2 * golden[ek]["epsilon"] + 1e-12)
 
 
+@pytest.fixture(params=[0, 2048], ids=["chunks", "entry-order"])
+def long_row(request, hip):
+    """the two summation modes of spmm.hip: every row by 512-entry chunks (default), or rows of <= L entries in the
+    reference's own entry order (option spmm_long_row = L: bit-identical to prod.rs:203-210)"""
+    hip.set_option("spmm_long_row", request.param)
+    yield request.param
+    hip.set_option("spmm_long_row", -1)
+
+
 @pytest.mark.parametrize("k", [1, 3, 8, 16, 33, 64, 100])
-def test_rmat_vs_oracle(hip, k):
+def test_rmat_vs_oracle(hip, k, long_row):
     from sprs_amd import gen, prod
     from sprs_amd.device import DeviceCsMat
     n = 30000
@@ -66,8 +75,8 @@ def test_rmat_vs_oracle(hip, k):
     ref = oracle_spmm((n, n), ip, ix, dt, rhs)
     assert rel_err(got, ref) <= TOL
     lens = np.diff(ip.astype(np.int64))
-    short = lens <= 2048                                        # spmm.hip LONG_ROW: these rows are summed in entry order,
-    assert np.array_equal(got[short], ref[short])               # the reference's own (prod.rs:203-210): bit for bit
+    short = (lens <= long_row) | (lens <= 1)                    # rows of <= L entries are summed in entry order, the
+    assert np.array_equal(got[short], ref[short])               # reference's own (prod.rs:203-210): bit for bit
     empty = np.diff(ip.astype(np.int64)) == 0
     assert empty.any() and np.all(got[empty] == 0.0)
     out0 = rng.random((n, k))
@@ -83,8 +92,8 @@ def test_rmat_vs_oracle(hip, k):
 
 
 @pytest.mark.parametrize("k", [2, 16, 40])
-def test_long_rows_take_the_chunk_kernels(hip, k):
-    """rows above spmm.hip's LONG_ROW (2048 entries) are cut into 512-entry chunks: same values up to the summation order"""
+def test_long_rows_take_the_chunk_kernels(hip, k, long_row):
+    """rows above option spmm_long_row are cut into 512-entry chunks: same values up to the summation order"""
     from sprs_amd import prod
     from sprs_amd.device import DeviceCsMat
     rng = np.random.default_rng(100 + k)
@@ -102,7 +111,7 @@ def test_long_rows_take_the_chunk_kernels(hip, k):
     ref = oracle_spmm((n, m), ip, ix, dt, rhs)
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= 1e-12 * scale
-    assert np.array_equal(got[lens <= 2048], ref[lens <= 2048])
+    assert np.array_equal(got[lens <= max(long_row, 1)], ref[lens <= max(long_row, 1)])
     out0 = rng.standard_normal((n, k))
     res = prod.DeviceMat.from_host(out0)
     prod.csr_mulacc_dense_rowmaj(a, prod.DeviceMat.from_host(rhs), res)
