@@ -985,6 +985,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "spmv_band_overlap")) {
         if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_overlap must be 0, 1 or 2");
         o.spmv_band_overlap = value;
+    } else if (!strcmp(name, "spmv_band_natural")) {
+        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_natural must be 0, 1 or 2");
+        o.spmv_band_natural = value;
     } else if (!strcmp(name, "spmv_band_split_permute")) {
         if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_split_permute must be 0, 1 or 2");
         o.spmv_band_split_permute = value;
@@ -1047,6 +1050,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spmv_band_short_group")) *value = o.spmv_band_short_group;
     else if (!strcmp(name, "spmv_band_short")) *value = o.spmv_band_short;
     else if (!strcmp(name, "spmv_band_split_permute")) *value = o.spmv_band_split_permute;
+    else if (!strcmp(name, "spmv_band_natural")) *value = o.spmv_band_natural;
     else if (!strcmp(name, "spmv_band_overlap")) *value = o.spmv_band_overlap;
     else if (!strcmp(name, "spmv_band_hot_threads")) *value = o.spmv_band_hot_threads;
     else if (!strcmp(name, "spmv_band_gather")) *value = o.spmv_band_gather;

@@ -71,6 +71,7 @@ struct Options {
     int64_t spmv_band_hot_threads = 0;    // threads per workgroup of the hot kernel: 1024 (default) or 512
     int64_t spmv_band_gather = 0;         // how the cold kernel reads x: 0 plain, 1 non-temporal, 2 device scope (L1 bypass)
     int64_t spmv_band_overlap = 0;        // cold pieces + short rows on a second stream beside the hot kernel: 0/1 on, 2 off
+    int64_t spmv_band_natural = 0;        // cold entries keep their original column and read x itself (no per-SpMV scatter of x): 1 on (measured slower: profiles/r03i), 0/2 off
     int64_t spmv_band_split_permute = 0;  // with the overlap: hot labels of x gathered first, the rest scattered on the second stream: 0/1 on, 2 off
     int64_t spmv_band_short = 0;          // short rows: 0/2 as one more gather piece, 1 tiled with the 8192 hottest x entries in LDS (measured slower)
     int64_t spmv_band_short_group = 0;    // blocks per workgroup of the tiled short-rows launch (0 = default 4)
@@ -109,7 +110,7 @@ struct SpmvPlan {
     bool built = false;
     bool xcs = false;
     BandPlan *band = nullptr;      // banded plan: when set, nothing else below is used
-    int64_t opt_band = -1, opt_band_hot = -1, opt_band_phases = -1, opt_band_group = -1, opt_band_split = -1;
+    int64_t opt_band = -1, opt_band_hot = -1, opt_band_phases = -1, opt_band_group = -1, opt_band_split = -1, opt_band_natural = -1, opt_band_short = -1;
     int64_t opt_xcs = -1, opt_split = -1, opt_idx32 = -1, opt_tile = -1, opt_sort = -1, opt_relabel = -1;   // option values the plan was built with
     uint32_t tile = 0;             // nnz per tile
     int idx_bytes = 8;             // width of the column ids the kernels read (handle's, or 4 for plan copies)

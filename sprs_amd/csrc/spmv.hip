@@ -579,6 +579,8 @@ static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
     pl.opt_band_hot = o.spmv_band_hot;
     pl.opt_band_phases = o.spmv_band_phases;
     pl.opt_band_split = o.spmv_band_split;
+    pl.opt_band_natural = o.spmv_band_natural;
+    pl.opt_band_short = o.spmv_band_short;
     pl.opt_band_group = o.spmv_band_group + 100000 * o.spmv_band_hot_threads + 100000000 * o.spmv_band_short_group;   // (one key for the three)
     pl.idx_bytes = (int)sizeof(IDX);
     const uint64_t rows = a->rows, nnz = a->nnz;
@@ -732,7 +734,8 @@ static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool 
         if (!pl.built || pl.opt_xcs != o.spmv_xcs || pl.opt_split != o.spmv_xcs_split ||
             pl.opt_idx32 != o.spmv_xcs_idx32 || pl.opt_tile != o.spmv_tile || pl.opt_sort != o.spmv_sort_tiles ||
             pl.opt_relabel != o.spmv_relabel || pl.opt_band != o.spmv_band || pl.opt_band_hot != o.spmv_band_hot ||
-            pl.opt_band_phases != o.spmv_band_phases || pl.opt_band_split != o.spmv_band_split || pl.opt_band_group != o.spmv_band_group + 100000 * o.spmv_band_hot_threads + 100000000 * o.spmv_band_short_group)
+            pl.opt_band_phases != o.spmv_band_phases || pl.opt_band_split != o.spmv_band_split || pl.opt_band_natural != o.spmv_band_natural ||
+            pl.opt_band_short != o.spmv_band_short || pl.opt_band_group != o.spmv_band_group + 100000 * o.spmv_band_hot_threads + 100000000 * o.spmv_band_short_group)
             SPRS_TRY((build_plan<IDX, PTR>(a, stream)));
         if (!pl.band) SPRS_TRY(get_scratch(pl, stream, &sc));
     }

@@ -291,6 +291,13 @@ __global__ __launch_bounds__(NTH) void band_hot_kernel(const BandPiece *__restri
 // Pieces start at multiples of 512 entries and are padded with zeros.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t ROW_START32 = 0x80000000u;
+// Cold ids in "natural" plans (option spmv_band_natural = 1, an experiment kept for A/B): an entry whose column is NOT one
+// of the hot labels keeps its ORIGINAL column and carries this flag — the cold kernel then gathers it from the caller's x,
+// and the per-SpMV permutation shrinks to the hot labels (a 12 us gather instead of a 10 M-element scatter).  Measured
+// SLOWER on R-MAT 10M, 1.32 against 1.12 ms per SpMV (profiles/r03i): in the natural order a cold x line mixes columns of
+// very different popularity, the cold kernel's gathers miss more (681 against 535 us) and take bandwidth from the hot
+// kernel beside them (1143 against 975 us) — the labelling pays for the scatter several times over.
+constexpr uint32_t NATURAL_ID = 0x40000000u;
 
 // how the cold kernel reads x: 0 plain, 1 non-temporal, 2 device-scope (served by L2, no L1 allocation)
 template <int POLICY>
@@ -304,8 +311,8 @@ template <bool ACC, int POLICY>
 __global__ __launch_bounds__(CNT) void band_cold_kernel(const BandPiece *__restrict__ pieces,
                                                         const ColdGroup *__restrict__ groups, uint32_t ngroups,
                                                         const double *__restrict__ vals, const uint32_t *__restrict__ cid,
-                                                        const double *__restrict__ xp, double *__restrict__ y,
-                                                        uint32_t block0) {
+                                                        const double *__restrict__ xp, const double *__restrict__ x,
+                                                        double *__restrict__ y, uint32_t block0) {
     constexpr int WPB = CNT / WAVE;
     __shared__ __attribute__((aligned(16))) double stage_s[WPB][WT];
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(CNT) void band_cold_kernel(const BandPiece *__restr
 #pragma unroll
     for (int q = 0; q < EPL; ++q) {
         const uint32_t c = lw[q / 4][q % 4];
-        xv[q] = gather_x<POLICY>(xp, c & ~ROW_START32);                  // padding: label 0, value 0, never summed into a row
+        xv[q] = gather_x<POLICY>((c & NATURAL_ID) ? x : xp, c & ~(ROW_START32 | NATURAL_ID));   // padding: label 0, value 0, never summed into a row
         fb |= (c >> 31) << q;
     }
     double pr[EPL];
@@ -577,7 +584,7 @@ __global__ void bp_fill_short_kernel(const PTR *__restrict__ indptr, const IDX *
                                      const uint64_t *__restrict__ long_pos, const uint32_t *__restrict__ perm,
                                      uint32_t *__restrict__ s_rowidx, uint32_t *__restrict__ s_ptr,
                                      uint32_t *__restrict__ s_cid, double *__restrict__ s_val,
-                                     uint32_t *__restrict__ long_rows, uint64_t split) {
+                                     uint32_t *__restrict__ long_rows, uint64_t split, uint32_t natural_from) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > rows) return;
     if (r == rows) {
@@ -601,7 +608,9 @@ __global__ void bp_fill_short_kernel(const PTR *__restrict__ indptr, const IDX *
         const uint64_t tile = d / WT;
         const uint32_t t = (uint32_t)(d % WT);
         const uint32_t ll = t / EPL, q = t % EPL;
-        s_cid[tile * WT + (q / 4) * (WAVE * 4) + ll * 4 + (q & 3u)] = perm[indices[p]] | (p == s ? ROW_START32 : 0u);
+        const uint32_t label = perm[indices[p]];
+        const uint32_t id = label >= natural_from ? (uint32_t)indices[p] | NATURAL_ID : label;   // natural_from = 0xFFFFFFFF: labels only
+        s_cid[tile * WT + (q / 4) * (WAVE * 4) + ll * 4 + (q & 3u)] = id | (p == s ? ROW_START32 : 0u);
         s_val[tile * WT + (q / 2) * (WAVE * 2) + ll * 2 + (q & 1u)] = data[p];
     }
 }
@@ -657,7 +666,8 @@ __global__ __launch_bounds__(256) void bp_scatter_kernel(const PTR *__restrict__
                                                          const uint64_t *__restrict__ pos,
                                                          const PieceBuild *__restrict__ pb,
                                                          double *__restrict__ vals_hot, uint16_t *__restrict__ cid_hot,
-                                                         double *__restrict__ vals_cold, uint32_t *__restrict__ cid_cold) {
+                                                         double *__restrict__ vals_cold, uint32_t *__restrict__ cid_cold,
+                                                         uint32_t natural_from) {
     __shared__ uint32_t fill[4][MAX_PIECES];       // entries of the row already placed, per piece
     const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -671,6 +681,7 @@ __global__ __launch_bounds__(256) void bp_scatter_kernel(const PTR *__restrict__
             const uint64_t p = p0 + lane;
             const bool valid = p < e;
             const uint32_t label = valid ? perm[indices[p]] : 0u;
+            const uint32_t natural = valid ? (uint32_t)indices[p] | NATURAL_ID : 0u;
             const double v = valid ? data[p] : 0.0;
             const uint32_t k = valid ? piece_of_label(map, label) : 0xFFFFFFFFu;
             // rank of the entry among the lanes of this batch that go to the same piece (lane order = row order)
@@ -705,7 +716,8 @@ __global__ __launch_bounds__(256) void bp_scatter_kernel(const PTR *__restrict__
                     const uint32_t i = (uint32_t)(e_rel % WT);
                     const uint32_t ll = i / EPL, q = i % EPL;
                     vals_cold[b.ent0 + tile * WT + (q / 2) * (WAVE * 2) + ll * 2 + (q & 1u)] = v;
-                    cid_cold[b.ent0 + tile * WT + (q / 4) * (WAVE * 4) + ll * 4 + (q & 3u)] = label | (before + rank == 0 ? ROW_START32 : 0u);
+                    cid_cold[b.ent0 + tile * WT + (q / 4) * (WAVE * 4) + ll * 4 + (q & 3u)] =
+                        (label >= natural_from ? natural : label) | (before + rank == 0 ? ROW_START32 : 0u);
                 }
             }
         }
@@ -814,6 +826,7 @@ struct BandPlan {
     uint32_t hot_threads = 1024, hot_block = 8192; // threads of a hot workgroup; entries it advances per iteration
     uint64_t cols = 0, cols_pad = 0;
     uint32_t *perm = nullptr, *long_rows = nullptr;
+    bool natural = false;                          // cold entries carry their original column (NATURAL_ID) and read the caller's x
     uint32_t *inv_hot = nullptr;                   // column of each hot label (0xFFFFFFFF: label not in use)
     uint32_t hot_labels = 0;                       // nh * 8192, at most cols_pad
     double *vals_hot = nullptr, *vals_cold = nullptr;
@@ -947,6 +960,9 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
                        cols, bp->hot_labels, bp->inv_hot);
     SPRS_TRY_HIP(hipGetLastError());
     bp->bytes += ((uint64_t)bp->hot_labels + 1) * 4;
+    // natural ids need bit 30 free, and the (opt-in) tiled short-rows launch reads labels only
+    bp->natural = o.spmv_band_natural == 1 && cols < (uint64_t)NATURAL_ID && o.spmv_band_short != 1 && bp->hot_labels != 0;
+    const uint32_t natural_from = bp->natural ? bp->hot_labels : 0xFFFFFFFFu;
 
     // ---- short piece + list of long rows ------------------------------------------------------
     // cold arrays: [short piece | cold pieces], every piece starting at a multiple of 4 entries
@@ -967,7 +983,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     SPRS_TRY_HIP(s_ptr_t.alloc((n_short_rows + 1) * 4));
     hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
                        a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)s_rowidx_t.p,
-                       (uint32_t *)s_ptr_t.p, (uint32_t *)nullptr, (double *)nullptr, bp->long_rows, split);
+                       (uint32_t *)s_ptr_t.p, (uint32_t *)nullptr, (double *)nullptr, bp->long_rows, split, 0xFFFFFFFFu);
     SPRS_TRY_HIP(hipGetLastError());
     uint64_t wblocks = (n_long + 3) / 4;
     if (wblocks > 256 * 64) wblocks = 256 * 64;
@@ -1061,7 +1077,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     // short piece: its entries go straight into place (piece 0 of the cold arrays), its row lists are copied
     hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
                        a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)nullptr,
-                       (uint32_t *)nullptr, bp->cid_cold, bp->vals_cold, bp->long_rows, split);
+                       (uint32_t *)nullptr, bp->cid_cold, bp->vals_cold, bp->long_rows, split, natural_from);
     SPRS_TRY_HIP(hipGetLastError());
     SPRS_TRY_HIP(hipMemcpyAsync(bp->ptr_all + ptr_off, s_ptr_t.p, (n_short_rows + 1) * 4, hipMemcpyDeviceToDevice, stream));
     if (n_short_rows)
@@ -1071,7 +1087,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     SPRS_TRY_HIP(hipMemcpyAsync(pb_d.p, pb.data(), NP * sizeof(PieceBuild), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL((bp_scatter_kernel<IDX, PTR>), dim3((unsigned)wblocks), dim3(256), 0, stream, ip, ix, a->data,
                        bp->long_rows, n_long, bp->perm, map, NP, pos.u64(), (const PieceBuild *)pb_d.p, bp->vals_hot,
-                       bp->cid_hot, bp->vals_cold, bp->cid_cold);
+                       bp->cid_hot, bp->vals_cold, bp->cid_cold, natural_from);
     SPRS_TRY_HIP(hipGetLastError());
     hipLaunchKernelGGL(bp_rows_kernel, dim3((unsigned)((flat + 255) / 256)), dim3(256), 0, stream, cnt.u64(), pos.u64(),
                        pair.u64(), n_long, NP, (const PieceBuild *)pb_d.p, bp->ptr_all, bp->rowidx_all);
@@ -1248,7 +1264,7 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     // gathered first (a few us), the hot kernel starts, and the scatter of the rest + the clearing of y go to the second
     // stream in front of the cold launch — 47 us less on the critical path.
     const bool overlap = options().spmv_band_overlap != 2 && bp->hot_wgs && bp->cold_blocks;
-    const bool split_permute = overlap && options().spmv_band_split_permute != 2 && bp->hot_labels;
+    const bool split_permute = bp->natural || (overlap && options().spmv_band_split_permute != 2 && bp->hot_labels);
     const uint64_t span = acc ? bp->cols : (bp->cols > a->rows ? bp->cols : a->rows);
     hipStream_t cstream = overlap ? sc->aux : stream;
     if (split_permute)
@@ -1262,7 +1278,10 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         SPRS_TRY_HIP(hipEventRecord(sc->fork, stream));           // the hot labels of xp (or all of it, and the cleared y) are ready
         SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux, sc->fork, 0));
     }
-    if (split_permute) {
+    if (bp->natural) {
+        // nothing else to permute: the cold entries read x itself; y is cleared for the empty rows and the direct writers
+        if (!acc) SPRS_TRY_HIP(hipMemsetAsync(y, 0, a->rows * sizeof(double), cstream));
+    } else if (split_permute) {
         hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, cstream, x,
                            (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, bp->hot_labels);
         SPRS_TRY_HIP(hipGetLastError());
@@ -1280,7 +1299,7 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
 #define SPRS_COLD(ACCV, POL)                                                                                              \
     hipLaunchKernelGGL((band_cold_kernel<ACCV, POL>), dim3(nb), dim3(CNT), 0, cstream, (const BandPiece *)sc->pieces,          \
                        (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,                             \
-                       (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, b0)
+                       (const uint32_t *)bp->cid_cold, (const double *)sc->xp, x, y, b0)
             const int64_t pol = options().spmv_band_gather;
             if (acc) {
                 if (pol == 1) SPRS_COLD(true, 1);
