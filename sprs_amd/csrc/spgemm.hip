@@ -455,7 +455,7 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
 //     issues its adds, waits for them to complete (s_waitcnt lgkmcnt(0)) and passes the token on.  Only the adds are
 //     serialised (a few instructions per batch); loads, searches and rank computations of all waves overlap.
 // No float atomics race anywhere (every accumulator sees its additions in the reference's order) => values bit-exact
-// and deterministic.  tests/test_spgemm_gpu.py compares bits with the oracle; the CPU emulator (tests/emu) runs the
+// and deterministic.  tests/test_spgemm_gpu.py compares bits with the CPU restatement of the reference; the CPU emulator (tests/emu) runs the
 // hand-over with the waves scheduled in reversed / rotated order.
 // ---------------------------------------------------------------------------
 
