@@ -790,7 +790,8 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                 q2 = q3;
                 if (w + 4 < nwin) q3 = w + 5 >= nwin ? re : edge(q2, re, (w + 5) << MID_WL);
             }
-            const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(has ? win_e - win_s : 0u), WAVE - 1);
+            const uint32_t winc = wave_incl_scan_u32(has ? win_e - win_s : 0u);
+            const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)winc, WAVE - 1);
             mark(1);
             if (wtotal == 0) continue;                                // wave-uniform: nothing of the row in this window
             // A window of more entries than the registers keep (the dense low columns of a power-law row) is taken bucket by
@@ -808,8 +809,8 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                 if (seg + 2 < nseg) seg_nxt = edge(we, win_e, wlo + 2 * (uint64_t)SEG_COLS);
             }
             const uint32_t len = has ? we - ws : 0u;
-            const uint32_t inc = wave_incl_scan_u32(len);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+            const uint32_t inc = nseg == 1 ? winc : wave_incl_scan_u32(len);
+            const uint32_t total = nseg == 1 ? wtotal : (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             if (total == 0) continue;                                 // wave-uniform
             kP[lane] = inc - len;                                     // lanes without a k: = total (the search never passes them)
             if (lane == WAVE - 1) kP[MID_K] = total;
@@ -828,11 +829,12 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                 bool valid[MID_KEEP];
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b) {
-                    const uint32_t tpos = (b0 + (uint32_t)b) * WAVE + lane;
-                    valid[b] = tpos < total;
+                    valid[b] = false;
                     own[b] = 0;
                     pos[b] = 0;
-                    if (b0 + (uint32_t)b < nb) {                      // wave-uniform
+                    if (b0 + (uint32_t)b < nb) {                      // wave-uniform: a batch that does not exist costs a branch
+                        const uint32_t tpos = (b0 + (uint32_t)b) * WAVE + lane;
+                        valid[b] = tpos < total;
                         if (nk <= 16) {
                             // few k's (most rows): count the k's that end at or before the position — scalar compares, no LDS
                             for (uint32_t j = 0; j + 1 < nk; ++j)
@@ -847,28 +849,37 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                 double bv[MID_KEEP];
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b) {
-                    cc[b] = valid[b] ? (uint32_t)((uint64_t)B.indices[pos[b]] - wlo) : 0u;
-                    bv[b] = valid[b] && with_value ? B.data[pos[b]] : 0.0;
+                    cc[b] = 0;
+                    bv[b] = 0.0;
+                    if (b0 + (uint32_t)b < nb) {                      // wave-uniform
+                        cc[b] = valid[b] ? (uint32_t)((uint64_t)B.indices[pos[b]] - wlo) : 0u;
+                        bv[b] = valid[b] && with_value ? B.data[pos[b]] : 0.0;
+                    }
                 }
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b) {
-                    kco[b] = valid[b] ? cc[b] | (own[b] << 16) : 0xFFFFFFFFu;
-                    kpr[b] = valid[b] && with_value ? kA[own[b]] * bv[b] : 0.0;
+                    kco[b] = 0xFFFFFFFFu;
+                    kpr[b] = 0.0;
+                    if (b0 + (uint32_t)b < nb) {                      // wave-uniform
+                        kco[b] = valid[b] ? cc[b] | (own[b] << 16) : 0xFFFFFFFFu;
+                        kpr[b] = valid[b] && with_value ? kA[own[b]] * bv[b] : 0.0;
+                    }
                 }
             };
-            auto set_bits = [&]() {
+            auto set_bits = [&](uint32_t b0) {
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b)
-                    if (kco[b] != 0xFFFFFFFFu) atomicOr(&bm32[(kco[b] & 0xFFFFu) >> 5], 1u << (kco[b] & 31));
+                    if (b0 + (uint32_t)b < nb)                        // wave-uniform
+                        if (kco[b] != 0xFFFFFFFFu) atomicOr(&bm32[(kco[b] & 0xFFFFu) >> 5], 1u << (kco[b] & 31));
             };
             // ---- bit pass ----
             if (keep) {
                 load_batches(0, true);
-                set_bits();
+                set_bits(0);
             } else {
                 for (uint32_t b0 = 0; b0 < nb; b0 += MID_KEEP) {
                     load_batches(b0, false);
-                    set_bits();
+                    set_bits(b0);
                 }
             }
             wave_sync_lds();
