@@ -95,6 +95,14 @@ def spgemm5(dev, idx_bytes, steps, warmup, check_rows, cpu_blocks, cpu_block_row
                      "algorithmic_bytes_per_launch": comp, "no_reuse_upper_bound_bytes": int(products * (8 + idx_bytes)),
                      "kernel_ms_avg": round(float(np.mean(ms)), 3), "kernel_ms_min": round(float(np.min(ms)), 3), "traffic": None},
     }
+    try:        # PMC traffic of the same product on exactly these kernel sources (scripts/spgemm_traffic.py), else null
+        sha = csrc_sha16()
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                if e["workload"] == "spgemm5" and e["index_bytes"] == idx_bytes and e.get("csrc_sha16") == sha:
+                    out["roofline"]["traffic"] = e["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     # ---- parity and CPU baseline on row blocks: the oracle is the checker and the timed CPU port, never the product -------
     from oracle import oracle
     npi = np.uint64 if idx_bytes == 8 else np.uint32

@@ -15,6 +15,7 @@
 #   spgemm_ab:<cfgs>      SpGEMM config 5 under option sets, separated by '|': e.g. "base|SPGEMM_RETAIN=0|SPGEMM_WINLOG=16 SPGEMM_OCCUPANCY=2"
 #   spmm_ab:<cfgs>        SpMM (k = 8, 16 on R-MAT 10M) under option sets, e.g. "base|SPMM_LONG_ROW=0"
 #   spgemm_pmc[:env]      SQ / TCC counter passes over SpGEMM config 5 (per kernel means) -> spgemm_pmc.txt
+#   spgemm_traffic        FETCH_SIZE / WRITE_SIZE pass over SpGEMM config 5 -> spgemm_traffic.txt (scripts/spgemm_traffic.py)
 #   spmm[:args]           SpMM on R-MAT 10M (scripts/spmm_bench.py [n nnz_per_row k ...]) + its kernel stats
 #   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
 TAG=${1:?tag}; shift
@@ -64,6 +65,12 @@ for step in "$@"; do
               echo "== group $i: $grp" | tee -a $OUT/spgemm_pmc.txt
               if [ -n "$f" ]; then python3 $ROOT/scripts/rocprof_summary.py "$f" sprs_hip | sed -n '/PMC counters/,$p' | grep -E "rows_kernel|PMC|kernel " | cut -c1-250 | tee -a $OUT/spgemm_pmc.txt; fi
             done ;;
+    spgemm_traffic) rm -rf /tmp/pt
+            python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print('csrc_sha16:', bench.csrc_sha16())" > $OUT/spgemm_traffic.txt
+            ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace -d /tmp/pt -o pmc -- python $ROOT/tests/spgemm_bench.py 1000000 8 8 1 > /dev/null 2>&1 )
+            f=$(find /tmp/pt -name "*.db" | head -1)
+            if [ -n "$f" ]; then python3 $ROOT/scripts/rocprof_summary.py "$f" sprs_hip | sed -n '/PMC counters/,$p' | cut -c1-250 >> $OUT/spgemm_traffic.txt; fi
+            python3 $ROOT/scripts/spgemm_traffic.py $OUT/spgemm_traffic.txt 2 | grep -E "read_bytes|write_bytes|traffic_bytes" ;;
     spmm)   timeout 600 python scripts/spmm_bench.py $arg 2>&1 | grep -E "^\{" | tee -a $OUT/spmm.jsonl
             ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spmm_bench.py ${arg:-10000000 32 16} > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|spmm" | cut -c1-200 | head -8 | tee -a $OUT/spmm_kernels.txt ;;
     py)     timeout 900 python $arg 2>&1 | grep -v amdgpu.ids | tee -a $OUT/py.log ;;

@@ -924,6 +924,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
     } else if (!strcmp(name, "spmm_long_row")) {
         if (value < -1) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmm_long_row must be >= -1");
         o.spmm_long_row = value;
+    } else if (!strcmp(name, "spgemm_tokens")) {
+        if (value != 1 && value != 2 && value != 4) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_tokens must be 1, 2 or 4");
+        o.spgemm_tokens = value;
     } else if (!strcmp(name, "spgemm_overlap")) {
         o.spgemm_overlap = value ? 1 : 0;
     } else if (!strcmp(name, "spgemm_midwin")) {
@@ -1031,6 +1034,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_mid")) *value = o.spgemm_mid;
     else if (!strcmp(name, "spgemm_midwin")) *value = o.spgemm_midwin;
     else if (!strcmp(name, "spgemm_overlap")) *value = o.spgemm_overlap;
+    else if (!strcmp(name, "spgemm_tokens")) *value = o.spgemm_tokens;
     else if (!strcmp(name, "spmm_long_row")) *value = o.spmm_long_row;
     else if (!strcmp(name, "spgemm_minwin")) *value = o.spgemm_minwin;
     else if (!strcmp(name, "spgemm_task_order")) *value = o.spgemm_task_order;

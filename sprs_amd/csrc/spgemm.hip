@@ -10,29 +10,26 @@
 // (smmp.rs:174-181, mul_acc.rs:28-30) — the same order as the reference, by a
 // single owner, so results are deterministic (no float atomics anywhere).
 //
-// Work decomposition: a TASK is (row i, column window w).
-//   * rows whose product count  ub_i = sum_{k in A_i} nnz(B_k)  is <= 512 are one
-//     task handled by ONE WAVE with an LDS hash table (keys + f64 accumulators): the
-//     products of the row are walked 64 at a time in the reference's order, keys inserted in
-//     parallel, products added through order tags; then a bitonic sort of the table in LDS.
-//     Rows of <= 64 products use 128-slot tables (32 waves per CU).
-//   * larger rows get one task per column window — 2^17 columns by default, narrowed down to
-//     2^13 for heavy rows so that a hub row becomes many tasks — handled by a 512-thread
-//     workgroup with an LDS BITMAP of the window: setting bits is the symbolic pass, a popcount
-//     prefix over the bitmap turns a column into its rank inside the (sorted!) output row, so
-//     indices come out sorted for free.  Values are accumulated in LDS, in passes of a few
-//     thousand outputs (superblock ranges of the window); within a pass the expansion is walked
-//     entry-parallel, 2048 products per chunk, and products that meet in one accumulator are
-//     added in position order through LDS order tags (see large_numeric_kernel).
-//   * a column-bucket table of B (entries of every row before each 2048-column boundary,
-//     built per call, 4 B per row per 2048 columns) replaces the binary searches that
-//     locate a row inside a window / superblock range.
-// Per-task counts are scanned (hand-written two-level prefix sum, scan.hip) into output
-// offsets; C.indptr falls out of the same scan.  Integer/LDS/HBM-bound: no MFMA.
-// History of what was measured (profiles/): per-row windows + LDS accumulators
-// 1.96 s -> 0.50 s on config 5; bucket table, LDS staging, prefetch -> 0.454 s (waves owning
-// column ranges, one k at a time); entry-parallel expansion with order tags -> 0.22 s.
-// SPGEMM_PROF (option spgemm_prof) prints the phase profile of the large-row numeric kernel.
+// Work decomposition (row_work_kernel classes every row by its product count ub_i = sum_{k in A_i} nnz(B_k) and its k's):
+//   * ub <= 512: ONE WAVE per row with an LDS hash table (keys + f64 accumulators): the products of the row are
+//     walked 64 at a time in the reference's order, keys inserted in parallel, products added through order tags;
+//     then a bitonic sort of the table in LDS.  Rows of <= 64 products use 128-slot tables (32 waves per CU).
+//   * <= 64 k's and ub <= spgemm_mid (65 536): ONE WAVE per row walking column windows of 2^14 with an LDS bitmap
+//     (mid_rows_kernel): no workgroup barrier anywhere, 20 independent waves per CU.
+//   * the rest: a 512-thread WORKGROUP per row (per narrower window for a heavy row) walking windows of 2^17 columns
+//     (large_rows_kernel).
+//   In both window kernels setting bits is the symbolic pass, a popcount prefix over the bitmap turns a column into its
+//   rank inside the (sorted!) output row — indices come out sorted for free — and the values are accumulated in LDS in
+//   passes, in the reference's order: one ds_add_f64 per k-run of a wave instruction, the LDS executes a wave's
+//   instructions in issue order, a token orders the waves of a workgroup (see "ORDER OF THE ADDITIONS" below).
+//   * a column-bucket table of B (entries of every row before each 2048-column boundary, built per plan, 4 B per row
+//     per 2048 columns) replaces the binary searches that locate a row inside a window / superblock range.
+// Per-task counts are scanned (hand-written two-level prefix sum, scan.hip) into output offsets; C.indptr falls out of
+// the same scan.  Integer / LDS / latency bound: no MFMA.
+// History of what was measured (profiles/): per-row windows + LDS accumulators 1.96 s -> 0.50 s on
+// config 5; bucket table, LDS staging, prefetch -> 0.454 s (waves owning column ranges, one k at a time); entry-parallel
+// expansion with order tags -> 0.22 s (round 1); row tasks, LDS-ordered adds, wave-per-row kernel -> 0.112 s (round 2).
+// Option spgemm_prof prints per-class / per-phase timings of the numeric kernels.
 #include "common.hpp"
 #include "scan.hpp"
 
@@ -635,6 +632,8 @@ __device__ __forceinline__ void token_wait(uint32_t *token, uint32_t turn) {
     if (turn == 0xFFFFFFFFu) return;       // timing experiments only (option spgemm_debug & 1): no ordering
     while (lds_load_u32(token) != turn) SPRS_POLL_PAUSE();
     asm volatile("" ::: "memory");
+    wave_sync_lds();      // (no instruction; in the CPU emulator, where the lanes of a wave run one after the other, it keeps lane 0
+                          // from passing the token on before its fellow lanes have seen their turn)
 }
 
 __device__ __forceinline__ void token_pass(uint32_t *token, uint32_t next) {
@@ -966,10 +965,13 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
     }
 }
 
-// ranks of the batch's columns (before the turn: only the adds are serialised), then the adds when the token arrives
+// ranks of the batch's columns (before the turn: only the adds are serialised), then the adds when the token arrives.
+// NTOK tokens instead of one: the accumulators are split by the low bits of their rank into NTOK independent sets (the
+// order only matters inside one accumulator), each with its own token chain — wave v + 1 adds into set 0 while wave v is
+// still busy with set 1: the hand-overs (a completed ds_add, a token write, the next wave's poll) overlap NTOK deep.
 __device__ __forceinline__ void batch_add(const Batch &bt, uint32_t U, const unsigned long long *bm, const uint16_t *sub,
                                           const uint32_t *super, uint32_t base_rank, double *acc, uint32_t *token, uint32_t turn,
-                                          bool lds_atomic) {
+                                          bool lds_atomic, uint32_t ntok) {
     uint32_t slot[LG_U];
 #pragma unroll
     for (int u = 0; u < LG_U; ++u) {
@@ -978,11 +980,16 @@ __device__ __forceinline__ void batch_add(const Batch &bt, uint32_t U, const uns
                                   (uint32_t)__popcll(bm[word] & ((1ull << (bt.cc[u] & 63)) - 1ull)) - base_rank
                             : 0u;
     }
-    token_wait(token, turn);
+    // (Finding the run boundaries BEFORE the turn — one cross-lane compare and a ballot per instruction, then scalar bit
+    // arithmetic and a predicated add per run inside the turn — was measured slower than the readlane / compare / ballot
+    // chain of add_runs: 0.1178 against 0.1151 s, profiles/r03s; 2 and 4 token chains: 0.116 / 0.118 s against 0.115 s.)
+    for (uint32_t tk = 0; tk < ntok; ++tk) {
+        token_wait(token + tk, turn);
 #pragma unroll
-    for (int u = 0; u < LG_U; ++u)
-        if ((uint32_t)u < U) add_runs(bt.val[u], bt.own[u], slot[u], bt.pr[u], acc, lds_atomic);
-    token_pass(token, turn + 1);           // (a real turn never is 0xFFFFFFFF: the token would have to wrap exactly there; see tok_base)
+        for (int u = 0; u < LG_U; ++u)
+            if ((uint32_t)u < U) add_runs(bt.val[u] && (slot[u] & (ntok - 1)) == tk, bt.own[u], slot[u], bt.pr[u], acc, lds_atomic);
+        token_pass(token + tk, turn + 1);       // (a real turn never is 0xFFFFFFFF: the token would have to wrap exactly there; see tok_base)
+    }
 }
 
 // value walk of one staged group restricted to a pass; returns the number of batches (the token advances by it)
@@ -991,14 +998,14 @@ __device__ __forceinline__ uint32_t walk_values(const IDX *__restrict__ b_indice
                                                 uint32_t gtot, const uint64_t *kS, const uint32_t *kP, const double *kA,
                                                 const unsigned long long *bm, const uint16_t *sub, const uint32_t *super,
                                                 uint32_t base_rank, double *acc, uint32_t *token, uint32_t tok_base,
-                                                bool lds_atomic) {
+                                                bool lds_atomic, uint32_t ntok) {
     const uint32_t wave = threadIdx.x / WAVE;
     const uint32_t U = batch_u(gtot);
     const uint32_t nbatch = (gtot + 64 * U - 1) / (64 * U);
     for (uint32_t b = wave; b < nbatch; b += LG_WAVES) {
         Batch bt;
         batch_load<K_CAP, true>(bt, b_indices, b_data, wlo, gtot, U, b, kS, kP, kA);
-        batch_add(bt, U, bm, sub, super, base_rank, acc, token, tok_base == 0xFFFFFFFFu ? tok_base : tok_base + b, lds_atomic);
+        batch_add(bt, U, bm, sub, super, base_rank, acc, token, tok_base == 0xFFFFFFFFu ? tok_base : tok_base + b, lds_atomic, ntok);
     }
     return nbatch;
 }
@@ -1038,7 +1045,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     __shared__ uint32_t kP[K_CAP + 1];
     __shared__ double kA[NUMERIC ? K_CAP : 1];
     __shared__ uint64_t wt[16];
-    __shared__ uint32_t token;
+    __shared__ uint32_t token[4];
     const uint32_t tid = threadIdx.x;
     const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x, xcd_chunk)];
     const uint64_t r = task_row[t];
@@ -1057,6 +1064,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const bool lds_atomic = (flags & 1u) != 0;
     const bool retain_ok = values && (flags & 2u) != 0;
     const bool no_order = (flags & 4u) != 0, no_emit = (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
+    const uint32_t ntok = 1u << ((flags >> 4) & 3u);                          // 1, 2 or 4 token chains (option spgemm_tokens)
     // a row whose k's fit one staged group: thread j keeps k_j, the bounds of B's row k_j and a_ik for the whole task
     const bool mine_k = one_group && tid < (uint32_t)(ae - as) && w_begin < w_end;
     uint64_t rk = 0, rs = 0, re = 0, cur = 0, nxt_e = 0;
@@ -1069,7 +1077,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
         cur = w_begin == 0 ? rs : first_ge(B, rk, rs, rs, re, w_begin << wl);
         nxt_e = w_begin + 1 >= nwin ? re : first_ge(B, rk, rs, cur, re, (w_begin + 1) << wl);
     }
-    if (tid == 0) token = 0;
+    if (tid < 4) token[tid] = 0;
     for (int i = tid; i < WORDS; i += LG_BLOCK) bm[i] = 0;
     lds_barrier();
     uint64_t out = 0;
@@ -1173,10 +1181,23 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             mark(3);
             // ---- values ---------------------------------------------------------------------------------
             // PASSES: the window's superblocks are cut greedily into ranges [pb, pe) of at most ACC_CAP outputs
-            uint32_t pb = 0;
+            // (for a row kept in registers, where my k leaves the NEXT pass is asked for one pass ahead: the bucket-table
+            // round trip runs under the walk of the current pass; passes are consecutive, so a pass starts where the
+            // previous one ended)
+            auto pass_end = [&](uint32_t from) {
+                uint32_t to = from + 1;
+                while (to < (uint32_t)nsb && super[to + 1] - super[from] <= (uint32_t)ACC_CAP) ++to;
+                return to;
+            };
+            uint32_t pb = 0, pe = values ? pass_end(0) : 0u;
+            const bool my_range = one_group && mine_k && we > ws;
+            uint64_t pass_s = ws, pass_e = ws;
+            if (values && my_range) pass_e = pe == (uint32_t)nsb ? we : first_ge(B, rk, rs, ws, we, wlo + (uint64_t)pe * (SUPER_WORDS * 64));
             while (values && pb < (uint32_t)nsb) {
-                uint32_t pe = pb + 1;
-                while (pe < (uint32_t)nsb && super[pe + 1] - super[pb] <= (uint32_t)ACC_CAP) ++pe;
+                const uint32_t pb_next = pe, pe_next = pb_next < (uint32_t)nsb ? pass_end(pb_next) : (uint32_t)nsb;
+                uint64_t pass_e_next = pass_e;
+                if (my_range && pb_next < (uint32_t)nsb)
+                    pass_e_next = pe_next == (uint32_t)nsb ? we : first_ge(B, rk, rs, pass_e, we, wlo + (uint64_t)pe_next * (SUPER_WORDS * 64));
                 const uint32_t base_rank = super[pb];
                 const uint32_t pass_out = super[pe] - base_rank;
                 if (pass_out) {                                  // block-uniform
@@ -1188,7 +1209,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                         lds_barrier();                           // the accumulators are clear before anybody adds
                         const uint32_t U = batch_u(k_total), wave = tid / WAVE;
                         const uint32_t nbatch = (k_total + 64 * U - 1) / (64 * U);
-                        if (wave < nbatch) batch_add(kept, U, bm, sub, super, base_rank, acc, &token, no_order ? 0xFFFFFFFFu : tok_base + wave, lds_atomic);
+                        if (wave < nbatch) batch_add(kept, U, bm, sub, super, base_rank, acc, token, no_order ? 0xFFFFFFFFu : tok_base + wave, lds_atomic, ntok);
                         tok_base += nbatch;
                     } else
                     for (uint64_t kc = as; kc < ae; kc += K_CAP) {
@@ -1198,18 +1219,13 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                             gtot = k_total;                      // kS / kP / kA as the bit pass left them
                             lds_barrier();                       // the accumulators are clear before anybody adds
                         } else if (one_group) {
-                            uint64_t s = ws, e = ws;
-                            if (mine_k && we > ws) {
-                                s = pb == 0 ? ws : first_ge(B, rk, rs, ws, we, plo);
-                                e = pe == (uint32_t)nsb ? we : first_ge(B, rk, rs, s, we, phi);
-                            }
-                            gtot = stage_compact<K_CAP>((uint32_t)(e - s), s, rav, kS, kP, kA, wt);
+                            gtot = stage_compact<K_CAP>(my_range ? (uint32_t)(pass_e - pass_s) : 0u, pass_s, rav, kS, kP, kA, wt);
                         } else {
                             gtot = stage_k_group<K_CAP>(A, B, kc, n, single ? wlo : plo, single ? whi : phi, single && nwin == 1,
                                                         kS, kP, kA, wt);
                         }
                         const uint32_t nb_ = walk_values<K_CAP>(B.indices, B.data, wlo, gtot, kS, kP, kA, bm, sub, super, base_rank, acc,
-                                                                &token, no_order ? 0xFFFFFFFFu : tok_base, lds_atomic);
+                                                                token, no_order ? 0xFFFFFFFFu : tok_base, lds_atomic, ntok);
                         tok_base += nb_;
                     }
                     lds_barrier();                               // every add has been performed
@@ -1217,7 +1233,10 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                     for (uint32_t i = tid; i < pass_out; i += LG_BLOCK) c_data[out + base_rank + i] = acc[i];
                     lds_barrier();                               // the next pass clears the accumulators
                 }
-                pb = pe;
+                pass_s = pass_e;
+                pass_e = pass_e_next;
+                pb = pb_next;
+                pe = pe_next;
             }
             out += wtot;
             for (int i = tid; i < words; i += LG_BLOCK) bm[i] = 0;
@@ -1538,7 +1557,8 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     }
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
-        const uint32_t flags = (options().spgemm_lds_atomic ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u) | ((uint32_t)options().spgemm_debug << 2);
+        const uint32_t flags = (options().spgemm_lds_atomic ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u) | ((uint32_t)options().spgemm_debug << 2) |
+                               ((options().spgemm_tokens >= 4 ? 2u : options().spgemm_tokens >= 2 ? 1u : 0u) << 4);
 #define SPRS_LG_NUM(WL, OCC)                                                                                         \
     hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, true, OCC>), g, blk, 0, stream, A, B, pl->b_cols,            \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
