@@ -929,6 +929,9 @@ int32_t sprs_hip_set_option(const char *name, int64_t value) {
         o.spgemm_tokens = value;
     } else if (!strcmp(name, "spgemm_overlap")) {
         o.spgemm_overlap = value ? 1 : 0;
+    } else if (!strcmp(name, "spgemm_midwin_sym")) {
+        if (value < 14 || value > 16) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_midwin_sym must be 14..16");
+        o.spgemm_midwin_sym = value;
     } else if (!strcmp(name, "spgemm_midwin")) {
         if (value < 13 || value > 14) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_midwin must be 13 or 14");
         o.spgemm_midwin = value;
@@ -1033,6 +1036,7 @@ int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     else if (!strcmp(name, "spgemm_occupancy")) *value = o.spgemm_occupancy;
     else if (!strcmp(name, "spgemm_mid")) *value = o.spgemm_mid;
     else if (!strcmp(name, "spgemm_midwin")) *value = o.spgemm_midwin;
+    else if (!strcmp(name, "spgemm_midwin_sym")) *value = o.spgemm_midwin_sym;
     else if (!strcmp(name, "spgemm_overlap")) *value = o.spgemm_overlap;
     else if (!strcmp(name, "spgemm_tokens")) *value = o.spgemm_tokens;
     else if (!strcmp(name, "spmm_long_row")) *value = o.spmm_long_row;

@@ -54,6 +54,7 @@ struct Options {
     int64_t spgemm_prof = 0;       // SpGEMM: print the time of the large-row numeric tasks by class and the longest ones (debug)
     int64_t spgemm_tokens = 1;     // SpGEMM: token chains of the workgroup kernel's ordered adds (accumulators split by rank mod n): 1, 2 or 4
     int64_t spgemm_overlap = 0;    // SpGEMM: wave kernels (hash rows, wave-per-row rows) on a second stream beside the large-row kernel
+    int64_t spgemm_midwin_sym = 16; // SpGEMM: log2 of the window of the wave-per-row COUNTING kernel (14..16)
     int64_t spgemm_midwin = 14;    // SpGEMM: log2 of the column window of the wave-per-row kernel (13 or 14)
     int64_t spgemm_mid = 65536;    // SpGEMM: rows of <= 64 k's and at most this many products run one wave per row (0: none)
     int64_t spgemm_debug = 0;      // SpGEMM TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
     };
     constexpr int MID_WORDS = 1 << (MID_WL - 6);      // bitmap words of a window; lane l takes words l, l + 64, ...
     constexpr int WPL = MID_WORDS / WAVE;             // words per lane (2^13 columns: 2, 2^14: 4, 2^15: 8)
-    static_assert(MID_WL >= 13 && MID_WL <= 14, "window of the wave-per-row kernel");   // (ranks must fit the 16-bit sub[])
+    static_assert(MID_WL >= 13 && (MID_WL <= 14 || (!NUMERIC && MID_WL <= 16)), "window of the wave-per-row kernel");   // (numeric: LDS / registers for 20 waves per CU; the counting kernel has no accumulators and takes 2^16)
     __shared__ unsigned long long bm_s[MID_WAVES][MID_WORDS];
     __shared__ uint16_t sub_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_WORDS : 1];
     __shared__ double acc_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_ACC : 1];
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             // bucket, 2048 columns at a time: its outputs then fit one pass of accumulators nearly always, instead of every
             // pass walking the whole window again (first version: 74 of 152 s of wave time, profiles/r02y).
             constexpr uint32_t SEG_COLS = 1u << BUCKET_LOG2;
-            const uint32_t nseg = wtotal > (uint32_t)(WAVE * MID_KEEP) ? (1u << (MID_WL - BUCKET_LOG2)) : 1u;
+            const uint32_t nseg = NUMERIC && wtotal > (uint32_t)(WAVE * MID_KEEP) ? (1u << (MID_WL - BUCKET_LOG2)) : 1u;   // (counting needs no passes)
             uint32_t seg_s = win_s, seg_nxt = win_e;
             if (nseg > 1 && has) seg_nxt = edge(win_s, win_e, win_lo + SEG_COLS);
             for (uint32_t seg = 0; seg < nseg; ++seg) {
@@ -1513,10 +1513,10 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
                        pl->counters.as<unsigned int>())
         SPRS_TRY_HIP(pl->counters.alloc(64));
         SPRS_TRY_HIP(hipMemsetAsync(pl->counters.p, 0, 64, wstream));
-        switch (pl->midwin) {
-            case 13: SPRS_MID_SYM(13); break;
-            default: SPRS_MID_SYM(14); break;
-        }
+        // the counting kernel has no accumulators: windows of 2^16 columns (four times fewer window prologues per row)
+        if (options().spgemm_midwin_sym == 16) SPRS_MID_SYM(16);
+        else if (options().spgemm_midwin_sym == 15) SPRS_MID_SYM(15);
+        else SPRS_MID_SYM(14);
 #undef SPRS_MID_SYM
         SPRS_TRY_HIP(hipGetLastError());
     }
