@@ -244,6 +244,61 @@ def test_order_of_additions_stress(hip):
                     hip.set_option("spgemm_lds_atomic", 1)
 
 
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_row_class_boundaries(hip, idx, ptr):
+    """Rows sitting exactly on the thresholds that route them (row_work_kernel): 64 / 65 and 512 / 513 products (hash
+    tables), 64 / 65 k's and `spgemm_mid` products (wave-per-row vs workgroup kernel), `spgemm_heavy` (one task per
+    window), with B wider than one 2^17-column window and columns on the window / bucket edges, empty rows of B among the
+    k's, for every index type."""
+    rng = np.random.default_rng(5)
+    cols = (1 << 17) * 2 + 4321
+    n_b = 200
+    b_lens = [0, 1, 2, 63, 64, 65, 511, 512, 513] + [int(v) for v in rng.integers(0, 700, size=n_b - 9)]
+    b_lens[20] = 0
+    B = ragged_csr(b_lens, cols, seed=21, idx=idx, ptr=ptr, positive=False)
+    # put entries exactly on window / bucket edges into a few rows of B
+    shape, bip, bix, bdt = B
+    edges = np.array([0, 2047, 2048, (1 << 14) - 1, 1 << 14, (1 << 16), (1 << 17) - 1, 1 << 17, (1 << 18) - 1, 1 << 18, cols - 1], dtype=np.int64)
+    for r in (30, 31, 32):
+        s0, e0 = int(bip[r]), int(bip[r + 1])
+        if e0 - s0 >= edges.size:
+            seg = np.array(sorted(set(edges.tolist() + bix[s0:e0].astype(np.int64).tolist())))[: e0 - s0]
+            # keep the row length: take the edges and fill with the smallest other columns
+            seg = np.array(sorted(set(edges.tolist()) | set(seg.tolist())))[: e0 - s0] if seg.size >= e0 - s0 else seg
+            if seg.size == e0 - s0:
+                bix[s0:e0] = np.sort(seg).astype(idx)
+    B = (shape, bip, bix, bdt)
+    lens = np.diff(bip.astype(np.int64))
+
+    def row_with(products_at_least, n_k):
+        ks = np.sort(rng.choice(n_b, size=n_k, replace=False))
+        return ks
+
+    a_rows = []
+    # k counts around 64, products small and large
+    for n_k in (1, 2, 63, 64, 65, 100, 199):
+        a_rows.append(row_with(0, n_k))
+    # single k's of exactly 64 / 65 / 512 / 513 entries: the hash-table thresholds
+    for k in (4, 5, 7, 8, 20):
+        a_rows.append(np.array([k]))
+    a_rows.append(np.array([], dtype=np.int64))
+    a_ip = np.zeros(len(a_rows) + 1, dtype=np.int64)
+    a_ip[1:] = np.cumsum([r.size for r in a_rows])
+    a_ix = np.concatenate(a_rows) if a_rows else np.zeros(0, dtype=np.int64)
+    a_dt = rng.standard_normal(a_ix.size) * 10.0 ** rng.integers(-4, 5, size=a_ix.size)
+    A = ((len(a_rows), n_b), a_ip.astype(ptr), a_ix.astype(idx), a_dt)
+    ub = [int(lens[r].sum()) for r in a_rows]
+    assert 64 in ub and 65 in ub and 512 in ub and 513 in ub
+    for mid, heavy in ((65536, 131072), (max(ub[3] - 1, 513), 131072), (ub[3], 1024), (0, 2048)):
+        hip.set_option("spgemm_mid", mid)
+        hip.set_option("spgemm_heavy", heavy)
+        try:
+            check_against_oracle(A, B, exact_values=True)
+        finally:
+            hip.set_option("spgemm_mid", 65536)
+            hip.set_option("spgemm_heavy", 131072)
+
+
 _DENSE_CASE = []
 
 
