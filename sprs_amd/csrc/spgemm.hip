@@ -1050,7 +1050,9 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x, xcd_chunk)];
     const uint64_t r = task_row[t];
     const uint64_t jt = t - first_task[r], nt = ntasks[r];
-    const uint32_t wl = wlog[r];                             // window width of this row: 2^WL, narrower for heavy rows
+    // window width of this row: what row_work_kernel chose (2^winlog, narrower for heavy rows: their tasks ARE windows);
+    // the counting kernel is launched in a wider layout (no accumulators) and walks a one-task row in its own, wider windows
+    const uint32_t wl = (!NUMERIC && nt == 1) ? (uint32_t)WL : (uint32_t)wlog[r];
     const uint64_t W = 1ull << wl;
     uint64_t nwin = (b_cols + W - 1) >> wl;
     if (nwin == 0) nwin = 1;
@@ -1473,11 +1475,11 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
                        pl->ntasks.as<uint64_t>(), (const uint8_t *)pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, \
                        (double *)nullptr, pl->xcd_chunk, 0u, (unsigned long long *)nullptr, (const uint64_t *)nullptr)
-        switch (pl->winlog) {
-            case 16: SPRS_LG_SYM(16); break;
-            case 18: SPRS_LG_SYM(18); break;
+        switch (pl->winlog) {                    // (counting: one layout wider than the numeric kernel's)
+            case 16: SPRS_LG_SYM(17); break;
+            case 18: SPRS_LG_SYM(19); break;
             case 19: SPRS_LG_SYM(19); break;
-            default: SPRS_LG_SYM(17); break;
+            default: SPRS_LG_SYM(18); break;
         }
 #undef SPRS_LG_SYM
         SPRS_TRY_HIP(hipGetLastError());
