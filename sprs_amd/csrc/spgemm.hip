@@ -796,8 +796,11 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             // A window of more entries than the registers keep (the dense low columns of a power-law row) is taken bucket by
             // bucket, 2048 columns at a time: its outputs then fit one pass of accumulators nearly always, instead of every
             // pass walking the whole window again (first version: 74 of 152 s of wave time, profiles/r02y).
-            constexpr uint32_t SEG_COLS = 1u << BUCKET_LOG2;
-            const uint32_t nseg = NUMERIC && wtotal > (uint32_t)(WAVE * MID_KEEP) ? (1u << (MID_WL - BUCKET_LOG2)) : 1u;   // (counting needs no passes)
+            // 1, 2, 4 or 8 segments of whole buckets, about 500 entries each or fewer (a segment of more outputs than
+            // accumulators is walked once per pass: rare, and bounded by the bucket)
+            const uint32_t nseg = !NUMERIC || wtotal <= (uint32_t)MID_ACC ? 1u : wtotal <= 2u * MID_ACC ? 2u : wtotal <= 4u * MID_ACC ? 4u
+                                                                                                          : (1u << (MID_WL - BUCKET_LOG2));
+            const uint32_t SEG_COLS = (1u << MID_WL) / nseg;
             uint32_t seg_s = win_s, seg_nxt = win_e;
             if (nseg > 1 && has) seg_nxt = edge(win_s, win_e, win_lo + SEG_COLS);
             for (uint32_t seg = 0; seg < nseg; ++seg) {
