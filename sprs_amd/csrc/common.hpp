@@ -62,7 +62,7 @@ struct Options {
     int64_t spgemm_retain = 1;     // SpGEMM: windows of few entries keep them in registers from the bit pass to the adds (A/B)
     int64_t spgemm_lds_atomic = 1; // SpGEMM: value adds as ds_add_f64 (1) or read / add / write (0); same order either way (A/B)
     int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)
-    int64_t spgemm_minwin = 13;    // SpGEMM: (no longer used: heavy rows are cut into runs of whole windows)
+    int64_t spgemm_minwin = 13;    // SpGEMM: log2 of the narrowest column window of a heavy row (11..16)
     int64_t spgemm_heavy = 131072;    // SpGEMM: a row of more products is cut into one task per (narrower) column window, about this many products each
     int64_t pool = 1;              // keep released result blocks (>= 1 MiB) for the next result instead of hipFree
     int64_t pool_max_bytes = 128ll << 30;   // cap on the bytes the pool may hold

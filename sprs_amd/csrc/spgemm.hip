@@ -155,7 +155,7 @@ __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 3
 // ---------------------------------------------------------------------------
 template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
-                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t wl, uint64_t mid_max,
+                                                       uint64_t b_cols, uint64_t heavy_products, uint32_t wl, uint32_t min_wl, uint64_t mid_max,
                                                        uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks,
                                                        uint8_t *__restrict__ cls, uint8_t *__restrict__ wlog) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
                 // it is not one serial chain at the end of the launch (its window 0 still is the longest task)
                 uint64_t width = b_cols / (acc / heavy_products);
                 wl_r = width <= 1 ? 0 : 63 - __clzll((long long)width);       // floor(log2)
-                if (wl_r < 13) wl_r = 13;
+                if (wl_r < min_wl) wl_r = min_wl;
                 if (wl_r > wl) wl_r = wl;
                 nt = (b_cols + (1ull << wl_r) - 1) >> wl_r;
                 if (nt == 0) nt = 1;
@@ -1420,7 +1420,8 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
-                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint64_t)options().spgemm_mid,
+                           (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint32_t)options().spgemm_minwin,
+                           (uint64_t)options().spgemm_mid,
                            pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), cls.as<uint8_t>(), pl->wlog.as<uint8_t>());
         SPRS_TRY_HIP(hipGetLastError());
         hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, (const uint8_t *)cls.as<uint8_t>(), pl->ntasks.as<uint64_t>(), rows,
