@@ -530,7 +530,7 @@ int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m) {
     clear_error();
     if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
     SPRS_TRY_HIP(hipDeviceSynchronize());     // nothing in flight may still read the plan copies
-    std::lock_guard<std::mutex> lock(m->mu);
+    std::lock_guard<std::recursive_mutex> lock(m->mu);
     m->plan.release();
     m->mm.release();
     return SPRS_HIP_OK;
@@ -540,7 +540,7 @@ int32_t sprs_hip_csmat_spmv_plan_info(const sprs_hip_csmat *m, int32_t *kind, ui
     clear_error();
     if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
     auto *mm = const_cast<sprs_hip_csmat *>(m);
-    std::lock_guard<std::mutex> lock(mm->mu);
+    std::lock_guard<std::recursive_mutex> lock(mm->mu);
     const SpmvPlan &pl = m->plan;
     int32_t k = 0;
     uint64_t bytes = 0;
@@ -684,7 +684,7 @@ int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b
     if (!a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     SPRS_TRY(spgemm_contract(a, b));
     SPRS_TRY(numeric_target_ok(a, b, c));
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
     c->mm.release();
     return spgemm_numeric(a, b, c);
@@ -728,7 +728,7 @@ int32_t sprs_hip_spgemm_plan_numeric(sprs_hip_spgemm_plan *plan, const sprs_hip_
     clear_error();
     if (!plan || !a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     SPRS_TRY(numeric_target_ok(a, b, c));
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
     c->mm.release();
     return spgemm_plan_numeric(plan, a, b, c);

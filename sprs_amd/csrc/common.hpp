@@ -160,7 +160,7 @@ struct sprs_hip_csmat {
     bool owns = false;
     uint64_t cap_indices = 0, cap_data = 0;   // bytes of the owned blocks (>= what nnz needs: blocks come from the pool)
     int device = 0;
-    std::mutex mu;             // guards plan
+    std::recursive_mutex mu;   // guards plan / mm: held from the look-up (or rebuild) of a plan until the kernels that read it are launched
     sprs_hip::SpmvPlan plan;
     sprs_hip::SpmmPlan mm;
 

@@ -288,8 +288,8 @@ template <typename IDX, typename PTR>
 int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, double *out, uint64_t ld_out,
                   bool acc, hipStream_t stream) {
     double *partial = nullptr;
+    std::lock_guard<std::recursive_mutex> lock(a->mu);   // held until the kernels that read the plan are launched
     {
-        std::lock_guard<std::mutex> lock(a->mu);
         const uint64_t want_long = options().spmm_long_row >= 0 ? (uint64_t)options().spmm_long_row : LONG_ROW;
         if (!a->mm.built || a->mm.long_row != want_long) SPRS_TRY(build_spmm_plan<PTR>(a, stream));
         SpmmPlan &pl = a->mm;

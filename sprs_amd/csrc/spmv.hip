@@ -728,8 +728,10 @@ template <typename IDX, typename PTR>
 static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool acc, hipStream_t stream) {
     const Options &o = options();
     SpmvScratch *sc = nullptr;
+    // The handle's lock is held until the kernels are launched: another host thread that changes an option (plan rebuild),
+    // refreshes or frees the handle cannot pull the plan away between its look-up and the launches that read it.
+    std::lock_guard<std::recursive_mutex> lock(a->mu);
     {
-        std::lock_guard<std::mutex> lock(a->mu);
         SpmvPlan &pl = a->plan;
         if (!pl.built || pl.opt_xcs != o.spmv_xcs || pl.opt_split != o.spmv_xcs_split ||
             pl.opt_idx32 != o.spmv_xcs_idx32 || pl.opt_tile != o.spmv_tile || pl.opt_sort != o.spmv_sort_tiles ||

@@ -1252,7 +1252,7 @@ uint64_t band_plan_bytes(const BandPlan *bp) { return bp ? bp->bytes : 0; }
 int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, bool acc, hipStream_t stream) {
     BandScratch *sc = nullptr;
     {
-        std::lock_guard<std::mutex> lock(a->mu);
+        std::lock_guard<std::recursive_mutex> lock(a->mu);
         SPRS_TRY(band_scratch(bp, stream, &sc));
     }
     // x into the plan's labelling; the same launch clears y (empty rows; the others are overwritten) unless accumulating.
