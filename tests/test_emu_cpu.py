@@ -30,3 +30,12 @@ def test_spgemm_kernels_under_wave_orders(emu_lib, order):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_spgemm_gpu.py"), "-x", "-q", "-m", "gpu",
                         "-k", sel, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_spmv_band_kernels_in_the_emulator(emu_lib):
+    """the banded SpMV plan (hot slices from an LDS tile, cold pieces, split permutation, carries, reduction) and its plan
+    build, on the small matrices of tests/test_spmv_band_gpu.py"""
+    env = dict(os.environ, SPRS_HIP_LIBRARY=emu_lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_spmv_band_gpu.py"), "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
