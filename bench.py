@@ -174,7 +174,6 @@ def main():
     ap.add_argument("--tile", type=int, default=None, help="nnz per workgroup tile: 2048 or 4096")
     ap.add_argument("--relabel", type=int, default=None, help="sliced plan column relabelling: 0 auto, 1 on, 2 off")
     ap.add_argument("--ldspad", type=int, default=None, help="extra dynamic LDS per workgroup (occupancy cap, tuning)")
-    ap.add_argument("--xmask", type=int, default=None, help="timing experiment only: gather x[col & mask]")
     ap.add_argument("--band", type=int, default=None, help="banded plan (hot columns from LDS): 0 auto, 1 on, 2 off")
     ap.add_argument("--cold-cache", action="store_true",
                     help="stream a 1 GiB scratch buffer between steps (outside the per-step kernel events): the matrix and x "
@@ -204,7 +203,7 @@ def main():
     from sprs_amd import _ffi
     import ctypes as C
     _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
-    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_relabel", args.relabel), ("spmv_lds_pad", args.ldspad), ("spmv_xmask", args.xmask), ("spmv_band", args.band)):
+    for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_relabel", args.relabel), ("spmv_lds_pad", args.ldspad), ("spmv_band", args.band)):
         if val is not None:
             sprs_amd.set_option(opt, val)
 
@@ -354,7 +353,7 @@ def main():
     # counter passes of the same command (scripts/gpu_pmc.sh -> profiles/pmc_traffic.json) and is
     # only filled in when workload, index width and options match that run.
     traffic = None
-    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.sort, args.tile, args.ldspad, args.xmask, args.relabel, args.band)) and not args.permute_cols
+    defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.sort, args.tile, args.ldspad, args.relabel, args.band)) and not args.permute_cols
     try:
         if world == 1 and defaults and not args.cold_cache:
             sha = csrc_sha16()

@@ -20,8 +20,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-DEFAULTS = dict(spmv_kernel=0, spmv_xcs=0, spmv_xcs_split=32, spmv_xcs_idx32=1, spmv_sort_tiles=0, spmv_relabel=0,
-                spmv_tile=0, spmv_band=0, spmv_band_hot=0, spmv_band_phases=0, spmv_band_group=0, spmv_band_split_launch=0, spmv_band_hot_threads=0, spmv_band_gather=0, spmv_band_overlap=0, spmv_band_short=0, spmv_band_short_group=0, spmv_xmask=-1, spmv_band_split=0, spmv_band_split_permute=0, spmv_band_natural=0)
+DEFAULTS = {}   # option -> library default, read from the library for every option the configurations name
 
 
 def main():
@@ -57,6 +56,9 @@ def main():
     stream = torch.cuda.current_stream()
     alg = nnz * (8 + args.idx_bytes) + (n + 1) * args.idx_bytes + 2 * n * 8
     first = None
+    for spec in args.configs:
+        for kv in filter(None, spec.partition(":")[2].split(",")):
+            DEFAULTS.setdefault(kv.split("=")[0], sprs_amd.get_option(kv.split("=")[0]))
     for spec in args.configs:
         name, _, rest = spec.partition(":")
         opts = dict(DEFAULTS)

@@ -894,175 +894,58 @@ int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const 
     return triplets_to_cs(rows, cols, n, row_inds_dev, col_inds_dev, in_idx_bytes, data_dev, storage, out_idx_bytes, out_iptr_bytes, out);
 }
 
+namespace {
+struct OptionDesc {
+    const char *name;
+    int64_t sprs_hip::Options::*field;
+    int64_t lo, hi;
+    bool devtools;
+};
+const OptionDesc kOptions[] = {
+#define SPRS_X(name, def, lo, hi, dev) {#name, &sprs_hip::Options::name, (int64_t)(lo), (int64_t)(hi), (dev) != 0},
+    SPRS_HIP_OPTIONS(SPRS_X)
+#undef SPRS_X
+};
+const OptionDesc *find_option(const char *name) {
+    for (const OptionDesc &d : kOptions)
+        if (!strcmp(name, d.name)) return &d;
+    return nullptr;
+}
+}  // namespace
+
 int32_t sprs_hip_set_option(const char *name, int64_t value) {
     clear_error();
     if (!name) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL name");
-    Options &o = options();
-    if (!strcmp(name, "spmv_kernel")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_kernel must be 0, 1 or 2");
-        o.spmv_kernel = value;
-    } else if (!strcmp(name, "spmv_xcs")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_xcs must be 0 (auto), 1 (on) or 2 (off)");
-        o.spmv_xcs = value;
-    } else if (!strcmp(name, "spmv_xcs_split")) {
-        if (value < 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_xcs_split must be >= 2");
-        o.spmv_xcs_split = value;
-    } else if (!strcmp(name, "spmv_xcs_idx32")) {
-        o.spmv_xcs_idx32 = value ? 1 : 0;
-    } else if (!strcmp(name, "spmv_relabel")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_relabel must be 0 (auto), 1 (on) or 2 (off)");
-        o.spmv_relabel = value;
-    } else if (!strcmp(name, "spmv_sort_tiles")) {
-        o.spmv_sort_tiles = value ? 1 : 0;
-    } else if (!strcmp(name, "spmv_tile")) {
-        if (value != 0 && value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 0 (auto), 2048 or 4096");
-        o.spmv_tile = value;
-    } else if (!strcmp(name, "spgemm_bucket")) {
-        o.spgemm_bucket = value ? 1 : 0;
-    } else if (!strcmp(name, "spgemm_prof")) {
-        o.spgemm_prof = value ? 1 : 0;
-    } else if (!strcmp(name, "spmm_long_row")) {
-        if (value < -1) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmm_long_row must be >= -1");
-        o.spmm_long_row = value;
-    } else if (!strcmp(name, "spgemm_tokens")) {
-        if (value != 1 && value != 2 && value != 4) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_tokens must be 1, 2 or 4");
-        o.spgemm_tokens = value;
-    } else if (!strcmp(name, "spgemm_overlap")) {
-        o.spgemm_overlap = value ? 1 : 0;
-    } else if (!strcmp(name, "spgemm_midwin_sym")) {
-        if (value < 14 || value > 16) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_midwin_sym must be 14..16");
-        o.spgemm_midwin_sym = value;
-    } else if (!strcmp(name, "spgemm_midwin")) {
-        if (value < 13 || value > 14) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_midwin must be 13 or 14");
-        o.spgemm_midwin = value;
-    } else if (!strcmp(name, "spgemm_mid")) {
-        if (value < 0 || value > (1ll << 31)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_mid must be 0 .. 2^31");
-        o.spgemm_mid = value;
-    } else if (!strcmp(name, "spgemm_debug")) {
-        o.spgemm_debug = value & 3;
-    } else if (!strcmp(name, "spgemm_occupancy")) {
-        if (value != 2 && value != 3) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_occupancy must be 2 or 3");
-        o.spgemm_occupancy = value;
-    } else if (!strcmp(name, "spgemm_retain")) {
-        o.spgemm_retain = value ? 1 : 0;
-    } else if (!strcmp(name, "spgemm_lds_atomic")) {
-        o.spgemm_lds_atomic = value ? 1 : 0;
-    } else if (!strcmp(name, "spgemm_winlog")) {
-        if (value < 16 || value > 19) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_winlog must be 16..19");
-        o.spgemm_winlog = value;
-    } else if (!strcmp(name, "pool")) {
-        o.pool = value ? 1 : 0;
-        if (!value) (void)pool_trim();
-    } else if (!strcmp(name, "pool_max_bytes")) {
-        if (value < 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "pool_max_bytes must be >= 0");
-        o.pool_max_bytes = value;
-    } else if (!strcmp(name, "spgemm_xcd_chunk")) {
-        if (value < -1 || value > 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_xcd_chunk must be 0 (round-robin) or -1 (one run per XCD)");
-        o.spgemm_xcd_chunk = value;
-    } else if (!strcmp(name, "spgemm_task_order")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_task_order must be 0, 1 or 2");
-        o.spgemm_task_order = value;
-    } else if (!strcmp(name, "spgemm_minwin")) {
-        if (value < 11 || value > 16) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_minwin must be 11..16");
-        o.spgemm_minwin = value;
-    } else if (!strcmp(name, "spgemm_heavy")) {
-        if (value < 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_heavy must be >= 1024");
-        o.spgemm_heavy = value;
-    } else if (!strcmp(name, "spmv_lds_pad")) {
-        if (value < 0 || value > 100000) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_lds_pad must be in 0..100000");
-        o.spmv_lds_pad = value;
-    } else if (!strcmp(name, "spmv_xmask")) {
-        o.spmv_xmask = value;
-    } else if (!strcmp(name, "spmv_band")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band must be 0 (auto), 1 (on) or 2 (off)");
-        o.spmv_band = value;
-    } else if (!strcmp(name, "spmv_band_hot")) {
-        if (value < 0 || value > 384) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_hot must be in 0..384");
-        o.spmv_band_hot = value;
-    } else if (!strcmp(name, "spmv_band_phases")) {
-        if (value < 0 || value > 8) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_phases must be in 0..8");
-        o.spmv_band_phases = value;
-    } else if (!strcmp(name, "spmv_band_hot_threads")) {
-        if (value != 0 && value != 512 && value != 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_hot_threads must be 0, 512 or 1024");
-        o.spmv_band_hot_threads = value;
-    } else if (!strcmp(name, "spmv_band_gather")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_gather must be 0, 1 or 2");
-        o.spmv_band_gather = value;
-    } else if (!strcmp(name, "spmv_band_overlap")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_overlap must be 0, 1 or 2");
-        o.spmv_band_overlap = value;
-    } else if (!strcmp(name, "spmv_band_natural")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_natural must be 0, 1 or 2");
-        o.spmv_band_natural = value;
-    } else if (!strcmp(name, "spmv_band_split_permute")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_split_permute must be 0, 1 or 2");
-        o.spmv_band_split_permute = value;
-    } else if (!strcmp(name, "spmv_band_short")) {
-        if (value < 0 || value > 2) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_short must be 0, 1 or 2");
-        o.spmv_band_short = value;
-    } else if (!strcmp(name, "spmv_band_short_group")) {
-        if (value < 0 || value > 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_short_group must be in 0..1024");
-        o.spmv_band_short_group = value;
-    } else if (!strcmp(name, "spmv_band_split")) {
-        if (value < 0 || value == 1) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_split must be 0 (default) or >= 2");
-        o.spmv_band_split = value;
-    } else if (!strcmp(name, "spmv_band_split_launch")) {
-        o.spmv_band_split_launch = value ? 1 : 0;
-    } else if (!strcmp(name, "spmv_band_group")) {
-        if (value < 0 || value > 1024) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_group must be in 0..1024");
-        o.spmv_band_group = value;
-    } else {
-        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
-    }
+    const OptionDesc *d = find_option(name);
+    if (!d) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
+    if (d->devtools && !DEVTOOLS)
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "option '%s' is a developer switch (wrong results / profiling printouts): this library was built without SPRS_HIP_DEVTOOLS", name);
+    if (value < d->lo || value > d->hi)
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "%s must be in %lld .. %lld", name, (long long)d->lo, (long long)d->hi);
+    // the few options whose legal values are not a range
+    if (!strcmp(name, "spmv_tile") && value != 0 && value != 2048 && value != 4096) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_tile must be 0 (auto), 2048 or 4096");
+    if (!strcmp(name, "spmv_band_tile") && value != 0 && value != 8192 && value != 16384) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_tile must be 0 (default), 8192 or 16384");
+    if (!strcmp(name, "spgemm_tokens") && value == 3) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spgemm_tokens must be 1, 2 or 4");
+    if (!strcmp(name, "spmv_band_split") && value == 1) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "spmv_band_split must be 0 (default) or >= 2");
+    options().*(d->field) = value;
+    if (!strcmp(name, "pool") && !value) (void)pool_trim();
     return SPRS_HIP_OK;
 }
 
 int32_t sprs_hip_get_option(const char *name, int64_t *value) {
     clear_error();
     if (!name || !value) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
-    Options &o = options();
-    if (!strcmp(name, "spmv_kernel")) *value = o.spmv_kernel;
-    else if (!strcmp(name, "spmv_xcs")) *value = o.spmv_xcs;
-    else if (!strcmp(name, "spmv_xcs_split")) *value = o.spmv_xcs_split;
-    else if (!strcmp(name, "spmv_xcs_idx32")) *value = o.spmv_xcs_idx32;
-    else if (!strcmp(name, "spmv_sort_tiles")) *value = o.spmv_sort_tiles;
-    else if (!strcmp(name, "spmv_relabel")) *value = o.spmv_relabel;
-    else if (!strcmp(name, "spmv_tile")) *value = o.spmv_tile;
-    else if (!strcmp(name, "spgemm_bucket")) *value = o.spgemm_bucket;
-    else if (!strcmp(name, "spgemm_prof")) *value = o.spgemm_prof;
-    else if (!strcmp(name, "spgemm_heavy")) *value = o.spgemm_heavy;
-    else if (!strcmp(name, "spgemm_lds_atomic")) *value = o.spgemm_lds_atomic;
-    else if (!strcmp(name, "spgemm_retain")) *value = o.spgemm_retain;
-    else if (!strcmp(name, "spgemm_occupancy")) *value = o.spgemm_occupancy;
-    else if (!strcmp(name, "spgemm_mid")) *value = o.spgemm_mid;
-    else if (!strcmp(name, "spgemm_midwin")) *value = o.spgemm_midwin;
-    else if (!strcmp(name, "spgemm_midwin_sym")) *value = o.spgemm_midwin_sym;
-    else if (!strcmp(name, "spgemm_overlap")) *value = o.spgemm_overlap;
-    else if (!strcmp(name, "spgemm_tokens")) *value = o.spgemm_tokens;
-    else if (!strcmp(name, "spmm_long_row")) *value = o.spmm_long_row;
-    else if (!strcmp(name, "spgemm_minwin")) *value = o.spgemm_minwin;
-    else if (!strcmp(name, "spgemm_task_order")) *value = o.spgemm_task_order;
-    else if (!strcmp(name, "spgemm_xcd_chunk")) *value = o.spgemm_xcd_chunk;
-    else if (!strcmp(name, "pool")) *value = o.pool;
-    else if (!strcmp(name, "pool_max_bytes")) *value = o.pool_max_bytes;
-    else if (!strcmp(name, "pool_cached_bytes")) *value = (int64_t)pool_cached_bytes();
-    else if (!strcmp(name, "spgemm_winlog")) *value = o.spgemm_winlog;
-    else if (!strcmp(name, "spmv_lds_pad")) *value = o.spmv_lds_pad;
-    else if (!strcmp(name, "spmv_xmask")) *value = o.spmv_xmask;
-    else if (!strcmp(name, "spmv_band")) *value = o.spmv_band;
-    else if (!strcmp(name, "spmv_band_hot")) *value = o.spmv_band_hot;
-    else if (!strcmp(name, "spmv_band_phases")) *value = o.spmv_band_phases;
-    else if (!strcmp(name, "spmv_band_group")) *value = o.spmv_band_group;
-    else if (!strcmp(name, "spmv_band_split_launch")) *value = o.spmv_band_split_launch;
-    else if (!strcmp(name, "spmv_band_split")) *value = o.spmv_band_split;
-    else if (!strcmp(name, "spmv_band_short_group")) *value = o.spmv_band_short_group;
-    else if (!strcmp(name, "spmv_band_short")) *value = o.spmv_band_short;
-    else if (!strcmp(name, "spmv_band_split_permute")) *value = o.spmv_band_split_permute;
-    else if (!strcmp(name, "spmv_band_natural")) *value = o.spmv_band_natural;
-    else if (!strcmp(name, "spmv_band_overlap")) *value = o.spmv_band_overlap;
-    else if (!strcmp(name, "spmv_band_hot_threads")) *value = o.spmv_band_hot_threads;
-    else if (!strcmp(name, "spmv_band_gather")) *value = o.spmv_band_gather;
-    else SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
+    if (!strcmp(name, "pool_cached_bytes")) {
+        *value = (int64_t)pool_cached_bytes();
+        return SPRS_HIP_OK;
+    }
+    if (!strcmp(name, "devtools")) {           // 1 when the library was built with SPRS_HIP_DEVTOOLS
+        *value = DEVTOOLS ? 1 : 0;
+        return SPRS_HIP_OK;
+    }
+    const OptionDesc *d = find_option(name);
+    if (!d) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "unknown option '%s'", name);
+    *value = options().*(d->field);
     return SPRS_HIP_OK;
 }
 

@@ -40,48 +40,61 @@ void clear_error();
     } while (0)
 
 // ---- options -------------------------------------------------------------
+// One table for the struct, sprs_hip_set_option and sprs_hip_get_option: X(name, default, min, max, devtools).
+// devtools = 1: the option only exists in builds with -DSPRS_HIP_DEVTOOLS (timing experiments that give WRONG results,
+// profiling printouts); the release library rejects it with INVALID_ARG and compiles the code behind it out.
+#ifdef SPRS_HIP_DEVTOOLS
+constexpr bool DEVTOOLS = true;
+#else
+constexpr bool DEVTOOLS = false;
+#endif
+#define SPRS_HIP_OPTIONS(X)                                                                                                     \
+    X(spmv_kernel, 0, 0, 2, 0)          /* 0 auto, 1 nnz-tiled, 2 wave-per-row (A/B only) */                                     \
+    X(spmv_xcs, 0, 0, 2, 0)             /* XCD-sliced plan for long rows: 0 auto, 1 force on, 2 off */                            \
+    X(spmv_xcs_split, 32, 2, INT64_MAX, 0) /* rows with >= this many entries go to the sliced part */                             \
+    X(spmv_xcs_idx32, 1, 0, 1, 0)       /* plan-owned copies store 32-bit column ids when cols < 2^32 */                          \
+    X(spmv_sort_tiles, 0, 0, 1, 0)      /* plan copies: entries of a tile sorted by column (10 % SLOWER: profiles/r01v) */         \
+    X(spmv_relabel, 0, 0, 2, 0)         /* sliced plan: columns relabelled by count class: 0 auto (on), 1 on, 2 off */             \
+    X(spmv_tile, 0, 0, 4096, 0)         /* nnz per workgroup tile: 0 auto, 2048 or 4096 */                                        \
+    X(spmv_lds_pad, 0, 0, 100000, 0)    /* extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning) */              \
+    X(spmv_graph, 0, 0, 2, 0)           /* multi-launch SpMV plans replayed as a hipGraph per (handle, stream): 0 auto, 1 on, 2 off */ \
+    X(spmv_xmask, -1, INT64_MIN, INT64_MAX, 1) /* TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1) */      \
+    X(spmv_band, 0, 0, 2, 0)            /* banded plan (hot columns from LDS, spmv_band.hip): 0 auto (on), 1 on, 2 off */          \
+    X(spmv_band_hot, 0, 0, 384, 0)      /* hot slices (0 = default 128) */                                                        \
+    X(spmv_band_tile, 0, 0, 16384, 0)   /* labels per hot slice = doubles of the x tile in LDS: 8192 or 16384 (0 = default 16384) */ \
+    X(spmv_band_phases, 0, 0, 8, 0)     /* label ranges of the cold rest (0 = default 1), 8 hash pieces each */                   \
+    X(spmv_band_split, 0, 0, INT64_MAX, 0) /* rows with at least this many entries are cut into pieces (0 = default 24) */        \
+    X(spmv_band_rounds, 0, 0, 64, 0)    /* workgroups of the hot kernel per CU, one after the other (0 = default 1: persistent) */ \
+    X(spmv_band_cold_tiles, 0, 0, 64, 0) /* consecutive wave tiles per wave of the cold kernel (0 = default 4) */                 \
+    X(spmv_band_split_launch, 0, 0, 1, 0) /* profiling: short rows and cold pieces in two launches instead of one */              \
+    X(spmv_band_cold_waves, 0, 0, 8, 0) /* waves per SIMD the cold kernel is compiled for: 0/8 (64 VGPRs + 8 B scratch), 7 (72 VGPRs) */ \
+    X(spmv_band_overlap, 0, 0, 2, 0)    /* cold pieces + short rows on a second stream beside the hot kernel: 0/1 on, 2 off */     \
+    X(spmv_band_split_permute, 0, 0, 2, 0) /* with the overlap: hot labels of x gathered first, the rest scattered on the second stream: 0/1 on, 2 off */ \
+    X(spmm_long_row, -1, -1, INT64_MAX, 0) /* SpMM: -1 default (0: all rows by chunks); L > 0: rows of <= L entries summed in entry order (reference bits, 3x slower) */ \
+    X(spgemm_task_order, 0, 0, 2, 0)    /* large-row tasks: 0/1 costliest first (stable sort by cost class), 2 row order (A/B) */  \
+    X(spgemm_xcd_chunk, 0, -1, 0, 0)    /* large-row task list -> XCDs: 0 round-robin, -1 one contiguous run per XCD */            \
+    X(spgemm_bucket, 1, 0, 1, 0)        /* column-bucket table of B instead of binary searches (A/B) */                           \
+    X(spgemm_prof, 0, 0, 1, 1)          /* print the time of the numeric tasks by class and the longest ones */                   \
+    X(spgemm_tokens, 1, 1, 4, 0)        /* token chains of the workgroup kernel's ordered adds: 1, 2 or 4 */                      \
+    X(spgemm_overlap, 0, 0, 1, 0)       /* wave kernels on a second stream beside the large-row kernel */                         \
+    X(spgemm_midwin_sym, 16, 14, 16, 0) /* log2 of the window of the wave-per-row COUNTING kernel */                              \
+    X(spgemm_midwin, 14, 13, 14, 0)     /* log2 of the column window of the wave-per-row kernel */                                \
+    X(spgemm_mid, 65536, 0, 1ll << 31, 0) /* rows of <= 64 k's and at most this many products run one wave per row (0: none) */   \
+    X(spgemm_debug, 0, 0, 3, 1)         /* TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission */ \
+    X(spgemm_occupancy, 3, 2, 3, 0)     /* workgroups per CU the large-row numeric kernel is compiled for: 3 (80 VGPRs) or 2 (128) */ \
+    X(spgemm_retain, 1, 0, 1, 0)        /* windows of few entries keep them in registers from the bit pass to the adds (A/B) */    \
+    X(spgemm_lds_atomic, 1, 0, 1, 0)    /* value adds as ds_add_f64 (1) or read / add / write (0); same order either way (A/B) */  \
+    X(spgemm_winlog, 17, 16, 19, 0)     /* log2 of the widest column window of a large-row task */                                \
+    X(spgemm_minwin, 13, 11, 16, 0)     /* log2 of the narrowest column window of a heavy row */                                  \
+    X(spgemm_heavy, 131072, 1024, INT64_MAX, 0) /* a row of more products is cut into one task per (narrower) column window */    \
+    X(spgemm_order, 0, 0, 1, 0)         /* order of the additions into one C(i,j): 0 strict (the reference's k-ascending chain, bit-exact), 1 relaxed (deterministic, any k order; within 1e-10) */ \
+    X(pool, 1, 0, 1, 0)                 /* keep released result blocks (>= 1 MiB) for the next result instead of hipFree */        \
+    X(pool_max_bytes, 128ll << 30, 0, INT64_MAX, 0) /* cap on the bytes the pool may hold */
+
 struct Options {
-    int64_t spmv_kernel = 0;       // 0 auto, 1 nnz-tiled, 2 wave-per-row (A/B only)
-    int64_t spmv_xcs = 0;          // XCD-sliced plan for long rows: 0 auto, 1 force on, 2 off
-    int64_t spmv_xcs_split = 32;   // rows with >= this many entries go to the sliced part
-    int64_t spmv_xcs_idx32 = 1;    // plan-owned copies store 32-bit column ids when cols < 2^32
-    int64_t spmv_sort_tiles = 0;   // plan copies: entries of a tile sorted by column (measured 10 % SLOWER: profiles/r01v)
-    int64_t spmv_relabel = 0;      // sliced plan: columns relabelled by count class, x permuted per SpMV: 0 auto (on), 1 on, 2 off
-    int64_t spmv_tile = 0;         // nnz per workgroup tile: 0 auto, 2048 or 4096
-    int64_t spgemm_task_order = 0; // large-row tasks: 0/1 costliest first (stable sort by cost class), 2 row order (A/B)
-    int64_t spgemm_xcd_chunk = 0;  // large-row task list -> XCDs: 0 round-robin, -1 one contiguous run per XCD
-    int64_t spgemm_bucket = 1;     // SpGEMM: column-bucket table of B instead of binary searches (A/B)
-    int64_t spgemm_prof = 0;       // SpGEMM: print the time of the large-row numeric tasks by class and the longest ones (debug)
-    int64_t spgemm_tokens = 1;     // SpGEMM: token chains of the workgroup kernel's ordered adds (accumulators split by rank mod n): 1, 2 or 4
-    int64_t spgemm_overlap = 0;    // SpGEMM: wave kernels (hash rows, wave-per-row rows) on a second stream beside the large-row kernel
-    int64_t spgemm_midwin_sym = 16; // SpGEMM: log2 of the window of the wave-per-row COUNTING kernel (14..16)
-    int64_t spgemm_midwin = 14;    // SpGEMM: log2 of the column window of the wave-per-row kernel (13 or 14)
-    int64_t spgemm_mid = 65536;    // SpGEMM: rows of <= 64 k's and at most this many products run one wave per row (0: none)
-    int64_t spgemm_debug = 0;      // SpGEMM TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission
-    int64_t spgemm_occupancy = 3;  // SpGEMM: workgroups per CU the large-row numeric kernel is compiled for: 3 (80 VGPRs) or 2 (128 VGPRs) (A/B)
-    int64_t spgemm_retain = 1;     // SpGEMM: windows of few entries keep them in registers from the bit pass to the adds (A/B)
-    int64_t spgemm_lds_atomic = 1; // SpGEMM: value adds as ds_add_f64 (1) or read / add / write (0); same order either way (A/B)
-    int64_t spgemm_winlog = 17;    // SpGEMM: log2 of the widest column window of a large-row task (16..19)
-    int64_t spgemm_minwin = 13;    // SpGEMM: log2 of the narrowest column window of a heavy row (11..16)
-    int64_t spgemm_heavy = 131072;    // SpGEMM: a row of more products is cut into one task per (narrower) column window, about this many products each
-    int64_t pool = 1;              // keep released result blocks (>= 1 MiB) for the next result instead of hipFree
-    int64_t pool_max_bytes = 128ll << 30;   // cap on the bytes the pool may hold
-    int64_t spmv_band = 0;         // banded plan (hot columns from LDS, spmv_band.hip) instead of the XCD-sliced one: 0 auto (on), 1 on, 2 off
-    int64_t spmv_band_hot = 0;     // hot slices of 8192 labels each (0 = default 128)
-    int64_t spmv_band_phases = 0;  // label ranges of the cold rest (0 = default 1), 8 hash pieces each
-    int64_t spmv_band_split_launch = 0;   // profiling: short rows and cold pieces in two launches instead of one
-    int64_t spmv_band_hot_threads = 0;    // threads per workgroup of the hot kernel: 1024 (default) or 512
-    int64_t spmv_band_gather = 0;         // how the cold kernel reads x: 0 plain, 1 non-temporal, 2 device scope (L1 bypass)
-    int64_t spmv_band_overlap = 0;        // cold pieces + short rows on a second stream beside the hot kernel: 0/1 on, 2 off
-    int64_t spmv_band_natural = 0;        // cold entries keep their original column and read x itself (no per-SpMV scatter of x): 1 on (measured slower: profiles/r03i), 0/2 off
-    int64_t spmv_band_split_permute = 0;  // with the overlap: hot labels of x gathered first, the rest scattered on the second stream: 0/1 on, 2 off
-    int64_t spmv_band_short = 0;          // short rows: 0/2 as one more gather piece, 1 tiled with the 8192 hottest x entries in LDS (measured slower)
-    int64_t spmv_band_short_group = 0;    // blocks per workgroup of the tiled short-rows launch (0 = default 4)
-    int64_t spmv_band_split = 0;          // rows with at least this many entries are cut into pieces (0 = default 24)
-    int64_t spmv_band_group = 0;   // blocks of 8192 entries per workgroup of the hot kernel (0 = default 16)
-    int64_t spmm_long_row = -1;    // SpMM: rows of more entries go to the chunk kernels (summation by chunks); -1 = default (0: all rows); L > 0: rows of <= L entries are summed in entry order by lane groups (the reference's bits, 3x slower)
-    int64_t spmv_lds_pad = 0;      // extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning)
-    int64_t spmv_xmask = -1;       // TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1)
+#define SPRS_X(name, def, lo, hi, dev) int64_t name = (def);
+    SPRS_HIP_OPTIONS(SPRS_X)
+#undef SPRS_X
 };
 Options &options();
 
@@ -112,8 +125,7 @@ struct SpmvPlan {
     bool built = false;
     bool xcs = false;
     BandPlan *band = nullptr;      // banded plan: when set, nothing else below is used
-    int64_t opt_band = -1, opt_band_hot = -1, opt_band_phases = -1, opt_band_group = -1, opt_band_split = -1, opt_band_natural = -1, opt_band_short = -1;
-    int64_t opt_xcs = -1, opt_split = -1, opt_idx32 = -1, opt_tile = -1, opt_sort = -1, opt_relabel = -1;   // option values the plan was built with
+    uint64_t opt_sig = 0;          // hash of the option values the plan was built with (plan_signature, spmv.hip)
     uint32_t tile = 0;             // nnz per tile
     int idx_bytes = 8;             // width of the column ids the kernels read (handle's, or 4 for plan copies)
     CsrPiece main;                 // the whole matrix (plain plan) or its short rows (sliced plan)

@@ -89,6 +89,13 @@ __global__ void build_tile_rows(const PTR *__restrict__ indptr, uint64_t rows, u
 // ---------------------------------------------------------------------------
 // one workgroup, one nnz tile
 // ---------------------------------------------------------------------------
+// developer builds only (option spmv_xmask): gathers forced into a narrow window of x, a TIMING experiment with wrong
+// results; the release library compiles it out
+__device__ __forceinline__ uint64_t xm(uint64_t col, uint64_t xmask) {
+    if constexpr (DEVTOOLS) return col & xmask;
+    else return col;
+}
+
 template <typename IDX, typename PTR, bool ACC, int TILE>
 __device__ __forceinline__ void tile_body(const TileArgs &a, const double *__restrict__ x, uint64_t tile,
                                           uint64_t xmask) {
@@ -129,8 +136,8 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, const double *__res
         double xv[PASSES][V];
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            xv[p][0] = x[(uint64_t)ix[p][0] & xmask];
-            xv[p][1] = x[(uint64_t)ix[p][1] & xmask];
+            xv[p][0] = x[xm((uint64_t)ix[p][0], xmask)];
+            xv[p][1] = x[xm((uint64_t)ix[p][1], xmask)];
         }
         if (a.pos) {
             // the tile's entries are stored sorted by column (plan copies only): lanes next to each
@@ -158,8 +165,8 @@ __device__ __forceinline__ void tile_body(const TileArgs &a, const double *__res
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const uint32_t i = p * (BLOCK * V) + tid * V;
-            const double p0 = i < cnt ? dp[i] * x[(uint64_t)ip[i] & xmask] : 0.0;
-            const double p1 = i + 1 < cnt ? dp[i + 1] * x[(uint64_t)ip[i + 1] & xmask] : 0.0;
+            const double p0 = i < cnt ? dp[i] * x[xm((uint64_t)ip[i], xmask)] : 0.0;
+            const double p1 = i + 1 < cnt ? dp[i + 1] * x[xm((uint64_t)ip[i + 1], xmask)] : 0.0;
             if (pp) {
                 if (i < cnt) prod[pp[i]] = p0;
                 if (i + 1 < cnt) prod[pp[i + 1]] = p1;
@@ -564,24 +571,21 @@ static int32_t build_sliced(sprs_hip_csmat *a, uint64_t nnz_short, uint64_t n_lo
     return SPRS_HIP_OK;
 }
 
+// the options a plan depends on: a handle rebuilds its plan when one of them changes
+static uint64_t plan_signature(const Options &o) {
+    const int64_t v[] = {o.spmv_xcs, o.spmv_xcs_split, o.spmv_xcs_idx32, o.spmv_sort_tiles, o.spmv_relabel, o.spmv_tile, o.spmv_band,
+                         o.spmv_band_hot, o.spmv_band_tile, o.spmv_band_phases, o.spmv_band_split, o.spmv_band_rounds, o.spmv_band_cold_tiles};
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (int64_t x : v) h = (h ^ (uint64_t)x) * 0x100000001b3ull;
+    return h | 1ull;
+}
+
 template <typename IDX, typename PTR>
 static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
     SpmvPlan &pl = a->plan;
     const Options &o = options();
     pl.release();
-    pl.opt_xcs = o.spmv_xcs;
-    pl.opt_split = o.spmv_xcs_split;
-    pl.opt_idx32 = o.spmv_xcs_idx32;
-    pl.opt_sort = o.spmv_sort_tiles;
-    pl.opt_relabel = o.spmv_relabel;
-    pl.opt_tile = o.spmv_tile;
-    pl.opt_band = o.spmv_band;
-    pl.opt_band_hot = o.spmv_band_hot;
-    pl.opt_band_phases = o.spmv_band_phases;
-    pl.opt_band_split = o.spmv_band_split;
-    pl.opt_band_natural = o.spmv_band_natural;
-    pl.opt_band_short = o.spmv_band_short;
-    pl.opt_band_group = o.spmv_band_group + 100000 * o.spmv_band_hot_threads + 100000000 * o.spmv_band_short_group;   // (one key for the three)
+    pl.opt_sig = plan_signature(o);
     pl.idx_bytes = (int)sizeof(IDX);
     const uint64_t rows = a->rows, nnz = a->nnz;
     const PTR *ip = (const PTR *)a->indptr;
@@ -592,7 +596,16 @@ static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
     // (it pays from smaller x on than the XCD-sliced plan: R-MAT 1M, x = 8 MB, cold caches: 0.101 vs 0.156 ms, profiles/r02p)
     const bool want_band = o.spmv_band == 1 || (o.spmv_band == 0 && o.spmv_xcs != 2 && a->cols * 8 >= (4ull << 20) && nnz >= (1ull << 22));
     if (want_band) {
-        SPRS_TRY(band_build(a, stream, &pl.band));
+        const int32_t st = band_build(a, stream, &pl.band);
+        // auto mode: a matrix the banded plan cannot be built for (its temporaries did not fit) keeps the plans below;
+        // an explicit spmv_band = 1 reports the failure
+        if (st == SPRS_HIP_OUT_OF_MEMORY && o.spmv_band == 0) {
+            (void)hipGetLastError();
+            clear_error();
+            pl.band = nullptr;
+        } else if (st != SPRS_HIP_OK) {
+            return st;
+        }
         if (pl.band) {
             pl.built = true;
             return SPRS_HIP_OK;
@@ -733,11 +746,7 @@ static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool 
     std::lock_guard<std::recursive_mutex> lock(a->mu);
     {
         SpmvPlan &pl = a->plan;
-        if (!pl.built || pl.opt_xcs != o.spmv_xcs || pl.opt_split != o.spmv_xcs_split ||
-            pl.opt_idx32 != o.spmv_xcs_idx32 || pl.opt_tile != o.spmv_tile || pl.opt_sort != o.spmv_sort_tiles ||
-            pl.opt_relabel != o.spmv_relabel || pl.opt_band != o.spmv_band || pl.opt_band_hot != o.spmv_band_hot ||
-            pl.opt_band_phases != o.spmv_band_phases || pl.opt_band_split != o.spmv_band_split || pl.opt_band_natural != o.spmv_band_natural ||
-            pl.opt_band_short != o.spmv_band_short || pl.opt_band_group != o.spmv_band_group + 100000 * o.spmv_band_hot_threads + 100000000 * o.spmv_band_short_group)
+        if (!pl.built || pl.opt_sig != plan_signature(o))
             SPRS_TRY((build_plan<IDX, PTR>(a, stream)));
         if (!pl.band) SPRS_TRY(get_scratch(pl, stream, &sc));
     }

@@ -1,0 +1,486 @@
+// Kernels of one SpMV on the BANDED plan (spmv_band.hip builds the plan and launches them) — device twin of
+// prod::mul_acc_mat_vec_csr (sprs/src/sparse/prod.rs:103-127) and of the one-column prod::csr_mulacc_dense_colmaj
+// (prod.rs:274-298).  Included by spmv_band.hip only.
+//
+// Geometry shared by every piece of the plan (hot slices, cold pieces, the short rows):
+//   * a WAVE TILE is 512 consecutive entries of a piece; lane l owns the 8 consecutive entries 8 l .. 8 l + 7;
+//   * values are stored transposed so that the four coalesced 16-byte loads of a lane return its own entries:
+//     entry 8 l + 2 p + e of tile w at vals[512 w + 128 p + 2 l + e];
+//   * the row structure travels with the column ids: a flag bit marks the first entry of a row inside the piece,
+//     tile_row[w] is the compact row (position in the piece's row list) of the first row starting in tile w;
+//   * a RANGE is a run of consecutive tiles walked by ONE wave: the sum of the row that is open at the end of a tile stays
+//     in a register and is completed in the next tile, so that only the row open at the START of a range needs a fix-up
+//     (band_carry_kernel: one record per range instead of one per tile; round 2 had 630 000 spills per SpMV, now ~25 000);
+//   * sums are written straight from the registers to where they belong (partial sum of a (row, piece) pair, or y for the
+//     short rows): the LDS only holds the x tile.
+#pragma once
+#include "spmv_shared.hpp"
+
+namespace sprs_hip {
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WT = 512;                       // entries per wave tile
+constexpr int WPASS = WT / (WAVE * 2);        // 16-byte value loads per lane and tile
+constexpr int EPL = WT / WAVE;                // entries per lane
+constexpr int HOT_THREADS = 1024;             // one workgroup per CU: 16 waves share the x tile
+constexpr int HOT_WAVES = HOT_THREADS / WAVE;
+constexpr int CNT = 256;                      // threads of a cold / short workgroup: 4 independent waves
+constexpr uint32_t ROW_START = 0x8000u;       // flag bit in a hot column id (14 bits of local column below it)
+constexpr uint32_t ROW_START32 = 0x80000000u; // flag bit in a cold label
+static_assert(WPASS == 4 && EPL == 8, "wave tile geometry");
+
+// One piece of the plan, as the kernels see it.
+struct BandPiece {
+    const uint32_t *rowidx;     // nr: long-row number (short piece: row of y) of compact row r
+    const uint32_t *tile_row;   // ntiles + 1: first compact row starting at / after tile c
+    double *out;                // nr partial sums, one per compact row, in row-list order (null for the short piece: it writes y)
+    uint64_t ent0;              // first entry of the piece in the value / column-id arrays of its class
+    uint64_t nnz;
+    uint32_t nr, ntiles;
+    uint32_t x0;                // hot: first label of the slice
+    uint32_t to_y;              // short piece
+    uint32_t range0;            // first range of the piece in the range table (cold / short pieces: ranges of `cold_tiles` tiles)
+    uint32_t pad;
+};
+
+// A run of consecutive tiles of one piece walked by one wave.
+struct Range {
+    uint32_t piece, tile0, ntiles, pad;
+};
+
+// A part of a hot slice taken by one workgroup: 16 ranges (one per wave; the last ones may be empty), x tile loaded once.
+struct HotSeg {
+    uint32_t piece, range0;
+};
+
+struct ColdGroup {              // a run of blocks of the cold launch
+    uint32_t first_block, first_piece, npieces;   // npieces 8: block b -> piece b % 8 (XCD b % 8); 1: one piece
+};
+
+// A pointer loaded from a struct in memory is a generic ("flat") pointer to the compiler, and a flat load counts on the
+// LDS counter as well (round 2, found in the ISA): the kernels retype what they load as GLOBAL memory.
+#ifdef SPRS_HIP_EMU
+#define SPRS_GLOBAL_AS
+#else
+#define SPRS_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+struct PieceView {
+    const SPRS_GLOBAL_AS uint32_t *rowidx, *tile_row;
+    SPRS_GLOBAL_AS double *out;
+    uint64_t ent0, nnz;
+    uint32_t nr, ntiles, x0, to_y, range0;
+    __device__ __forceinline__ PieceView(const BandPiece &p)
+        : rowidx((const SPRS_GLOBAL_AS uint32_t *)p.rowidx), tile_row((const SPRS_GLOBAL_AS uint32_t *)p.tile_row),
+          out((SPRS_GLOBAL_AS double *)p.out), ent0(p.ent0), nnz(p.nnz), nr(p.nr), ntiles(p.ntiles), x0(p.x0), to_y(p.to_y),
+          range0(p.range0) {}
+};
+
+// ---- wave primitives without the LDS ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t band_scan_incl_u32(uint32_t v, uint32_t lane) {
+#ifdef SPRS_HIP_EMU
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, WAVE);
+        if (lane >= (uint32_t)off) v += o;
+    }
+    return v;
+#else
+    (void)lane;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);     // row_shr:1 (zeros shifted in)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+#endif
+}
+
+// Segmented inclusive scan over the lanes.  In: S = the sum of the run that is open at the end of the lane, F = 1 when a
+// row starts inside the lane.  Out: S = the sum of the run open at the end of the lane INCLUDING what lower lanes hold
+// of it; F = 1 when a row starts in this lane or below.  The operator (S, F) o (s, f) = (f ? s : S + s, F | f) is
+// associative: the DPP scan pattern of band_scan_incl_u32 applies (lanes that receive nothing get the identity (0, 0)).
+#ifndef SPRS_HIP_EMU
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ void band_seg_step(double &S, uint32_t &F) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(S), CTRL, ROW_MASK, 0xf, BOUND);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(S), CTRL, ROW_MASK, 0xf, BOUND);
+    const uint32_t fs = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)F, CTRL, ROW_MASK, 0xf, BOUND);
+    const double vs = __hiloint2double(hi, lo);
+    S = F ? S : vs + S;
+    F |= fs;
+}
+#endif
+
+__device__ __forceinline__ void band_seg_scan(double &S, uint32_t &F, uint32_t lane) {
+#ifdef SPRS_HIP_EMU
+    for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
+        const double vs = __shfl_up(S, dlt, WAVE);
+        const uint32_t fs = __shfl_up(F, dlt, WAVE);
+        if (lane >= (uint32_t)dlt) {
+            if (!F) S = vs + S;
+            F |= fs;
+        }
+    }
+#else
+    (void)lane;
+    band_seg_step<0x111, 0xf, true>(S, F);
+    band_seg_step<0x112, 0xf, true>(S, F);
+    band_seg_step<0x114, 0xf, true>(S, F);
+    band_seg_step<0x118, 0xf, true>(S, F);
+    band_seg_step<0x142, 0xa, false>(S, F);
+    band_seg_step<0x143, 0xc, false>(S, F);
+#endif
+}
+
+// value of the lane below (lane 0: 0.0, flag 0)
+__device__ __forceinline__ double band_lane_below(double S, uint32_t lane) {
+#ifdef SPRS_HIP_EMU
+    const double b = __shfl_up(S, 1, WAVE);
+    return lane ? b : 0.0;
+#else
+    (void)lane;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(S), 0x138, 0xf, 0xf, true);   // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(S), 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+#endif
+}
+
+__device__ __forceinline__ double band_read_lane63(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), WAVE - 1);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), WAVE - 1);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row sums of one wave tile.
+//   pr[q]   product of the lane's entry q (0.0 for the padding behind the piece's last entry)
+//   fb      bit q = entry q is the first of its row inside the piece
+//   R0      compact row of the first row that starts in the tile
+//   open    (in / out, wave-uniform) sum of the row that is open when the tile begins / ends
+//   mine    (in / out, wave-uniform) a row has started in this range before / by the end of this tile
+//   last    (out, wave-uniform) compact row of the last row that has started so far (valid when mine)
+// Every row that ENDS inside the tile is emitted: emit(compact row, sum).  The row open at the start of the range began
+// in an earlier range: what this range holds of it goes to *carry (band_carry_kernel adds it where it belongs).
+// Order of the additions inside a row: entry order inside a lane, lanes in order, tiles in order — fixed by the plan,
+// the same in every run (no float atomics anywhere in the SpMV).
+// ---------------------------------------------------------------------------------------------
+template <typename Emit>
+__device__ __forceinline__ void band_tile_sums(const double (&pr)[EPL], uint32_t fb, uint32_t lane, uint32_t R0, double &open, bool &mine,
+                                               uint32_t &last, SPRS_GLOBAL_AS double *carry, Emit emit) {
+    const uint32_t nfl = (uint32_t)__popc(fb);                          // rows starting in this lane
+    const uint32_t incl = band_scan_incl_u32(nfl, lane);
+    const uint32_t prefix = incl - nfl;                                 // rows starting in lower lanes
+    const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    // ---- serial fold of the lane's entries: rows that start AND end inside the lane are complete at once ----------
+    double run = 0.0, head = 0.0;
+    uint32_t seen = 0;
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        if ((fb >> q) & 1u) {
+            if (seen == 0) head = run;                                  // the run that was open when the lane began ends here
+            else emit(R0 + prefix + seen - 1, run);
+            run = 0.0;
+            ++seen;
+        }
+        run += pr[q];
+    }
+    // ---- runs that cross lanes -------------------------------------------------------------------------------------
+    double S = run;
+    uint32_t F = seen ? 1u : 0u;
+    band_seg_scan(S, F, lane);
+    double before = band_lane_below(S, lane);                           // open run at the end of the lane below
+    if (prefix == 0) before = open + before;                            // no row has started in the tile so far: the range's open row
+    if (seen) {
+        const double v = before + head;                                 // the run that ends at this lane's first row start
+        if (prefix == 0 && !mine) *carry = v;                           // ... began before the range
+        else emit(R0 + prefix - 1, v);                                  // (prefix == 0: the row open since an earlier tile of the range)
+    }
+    const double s63 = band_read_lane63(S);
+    open = nf ? s63 : open + s63;
+    if (nf) {
+        mine = true;
+        last = R0 + nf - 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hot slices: x tile in LDS, 16-bit local column ids.
+//
+// One workgroup per CU (16 waves, the x tile takes 64 or 128 KiB of the 160 KiB of LDS), `rounds` workgroups per CU in
+// all.  A workgroup owns an equal share of the wave tiles of ALL hot slices, i.e. a few SEGMENTS (parts of a slice): per
+// segment it loads the slice's x tile once, then its 16 waves walk their ranges independently — no barrier until the
+// next segment.  (Round 2 launched one workgroup per 131 072 entries: 2 146 workgroups of unequal slices, 8.4 rounds
+// on 256 CUs and a tail of ~7 %; with equal shares every CU streams until the end.)
+// ---------------------------------------------------------------------------------------------
+template <int XT_LOG2>
+__global__ __launch_bounds__(HOT_THREADS) void band_hot_kernel(const BandPiece *__restrict__ pieces, const HotSeg *__restrict__ segs,
+                                                               const uint32_t *__restrict__ wg_seg, const Range *__restrict__ ranges,
+                                                               const double *__restrict__ vals, const uint16_t *__restrict__ cid,
+                                                               const double *__restrict__ xp, double *__restrict__ carry) {
+    constexpr int XT = 1 << XT_LOG2;
+    __shared__ __attribute__((aligned(16))) double xs[XT];
+    const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const uint32_t s0 = wg_seg[blockIdx.x], s1 = wg_seg[blockIdx.x + 1];
+    for (uint32_t s = s0; s < s1; ++s) {
+        const HotSeg seg = segs[s];
+        const PieceView d(pieces[seg.piece]);
+        const Range rg = ranges[seg.range0 + wave];
+        if (s != s0) __syncthreads();                                    // every wave is done with the previous x tile
+        {   // x tile of the slice -> LDS (xp is padded to a whole number of tiles)
+            const dbl2 *src = (const dbl2 *)(xp + d.x0);
+            dbl2 v[XT / (2 * HOT_THREADS)];
+#pragma unroll
+            for (int q = 0; q < XT / (2 * HOT_THREADS); ++q) v[q] = src[q * HOT_THREADS + tid];
+#pragma unroll
+            for (int q = 0; q < XT / (2 * HOT_THREADS); ++q) *(dbl2 *)&xs[2 * (q * HOT_THREADS + tid)] = v[q];
+        }
+        // the first tile of the range is requested before the barrier
+        dbl2 av[WPASS];
+        u32x4 cw = {0u, 0u, 0u, 0u};
+        uint32_t R0n = 0;
+        auto request = [&](uint32_t w) {
+            const uint64_t g = d.ent0 + (uint64_t)w * WT;
+#pragma unroll
+            for (int p = 0; p < WPASS; ++p) av[p] = __builtin_nontemporal_load((const dbl2 *)(vals + g + p * (WAVE * 2) + lane * 2));
+            cw = __builtin_nontemporal_load((const u32x4 *)(cid + g + lane * EPL));
+            R0n = d.tile_row[w];
+        };
+        const uint32_t tend = rg.tile0 + rg.ntiles;
+        if (rg.ntiles) request(rg.tile0);
+        __syncthreads();                                                 // xs complete
+        double open = 0.0;
+        bool mine = false;
+        uint32_t last = 0;
+        SPRS_GLOBAL_AS double *cslot = (SPRS_GLOBAL_AS double *)carry + seg.range0 + wave;
+        for (uint32_t w = rg.tile0; w < tend; ++w) {                     // wave-uniform
+            const uint64_t base = (uint64_t)w * WT;
+            const uint32_t cnt = d.nnz - base < (uint64_t)WT ? (uint32_t)(d.nnz - base) : (uint32_t)WT;
+            double pr[EPL];
+            uint32_t fb = 0;
+#pragma unroll
+            for (int p = 0; p < WPASS; ++p) {
+                const uint32_t c2 = cw[p];
+                const uint32_t i0 = lane * EPL + 2 * p;
+                pr[2 * p] = i0 < cnt ? av[p][0] * xs[c2 & (XT - 1)] : 0.0;
+                pr[2 * p + 1] = i0 + 1 < cnt ? av[p][1] * xs[(c2 >> 16) & (XT - 1)] : 0.0;
+                fb |= ((c2 >> 15) & 1u) << (2 * p);
+                fb |= ((c2 >> 31) & 1u) << (2 * p + 1);
+            }
+            const uint32_t R0 = R0n;
+            if (w + 1 < tend) request(w + 1);                            // the next tile streams while this one is summed
+            band_tile_sums(pr, fb, lane, R0, open, mine, last, cslot, [&](uint32_t r, double v) { d.out[r] = v; });
+        }
+        if (rg.ntiles && lane == 0) {
+            if (mine) d.out[last] = open;                                // the row still open at the end of the range: its sum so far
+            else *cslot = open;                                          // no row starts in the whole range: all of it belongs to an earlier row
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cold pieces and the short rows: x gathered through L1 / L2 from xp, 32-bit labels.
+//
+// Same wave-tile scheme without an x tile and without LDS: four independent waves per workgroup, each walking one range
+// of `ct` consecutive tiles, so that many workgroups share a CU beside the hot kernel's one and thousands of gathers are
+// in flight per CU.  Labels are stored transposed for two coalesced 16-byte loads: entry 8 l + 4 p + e at
+// cid[512 w + 256 p + 4 l + e].  Pieces start at multiples of 512 entries and are padded with (label 0, value 0).
+// The short piece (to_y) writes y[rowidx[r]] instead of a partial sum.
+// ---------------------------------------------------------------------------------------------
+// WPS = waves per SIMD the kernel is compiled for: 8 (64 VGPRs, a few dwords of scratch) or 7 (72 VGPRs, none).
+// (Non-temporal and device-scope gathers were measured slower in round 2 — 2.29 ms per SpMV / no change — and are gone.)
+template <bool ACC, int WPS>
+__global__ __launch_bounds__(CNT, WPS) void band_cold_kernel(const BandPiece *__restrict__ pieces, const ColdGroup *__restrict__ groups,
+                                                        uint32_t ngroups, const double *__restrict__ vals,
+                                                        const uint32_t *__restrict__ cid, const double *__restrict__ xp,
+                                                        double *__restrict__ y, double *__restrict__ carry, uint32_t block0, uint32_t ct) {
+    constexpr int WPB = CNT / WAVE;
+    const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    const uint32_t bid = blockIdx.x + block0;
+    uint32_t g = 0;
+    while (g + 1 < ngroups && bid >= groups[g + 1].first_block) ++g;     // block-uniform
+    const ColdGroup cg = groups[g];
+    const uint32_t lb = bid - cg.first_block;
+    const uint32_t pi = cg.first_piece + (cg.npieces == 1 ? 0u : (lb & 7u));
+    const uint32_t r = (cg.npieces == 1 ? lb : (lb >> 3)) * WPB + wave;  // range of the piece
+    const PieceView d(pieces[pi]);
+    const uint32_t t0 = r * ct;
+    if (t0 >= d.ntiles) return;                                          // wave-uniform; no workgroup barrier below
+    const uint32_t tend = t0 + ct < d.ntiles ? t0 + ct : d.ntiles;
+    dbl2 av[WPASS];
+    u32x4 lw[2];
+    uint32_t R0n = 0;
+    auto request = [&](uint32_t w) {
+        const uint64_t gpos = d.ent0 + (uint64_t)w * WT;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) lw[p] = __builtin_nontemporal_load((const u32x4 *)(cid + gpos + p * (WAVE * 4) + lane * 4));
+#pragma unroll
+        for (int p = 0; p < WPASS; ++p) av[p] = __builtin_nontemporal_load((const dbl2 *)(vals + gpos + p * (WAVE * 2) + lane * 2));
+        R0n = d.tile_row[w];
+    };
+    request(t0);
+    double open = 0.0;
+    bool mine = false;
+    uint32_t last = 0;
+    SPRS_GLOBAL_AS double *cslot = (SPRS_GLOBAL_AS double *)carry + d.range0 + r;
+    const bool to_y = d.to_y != 0;
+    auto emit = [&](uint32_t row, double v) {
+        if (to_y) {
+            const uint32_t yr = d.rowidx[row];
+            if constexpr (ACC) y[yr] = y[yr] + v;                        // every compact row has entries: empty rows are never touched (prod.rs:120-126)
+            else y[yr] = v;
+        } else {
+            d.out[row] = v;
+        }
+    };
+    for (uint32_t w = t0; w < tend; ++w) {
+        const uint64_t base = (uint64_t)w * WT;
+        const uint32_t cnt = d.nnz - base < (uint64_t)WT ? (uint32_t)(d.nnz - base) : (uint32_t)WT;
+        double xv[EPL];
+        uint32_t fb = 0;
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) {
+            const uint32_t c = lw[q / 4][q % 4];
+            xv[q] = xp[c & ~ROW_START32];             // padding: label 0, value 0, never summed into a row
+            fb |= (c >> 31) << q;
+        }
+        double pr[EPL];
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) pr[q] = lane * EPL + q < cnt ? av[q / 2][q % 2] * xv[q] : 0.0;
+        // (no prefetch of the next tile here: its 24 registers would halve the waves per SIMD, and the gathers live on those)
+        band_tile_sums(pr, fb, lane, R0n, open, mine, last, cslot, emit);
+        if (w + 1 < tend) request(w + 1);
+    }
+    if (lane == 0) {
+        if (mine) emit(last, open);
+        else *cslot = open;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The row that is open at the START of a range began in an earlier range: the part of it each range holds (its HEAD) was
+// left in carry[range].  One thread per range: the first range of a run of ranges that continue the same row adds their
+// heads, in range order, to that row's sum (a (row, piece) partial, or y for the short rows).  Which ranges have a head,
+// and whose, is read off the plan (the first entry's row-start flag, tile_row).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool range_has_head(const BandPiece &d, const Range &rg, const uint16_t *__restrict__ cid_hot,
+                                               const uint32_t *__restrict__ cid_cold, uint32_t nhot) {
+    const uint64_t e = d.ent0 + (uint64_t)rg.tile0 * WT;                 // entry 0 of lane 0 sits first in both layouts
+    return rg.piece < nhot ? !(cid_hot[e] & ROW_START) : !(cid_cold[e] & ROW_START32);
+}
+
+__global__ __launch_bounds__(256) void band_carry_kernel(const Range *__restrict__ ranges, uint32_t nranges,
+                                                         const BandPiece *__restrict__ pieces, uint32_t nhot,
+                                                         const uint16_t *__restrict__ cid_hot, const uint32_t *__restrict__ cid_cold,
+                                                         const double *__restrict__ carry, double *__restrict__ y) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nranges) return;
+    const Range rg = ranges[i];
+    if (!rg.ntiles) return;
+    const BandPiece d = pieces[rg.piece];
+    if (!range_has_head(d, rg, cid_hot, cid_cold, nhot)) return;
+    const uint32_t row = d.tile_row[rg.tile0] - 1;                        // the row open at the start of the range (a piece begins with a row start)
+    // a leader has no predecessor that continues the same row
+    for (uint32_t j = i; j-- > 0;) {
+        const Range pj = ranges[j];
+        if (!pj.ntiles) continue;                                        // (waves of a short hot segment without tiles)
+        if (pj.piece == rg.piece && d.tile_row[pj.tile0] - 1 == row && range_has_head(d, pj, cid_hot, cid_cold, nhot)) return;
+        break;
+    }
+    double *dst = d.to_y ? y + d.rowidx[row] : d.out + row;
+    double acc = *dst;
+    acc += carry[i];
+    for (uint32_t j = i + 1; j < nranges; ++j) {
+        const Range nj = ranges[j];
+        if (!nj.ntiles) continue;
+        if (nj.piece != rg.piece || d.tile_row[nj.tile0] - 1 != row || !range_has_head(d, nj, cid_hot, cid_cold, nhot)) break;
+        acc += carry[j];
+    }
+    *dst = acc;
+}
+
+__global__ __launch_bounds__(256) void band_permute_kernel(const double *__restrict__ x, const uint32_t *__restrict__ perm,
+                                                           uint64_t cols, double *__restrict__ xp, double *__restrict__ y_zero,
+                                                           uint64_t rows, uint32_t first_label) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < cols) {
+        const uint32_t l = perm[j];
+        if (l >= first_label) xp[l] = x[j];     // labels below first_label were gathered by band_gather_hot_kernel
+    }
+    if (y_zero && j < rows) y_zero[j] = 0.0;
+}
+
+// The hot kernel only reads the labels of the hot slices: those are gathered first, through the inverse of the labelling
+// (a few MB), so that the hot kernel starts a few us into the SpMV while the scatter of the rest of x (and the clearing
+// of y) runs beside it on the second stream, in front of the cold launch that needs them.
+__global__ __launch_bounds__(256) void band_gather_hot_kernel(const double *__restrict__ x, const uint32_t *__restrict__ inv_hot,
+                                                              uint32_t hot_labels, double *__restrict__ xp) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= hot_labels) return;
+    const uint32_t j = inv_hot[l];
+    xp[l] = j != 0xFFFFFFFFu ? x[j] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y[long_rows[j]] (+)= sum of the row's partials, pieces in ascending order (a fixed order: deterministic).
+// One WAVE per 64 consecutive long rows (lane = row), no LDS, no barrier.  For piece k, wmask tells which of the 64 rows
+// have a partial there and wbase where the first of them sits; the present rows' partials follow each other in memory.
+// The table rows of a row block are contiguous over k: one coalesced load puts 64 pieces into the lanes, readlane hands
+// them out.  Round 2 split the pieces of a row block over the 4 waves of a workgroup and combined through LDS behind a
+// barrier — each wave was two dependent round trips long and the kernel ran at half the bandwidth of its traffic.
+// ---------------------------------------------------------------------------------------------
+constexpr int RU = 16;       // partials in flight per lane
+template <bool ACC>
+__global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restrict__ partial, const unsigned long long *__restrict__ wmask,
+                                                          const uint32_t *__restrict__ wbase, const uint32_t *__restrict__ long_rows,
+                                                          double *__restrict__ y, uint32_t n_long, uint32_t npieces, uint32_t np_pad,
+                                                          uint32_t nwb) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    // wave -> row block: block b runs on XCD b % 8 (observed; only speed depends on it): every XCD gets a CONTIGUOUS range
+    // of row blocks (neighbouring row blocks read neighbouring partials of every piece, often the same 128-byte line)
+    const uint32_t gw = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;        // global wave
+    const uint32_t nwaves = gridDim.x * (blockDim.x / WAVE);
+    const uint32_t wpb = blockDim.x / WAVE;
+    const uint32_t xcd = blockIdx.x & 7u, inx = (blockIdx.x >> 3) * wpb + threadIdx.x / WAVE;   // wave number inside the XCD
+    const uint32_t per_xcd = (nwb + 7u) / 8u, waves_per_xcd = nwaves / 8u;
+    (void)gw;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t i = inx; i < per_xcd; i += waves_per_xcd) {            // wave-uniform
+        const uint32_t wb = xcd * per_xcd + i;
+        if (wb >= nwb) break;
+        const uint64_t j = (uint64_t)wb * WAVE + lane;
+        const uint32_t r = long_rows[j < n_long ? j : n_long - 1];      // (requested early: needed only at the very end)
+        const unsigned long long *mrow = wmask + (uint64_t)wb * np_pad;
+        const uint32_t *brow = wbase + (uint64_t)wb * np_pad;
+        double s = 0.0;
+        for (uint32_t k0 = 0; k0 < npieces; k0 += WAVE) {
+            const bool in = k0 + lane < npieces;
+            const unsigned long long mk = in ? mrow[k0 + lane] : 0ull;
+            const uint32_t bs = in ? brow[k0 + lane] : 0u;
+            const uint32_t nk = npieces - k0 < (uint32_t)WAVE ? npieces - k0 : (uint32_t)WAVE;
+            for (uint32_t kk = 0; kk < nk; kk += RU) {
+                double v[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int src = (int)(kk + u < nk ? kk + u : nk - 1);                          // wave-uniform
+                    const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mk >> 32), src) << 32) |
+                                                 (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, src);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bs, src);
+                    const bool have = kk + u < nk && ((m >> lane) & 1ull);
+                    v[u] = have ? partial[b + (uint32_t)__popcll(m & below)] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < RU; ++u) s += v[u];              // ascending pieces (absent ones add +0.0)
+            }
+        }
+        if (j < n_long) {
+            if constexpr (ACC) y[r] = y[r] + s;
+            else y[r] = s;
+        }
+    }
+}
+
+}  // namespace
+}  // namespace sprs_hip

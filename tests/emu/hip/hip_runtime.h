@@ -56,6 +56,8 @@ hipError_t hipGetDeviceCount(int *n);
 hipError_t hipGetDevice(int *d);
 hipError_t hipSetDevice(int d);
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b);
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }   // a small "chip": several hot workgroups
 struct hipemuEvent;
 typedef hipemuEvent *hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
@@ -176,6 +178,9 @@ inline void __threadfence_block() {}
 #endif
 inline long long __double_as_longlong(double v) { long long b; memcpy(&b, &v, 8); return b; }
 inline double __longlong_as_double(long long b) { double v; memcpy(&v, &b, 8); return v; }
+inline int __double2loint(double v) { long long b; memcpy(&b, &v, 8); return (int)(unsigned)(b & 0xFFFFFFFFll); }
+inline int __double2hiint(double v) { long long b; memcpy(&b, &v, 8); return (int)(unsigned)((unsigned long long)b >> 32); }
+inline double __hiloint2double(int hi, int lo) { long long b = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo); double v; memcpy(&v, &b, 8); return v; }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }

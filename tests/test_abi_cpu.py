@@ -58,6 +58,17 @@ def test_version_and_options():
         sprs_amd.set_option("spmv_xcs", 7)
 
 
+def test_release_library_rejects_developer_switches():
+    """spgemm_debug / spmv_xmask (timing experiments with WRONG results) and spgemm_prof exist only in builds with
+    -DSPRS_HIP_DEVTOOLS (make DEVTOOLS=1); the library the product ships is built without and must refuse them."""
+    import sprs_amd
+    assert sprs_amd.get_option("devtools") == 0, "the in-tree libsprs_hip.so must be the release build"
+    for name, val in (("spgemm_debug", 1), ("spmv_xmask", 1023), ("spgemm_prof", 1)):
+        with pytest.raises(sprs_amd.SprsHipError) as e:
+            sprs_amd.set_option(name, val)
+        assert e.value.status == sprs_amd._ffi.INVALID_ARG and "developer switch" in str(e.value)
+
+
 def test_argument_checks_need_no_device():
     from sprs_amd import _ffi
     h = C.c_void_p()

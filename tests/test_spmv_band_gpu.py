@@ -4,7 +4,7 @@ test_spmv_gpu.py: <= 1e-10 relative (north star), empty rows exact.  Reference s
 prod::mul_acc_mat_vec_csr, sprs/src/sparse/prod.rs:103-127.
 
 The shapes below are chosen to hit the plan's corner cases at sizes the oracle handles in seconds:
-rows spanning several hot tiles (carries), tiles with more row segments than one staging round holds,
+rows spanning several hot tiles, ranges and workgroups (register and head carries), tiles full of row starts,
 hot slices without entries, a cold rest in several label ranges, every index-width combination."""
 import numpy as np
 import pytest
@@ -26,9 +26,9 @@ def hip():
 
 
 class band_options:
-    def __init__(self, hip, hot, phases, group=0, split=0):
-        self.hip, self.vals = hip, dict(spmv_band=1, spmv_band_hot=hot, spmv_band_phases=phases,
-                                        spmv_band_group=group, spmv_band_split=split)
+    def __init__(self, hip, hot, phases, rounds=0, split=0, tile=0, cold_tiles=0):
+        self.hip, self.vals = hip, dict(spmv_band=1, spmv_band_hot=hot, spmv_band_phases=phases, spmv_band_rounds=rounds,
+                                        spmv_band_split=split, spmv_band_tile=tile, spmv_band_cold_tiles=cold_tiles)
 
     def __enter__(self):
         for k, v in self.vals.items():
@@ -70,25 +70,26 @@ def check_band(hip, shape, ip, ix, dt, seed=0, expect_kind=3):
 
 
 @pytest.mark.parametrize("idx,ptr", IDX_COMBOS + [(np.uint64, np.uint32)])
-@pytest.mark.parametrize("hot,phases", [(2, 1), (5, 3)])
-def test_rmat_vs_oracle(hip, idx, ptr, hot, phases):
+@pytest.mark.parametrize("hot,phases,tile", [(2, 1, 16384), (5, 3, 8192)])
+def test_rmat_vs_oracle(hip, idx, ptr, hot, phases, tile):
     from sprs_amd import gen
     n = 50000
     indptr, indices, data = gen.rmat_csr(n, 16)
     ip, ix, dt = indptr.numpy().astype(ptr), indices.numpy().astype(idx), data.numpy()
-    with band_options(hip, hot, phases):
+    with band_options(hip, hot, phases, tile=tile):
         check_band(hip, (n, n), ip, ix, dt)
 
 
 def test_hub_rows_and_many_segments(hip):
-    """3 dense rows (20 000 entries each: every hot slice sees rows longer than two tiles -> carries) and 7 000
-    rows of 33 entries (a hot tile holds thousands of row segments: more than one staging round), short and
-    empty rows in between."""
+    """3 dense rows (20 000 entries each: every hot slice sees rows that span several tiles, ranges and workgroups ->
+    register carries inside a range, head carries between ranges, runs of ranges without a row start) and 7 000 rows of
+    33 entries (tiles in which every lane holds several row starts), short and empty rows in between; one, three and
+    forty hot workgroups per CU, one to seven tiles per cold range."""
     lens = [0, 20000, 3, 0] + [33] * 3500 + [20000] + [1, 0, 31, 32] * 50 + [33] * 3500 + [20000, 0, 0, 7]
     shape, ip, ix, dt = ragged_csr(lens, 20000, seed=3)
-    for group in (1, 4):
-        with band_options(hip, 2, 2, group=group):
-            check_band(hip, shape, ip, ix, dt, seed=group)
+    for rounds, tile, ct in ((1, 8192, 4), (3, 16384, 1), (40, 8192, 7)):
+        with band_options(hip, 2, 2, rounds=rounds, tile=tile, cold_tiles=ct):
+            check_band(hip, shape, ip, ix, dt, seed=rounds)
 
 
 def test_split_and_empty_pieces(hip):
