@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--idx-bytes", type=int, default=8)
     ap.add_argument("--oracle", action="store_true", help="check the first configuration against the CPU oracle")
+    ap.add_argument("--repeat", type=int, default=1, help="run the whole list of configurations this many times, in rotation (run-to-run "
+                                                          "drift of a box is several per cent: compare medians)")
     ap.add_argument("configs", nargs="+")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -59,7 +61,7 @@ def main():
     for spec in args.configs:
         for kv in filter(None, spec.partition(":")[2].split(",")):
             DEFAULTS.setdefault(kv.split("=")[0], sprs_amd.get_option(kv.split("=")[0]))
-    for spec in args.configs:
+    for spec in list(args.configs) * args.repeat:
         name, _, rest = spec.partition(":")
         opts = dict(DEFAULTS)
         for kv in filter(None, rest.split(",")):

@@ -64,10 +64,10 @@ constexpr bool DEVTOOLS = false;
     X(spmv_band_tile, 0, 0, 16384, 0)   /* labels per hot slice = doubles of the x tile in LDS: 8192 or 16384 (0 = default 16384) */ \
     X(spmv_band_phases, 0, 0, 8, 0)     /* label ranges of the cold rest (0 = default 1), 8 hash pieces each */                   \
     X(spmv_band_split, 0, 0, INT64_MAX, 0) /* rows with at least this many entries are cut into pieces (0 = default 24) */        \
-    X(spmv_band_rounds, 0, 0, 64, 0)    /* workgroups of the hot kernel per CU, one after the other (0 = default 1: persistent) */ \
+    X(spmv_band_rounds, 0, 0, 64, 0)    /* workgroups of the hot kernel per CU, one after the other (0 = default 2) */ \
+    X(spmv_band_debug, 0, 0, 255, 1)    /* TIMING EXPERIMENTS ONLY (wrong results): hot kernel 1 no stores of the row sums, 2 one row start per lane, 4 none */ \
+    X(spmv_band_hot_run, 0, 0, 4096, 0) /* consecutive wave tiles per range of the hot kernel (0 = default 4); a workgroup streams 16 neighbouring ranges */ \
     X(spmv_band_cold_tiles, 0, 0, 64, 0) /* consecutive wave tiles per wave of the cold kernel (0 = default 4) */                 \
-    X(spmv_band_split_launch, 0, 0, 1, 0) /* profiling: short rows and cold pieces in two launches instead of one */              \
-    X(spmv_band_cold_waves, 0, 0, 8, 0) /* waves per SIMD the cold kernel is compiled for: 0/8 (64 VGPRs + 8 B scratch), 7 (72 VGPRs) */ \
     X(spmv_band_overlap, 0, 0, 2, 0)    /* cold pieces + short rows on a second stream beside the hot kernel: 0/1 on, 2 off */     \
     X(spmv_band_split_permute, 0, 0, 2, 0) /* with the overlap: hot labels of x gathered first, the rest scattered on the second stream: 0/1 on, 2 off */ \
     X(spmm_long_row, -1, -1, INT64_MAX, 0) /* SpMM: -1 default (0: all rows by chunks); L > 0: rows of <= L entries summed in entry order (reference bits, 3x slower) */ \

@@ -308,10 +308,11 @@ struct BandPlan {
     uint16_t *cid_hot = nullptr;
     uint32_t *cid_cold = nullptr;
     uint32_t *rowidx_all = nullptr, *tile_row_all = nullptr;
-    Range *ranges = nullptr;                       // every range of the plan: hot segments (16 each) first, then the cold pieces, the short piece
-    HotSeg *segs = nullptr;
+    Seg *segs = nullptr;                           // hot segments (workgroup by workgroup), then one segment per cold piece, the short piece
     uint32_t *wg_seg = nullptr;                    // hot workgroup b takes segments wg_seg[b] .. wg_seg[b + 1] - 1
-    uint32_t nranges = 0, nsegs = 0, hot_wgs = 0, cold_tiles = 4;
+    uint32_t nranges = 0, nsegs = 0, hot_wgs = 0, cold_tiles = 4, hot_run = 4;
+    void *spills = nullptr;                        // Spill records (device)
+    uint32_t nspills = 0;
     ColdGroup *groups = nullptr;
     unsigned long long *wmask = nullptr;           // per (64 long rows, piece): which rows have a partial
     uint32_t *wbase = nullptr;                     //                            and where the first one is
@@ -339,8 +340,8 @@ void band_free(BandPlan *bp) {
     drop(bp->cid_cold);
     drop(bp->rowidx_all);
     drop(bp->tile_row_all);
-    drop(bp->ranges);
     drop(bp->segs);
+    drop(bp->spills);
     drop(bp->wg_seg);
     drop(bp->groups);
     drop(bp->wmask);
@@ -408,6 +409,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     bp->n_long = (uint32_t)n_long;
     bp->n_short_rows = (uint32_t)n_short_rows;
     bp->cold_tiles = (uint32_t)(o.spmv_band_cold_tiles > 0 ? o.spmv_band_cold_tiles : 4);
+    bp->hot_run = (uint32_t)(o.spmv_band_hot_run > 0 ? o.spmv_band_hot_run : 4);
     // 128 slices of 16384 labels measured best on R-MAT 10M (profiles/r05*: sweep over 64 .. 256)
     uint64_t nh = o.spmv_band_hot > 0 ? (uint64_t)o.spmv_band_hot : 128;
     if (nh > (cols + XT - 1) / XT) nh = (cols + XT - 1) / XT;
@@ -568,7 +570,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     {   // ---- tables of the final reduction ---------------------------------------------------------------
         const uint64_t nwb = (n_long + WAVE - 1) / WAVE;
         bp->total_pairs = row_off;
-        bp->np_pad = (NP + 3u) & ~3u;
+        bp->np_pad = (NP + (uint32_t)RU - 1u) / (uint32_t)RU * (uint32_t)RU;
         const uint64_t slots = nwb * bp->np_pad;
         SPRS_TRY_HIP(hipMalloc((void **)&bp->wmask, (slots + WAVE) * 8));
         SPRS_TRY_HIP(hipMalloc((void **)&bp->wbase, (slots + WAVE) * 4));
@@ -596,15 +598,19 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
                        (const TileRowJob *)jobs_d.p);
     SPRS_TRY_HIP(hipGetLastError());
 
-    // ---- who walks what: hot segments (equal shares of the hot tiles per workgroup), ranges, cold launch groups ------------
-    std::vector<Range> ranges;
-    std::vector<HotSeg> segs;
+    // ---- who walks what: hot segments (equal shares of the hot tiles per workgroup), cold segments, launch groups ------------
+    std::vector<Seg> segs;
     std::vector<uint32_t> wg_seg(1, 0u);
+    uint32_t nranges = 0;
+    auto add_seg = [&](uint32_t piece, uint32_t tile0, uint32_t n, uint32_t run) {
+        segs.push_back(Seg{piece, tile0, n, nranges, run, 0u, 0u, 0u});
+        nranges += (n + run - 1) / run;
+    };
     if (hot_tiles) {
         int ncu = 0;
         SPRS_TRY_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, a->device));
         if (ncu < 1) ncu = 1;
-        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : 1;
+        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : 2;   // 2: median 1.048 against 1.072 ms with 1 (profiles/r05j)
         uint64_t nwg = (uint64_t)ncu * rounds;
         if (nwg > hot_tiles) nwg = hot_tiles;
         const uint64_t Q = (hot_tiles + nwg - 1) / nwg;           // wave tiles per workgroup
@@ -616,13 +622,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
             while (t < t_end) {
                 while (k_first + bp->host_pieces[k].ntiles <= t) k_first += bp->host_pieces[k++].ntiles;   // (slices without tiles are skipped)
                 const uint64_t s_end = std::min(t_end, k_first + bp->host_pieces[k].ntiles);
-                const uint32_t tile0 = (uint32_t)(t - k_first), n = (uint32_t)(s_end - t);
-                const uint32_t c = (n + HOT_WAVES - 1) / HOT_WAVES;
-                segs.push_back(HotSeg{k, (uint32_t)ranges.size()});
-                for (uint32_t w = 0; w < (uint32_t)HOT_WAVES; ++w) {
-                    const uint32_t w0 = w * c;
-                    ranges.push_back(Range{k, tile0 + w0, w0 < n ? std::min(c, n - w0) : 0u, 0u});
-                }
+                add_seg(k, (uint32_t)(t - k_first), (uint32_t)(s_end - t), bp->hot_run);
                 t = s_end;
             }
             wg_seg.push_back((uint32_t)segs.size());
@@ -631,18 +631,16 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     }
     for (uint32_t k = (uint32_t)nh; k <= NP; ++k) {
         BandPiece &d = bp->host_pieces[k];
-        d.range0 = (uint32_t)ranges.size();
-        for (uint32_t t = 0; t < d.ntiles; t += bp->cold_tiles) ranges.push_back(Range{k, t, std::min(bp->cold_tiles, d.ntiles - t), 0u});
+        d.range0 = nranges;
+        if (d.ntiles) add_seg(k, 0u, d.ntiles, bp->cold_tiles);
     }
-    bp->nranges = (uint32_t)ranges.size();
+    bp->nranges = nranges;
     bp->nsegs = (uint32_t)segs.size();
-    SPRS_TRY_HIP(hipMalloc((void **)&bp->ranges, (ranges.size() + 1) * sizeof(Range)));
-    SPRS_TRY_HIP(hipMalloc((void **)&bp->segs, (segs.size() + 1) * sizeof(HotSeg)));
+    SPRS_TRY_HIP(hipMalloc((void **)&bp->segs, (segs.size() + 1) * sizeof(Seg)));
     SPRS_TRY_HIP(hipMalloc((void **)&bp->wg_seg, wg_seg.size() * 4));
-    if (!ranges.empty()) SPRS_TRY_HIP(hipMemcpyAsync(bp->ranges, ranges.data(), ranges.size() * sizeof(Range), hipMemcpyHostToDevice, stream));
-    if (!segs.empty()) SPRS_TRY_HIP(hipMemcpyAsync(bp->segs, segs.data(), segs.size() * sizeof(HotSeg), hipMemcpyHostToDevice, stream));
+    if (!segs.empty()) SPRS_TRY_HIP(hipMemcpyAsync(bp->segs, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice, stream));
     SPRS_TRY_HIP(hipMemcpyAsync(bp->wg_seg, wg_seg.data(), wg_seg.size() * 4, hipMemcpyHostToDevice, stream));
-    bp->bytes += ranges.size() * sizeof(Range) + segs.size() * sizeof(HotSeg);
+    bp->bytes += segs.size() * sizeof(Seg);
 
     std::vector<ColdGroup> groups;
     uint32_t blocks = 0;
@@ -665,6 +663,23 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     if (bp->ngroups) {
         SPRS_TRY_HIP(hipMalloc((void **)&bp->groups, groups.size() * sizeof(ColdGroup)));
         SPRS_TRY_HIP(hipMemcpyAsync(bp->groups, groups.data(), groups.size() * sizeof(ColdGroup), hipMemcpyHostToDevice, stream));
+    }
+    // ---- rows that run on from one range into the next: one record per run -----------------------------------------------
+    if (nranges) {
+        TmpBuf pcs_d, poff_d, cnt_d;
+        SPRS_TRY_HIP(pcs_d.alloc(bp->host_pieces.size() * sizeof(BandPiece)));
+        SPRS_TRY_HIP(poff_d.alloc(bp->pair_off.size() * 8));
+        SPRS_TRY_HIP(cnt_d.alloc(4));
+        SPRS_TRY_HIP(hipMemcpyAsync(pcs_d.p, bp->host_pieces.data(), bp->host_pieces.size() * sizeof(BandPiece), hipMemcpyHostToDevice, stream));
+        SPRS_TRY_HIP(hipMemcpyAsync(poff_d.p, bp->pair_off.data(), bp->pair_off.size() * 8, hipMemcpyHostToDevice, stream));
+        SPRS_TRY_HIP(hipMemsetAsync(cnt_d.p, 0, 4, stream));
+        SPRS_TRY_HIP(hipMalloc(&bp->spills, ((uint64_t)nranges + 1) * sizeof(Spill)));     // at most one per range
+        hipLaunchKernelGGL(bp_spill_kernel, dim3((nranges + 255) / 256), dim3(256), 0, stream, (const Seg *)bp->segs, bp->nsegs, nranges,
+                           (const BandPiece *)pcs_d.p, (const uint64_t *)poff_d.p, bp->nh, (const uint16_t *)bp->cid_hot,
+                           (const uint32_t *)bp->cid_cold, (Spill *)bp->spills, (unsigned int *)cnt_d.p);
+        SPRS_TRY_HIP(hipGetLastError());
+        SPRS_TRY_HIP(hipMemcpy(&bp->nspills, cnt_d.p, 4, hipMemcpyDeviceToHost));
+        bp->bytes += (uint64_t)bp->nspills * sizeof(Spill);
     }
     SPRS_TRY_HIP(hipStreamSynchronize(stream));   // plan complete, temporaries (and the host vectors above) may go
     if (getenv("SPRS_HIP_DEBUG")) {
@@ -735,7 +750,7 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         hipLaunchKernelGGL(band_gather_hot_kernel, dim3((bp->hot_labels + 255) / 256), dim3(256), 0, stream, x,
                            (const uint32_t *)bp->inv_hot, bp->hot_labels, sc->xp);
     else
-        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, stream, x,
+        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, stream, x,
                            (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, 0u);
     SPRS_TRY_HIP(hipGetLastError());
     if (overlap) {
@@ -743,50 +758,56 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux, sc->fork, 0));
     }
     if (split_permute) {
-        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, cstream, x,
+        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, cstream, x,
                            (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, bp->hot_labels);
         SPRS_TRY_HIP(hipGetLastError());
     }
     if (bp->cold_blocks) {
-        // one launch for the cold pieces and the short rows; option spmv_band_split_launch: two launches (profiling)
-        uint32_t cut = bp->cold_blocks;
-        if (options().spmv_band_split_launch && bp->has_short_group) cut = bp->short_first_block;
+        // two launches: the cold pieces of the long rows (partial sums out), then the short rows (y out)
+        const uint32_t cut = bp->has_short_group ? bp->short_first_block : bp->cold_blocks;
         for (uint32_t part = 0; part < 2; ++part) {
             const uint32_t b0 = part ? cut : 0u, nb = part ? bp->cold_blocks - cut : cut;
             if (!nb) continue;
-#define SPRS_COLD(ACCV, POL)                                                                                              \
-    hipLaunchKernelGGL((band_cold_kernel<ACCV, POL>), dim3(nb), dim3(CNT), 0, cstream, (const BandPiece *)sc->pieces,          \
+#define SPRS_COLD(ACCV, TOYV)                                                                                               \
+    hipLaunchKernelGGL((band_cold_kernel<ACCV, TOYV>), dim3(nb), dim3(CNT), 0, cstream, (const BandPiece *)sc->pieces,          \
                        (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,                             \
                        (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, sc->carry, b0, bp->cold_tiles)
-            const bool w8 = options().spmv_band_cold_waves != 7;
-            if (acc) {
-                if (w8) SPRS_COLD(true, 8);
-                else SPRS_COLD(true, 7);
-            } else {
-                if (w8) SPRS_COLD(false, 8);
-                else SPRS_COLD(false, 7);
-            }
+            if (!part) SPRS_COLD(false, false);
+            else if (acc) SPRS_COLD(true, true);
+            else SPRS_COLD(false, true);
 #undef SPRS_COLD
             SPRS_TRY_HIP(hipGetLastError());
         }
     }
     if (overlap) SPRS_TRY_HIP(hipEventRecord(sc->join, sc->aux));
     if (bp->hot_wgs) {
+        const uint32_t lds = hot_lds_bytes(bp->xt_log2);
+#ifndef SPRS_HIP_EMU
+        static std::once_flag once;                                  // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
+        hipError_t attr_err = hipSuccess;
+        std::call_once(once, [&] {
+            attr_err = hipFuncSetAttribute((const void *)band_hot_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds_bytes(13));
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute((const void *)band_hot_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds_bytes(14));
+        });
+        SPRS_TRY_HIP(attr_err);
+#endif
         if (bp->xt_log2 == 13)
-            hipLaunchKernelGGL((band_hot_kernel<13>), dim3(bp->hot_wgs), dim3(HOT_THREADS), 0, stream, (const BandPiece *)sc->pieces,
-                               (const HotSeg *)bp->segs, (const uint32_t *)bp->wg_seg, (const Range *)bp->ranges,
-                               (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry);
+            hipLaunchKernelGGL((band_hot_kernel<13>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
+                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg,
+                               (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry,
+                               (uint32_t)options().spmv_band_debug);
         else
-            hipLaunchKernelGGL((band_hot_kernel<14>), dim3(bp->hot_wgs), dim3(HOT_THREADS), 0, stream, (const BandPiece *)sc->pieces,
-                               (const HotSeg *)bp->segs, (const uint32_t *)bp->wg_seg, (const Range *)bp->ranges,
-                               (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry);
+            hipLaunchKernelGGL((band_hot_kernel<14>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
+                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg,
+                               (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry,
+                               (uint32_t)options().spmv_band_debug);
         SPRS_TRY_HIP(hipGetLastError());
     }
     if (overlap) SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->join, 0));
-    if (bp->nranges) {
-        hipLaunchKernelGGL(band_carry_kernel, dim3((bp->nranges + 255) / 256), dim3(256), 0, stream, (const Range *)bp->ranges,
-                           bp->nranges, (const BandPiece *)sc->pieces, bp->nh, (const uint16_t *)bp->cid_hot,
-                           (const uint32_t *)bp->cid_cold, (const double *)sc->carry, y);
+    if (bp->nspills) {
+        hipLaunchKernelGGL(band_carry_kernel, dim3((bp->nspills + 255) / 256), dim3(256), 0, stream, (const Spill *)bp->spills,
+                           bp->nspills, (const double *)sc->carry, sc->partial, y);
         SPRS_TRY_HIP(hipGetLastError());
     }
     const uint32_t nwb = (bp->n_long + WAVE - 1) / WAVE;
@@ -795,11 +816,11 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     if (acc)
         hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, stream, (const double *)sc->partial,
                            (const unsigned long long *)bp->wmask, (const uint32_t *)bp->wbase,
-                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->npieces, bp->np_pad, nwb);
+                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->np_pad, nwb);
     else
         hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, stream, (const double *)sc->partial,
                            (const unsigned long long *)bp->wmask, (const uint32_t *)bp->wbase,
-                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->npieces, bp->np_pad, nwb);
+                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->np_pad, nwb);
     SPRS_TRY_HIP(hipGetLastError());
     return SPRS_HIP_OK;
 }

@@ -11,8 +11,8 @@
 //   * a RANGE is a run of consecutive tiles walked by ONE wave: the sum of the row that is open at the end of a tile stays
 //     in a register and is completed in the next tile, so that only the row open at the START of a range needs a fix-up
 //     (band_carry_kernel: one record per range instead of one per tile; round 2 had 630 000 spills per SpMV, now ~25 000);
-//   * sums are written straight from the registers to where they belong (partial sum of a (row, piece) pair, or y for the
-//     short rows): the LDS only holds the x tile.
+//   * the sums of the rows that end in a tile are consecutive compact rows: they leave the wave coalesced through a 1 KiB
+//     LDS window per wave (band_tile_sums).
 #pragma once
 #include "spmv_shared.hpp"
 
@@ -45,14 +45,15 @@ struct BandPiece {
     uint32_t pad;
 };
 
-// A run of consecutive tiles of one piece walked by one wave.
-struct Range {
-    uint32_t piece, tile0, ntiles, pad;
-};
-
-// A part of a hot slice taken by one workgroup: 16 ranges (one per wave; the last ones may be empty), x tile loaded once.
-struct HotSeg {
-    uint32_t piece, range0;
+// A SEGMENT is a run of consecutive tiles of one piece, cut into RANGES of `run` tiles (the last one may be shorter): range r
+// of the segment = tiles tile0 + r * run ...; a range is walked by ONE wave.  Hot slices: a segment is the part of a slice
+// one workgroup takes (x tile loaded once), its 16 waves take the ranges r = wave, wave + 16, ... — at any time the
+// workgroup streams 16 neighbouring ranges, i.e. one contiguous window of the arrays.  (First version of this kernel: one
+// long range per wave; the 4096 waves of the chip then streamed 4096 windows a constant 557 056 bytes = 17 x 32 KiB apart
+// and hit the same memory channels in step: 909 us against 585 us for the same bytes, profiles/r05b.)
+// Cold pieces and the short piece are one segment each.  Ranges are numbered segment after segment: carry[range0 + r].
+struct Seg {
+    uint32_t piece, tile0, ntiles, range0, run, pad0, pad1, pad2;
 };
 
 struct ColdGroup {              // a run of blocks of the cold launch
@@ -63,8 +64,10 @@ struct ColdGroup {              // a run of blocks of the cold launch
 // LDS counter as well (round 2, found in the ISA): the kernels retype what they load as GLOBAL memory.
 #ifdef SPRS_HIP_EMU
 #define SPRS_GLOBAL_AS
+#define SPRS_HOT_WAVES_ATTR
 #else
 #define SPRS_GLOBAL_AS __attribute__((address_space(1)))
+#define SPRS_HOT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
 struct PieceView {
     const SPRS_GLOBAL_AS uint32_t *rowidx, *tile_row;
@@ -167,21 +170,58 @@ __device__ __forceinline__ double band_read_lane63(double v) {
 // Order of the additions inside a row: entry order inside a lane, lanes in order, tiles in order — fixed by the plan,
 // the same in every run (no float atomics anywhere in the SpMV).
 // ---------------------------------------------------------------------------------------------
-template <typename Emit>
+// The sums leave the wave COALESCED: the rows that end inside a tile are consecutive compact rows (R0 - 1 .. R0 + nf - 2),
+// so the lanes park their sums in a small LDS window of the wave (STG doubles, by row) and the wave then writes the
+// window out, lane = row.  (Stores straight from the lanes that hold the sums — eight masked 8-byte stores per tile at
+// scattered addresses — cost the hot kernel 375 us for 0.32 GB of partial sums: 880 against 505 us without them,
+// profiles/r05d.)  Tiles with more row ends than the window take several passes.
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave complete in order; this keeps the COMPILER from moving them across the hand-over
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int STG = 128;
+constexpr uint32_t hot_lds_bytes(uint32_t xt_log2) { return ((1u << xt_log2) + (uint32_t)HOT_WAVES * 128u) * 8u; }     // doubles of a wave's staging window: hot 16 x 1 KiB + x tile 128 KiB leave 16 KiB of LDS to the cold workgroups
+
+// What band_tile_sums leaves in the wave's LDS window for a LATER flush: the hot kernel writes a tile's sums out after it
+// has waited for the next tile's loads — a store issued right before that wait is waited for as well (loads and stores
+// share the counter on this chip), which exposed the whole store latency once per tile (profiles/r05f: 140 us).
+struct Pending {
+    uint32_t cnt = 0;           // sums parked in the window
+    uint32_t row0 = 0;          // compact row of the first one
+    bool first_to_carry = false;   // the first one belongs to the row that was open when the range began
+};
+
+template <typename Out>
+__device__ __forceinline__ void band_flush(Pending &pd, uint32_t lane, SPRS_GLOBAL_AS double *carry, const double *stage, Out out) {
+    for (uint32_t j = lane; j < pd.cnt; j += WAVE) {
+        const double v = stage[j];
+        if (j == 0 && pd.first_to_carry) *carry = v;
+        else out(pd.row0 + j, v);
+    }
+    wave_lds_fence();                                                   // read before the next window / tile overwrites it
+    pd.cnt = 0;
+}
+
+// DEFER: the last window of the tile stays parked (pd) for band_flush; otherwise everything is written out here.
+template <bool DEFER, typename Out>
 __device__ __forceinline__ void band_tile_sums(const double (&pr)[EPL], uint32_t fb, uint32_t lane, uint32_t R0, double &open, bool &mine,
-                                               uint32_t &last, SPRS_GLOBAL_AS double *carry, Emit emit) {
+                                               uint32_t &last, SPRS_GLOBAL_AS double *carry, double *stage, Pending &pd, Out out) {
     const uint32_t nfl = (uint32_t)__popc(fb);                          // rows starting in this lane
     const uint32_t incl = band_scan_incl_u32(nfl, lane);
     const uint32_t prefix = incl - nfl;                                 // rows starting in lower lanes
     const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
-    // ---- serial fold of the lane's entries: rows that start AND end inside the lane are complete at once ----------
+    // ---- serial fold of the lane's entries: ev[q] = sum of the run that ends at the row start of entry q ------------
+    double ev[EPL];
     double run = 0.0, head = 0.0;
     uint32_t seen = 0;
 #pragma unroll
     for (int q = 0; q < EPL; ++q) {
+        ev[q] = run;                                                    // (only read where entry q starts a row)
         if ((fb >> q) & 1u) {
             if (seen == 0) head = run;                                  // the run that was open when the lane began ends here
-            else emit(R0 + prefix + seen - 1, run);
             run = 0.0;
             ++seen;
         }
@@ -193,10 +233,22 @@ __device__ __forceinline__ void band_tile_sums(const double (&pr)[EPL], uint32_t
     band_seg_scan(S, F, lane);
     double before = band_lane_below(S, lane);                           // open run at the end of the lane below
     if (prefix == 0) before = open + before;                            // no row has started in the tile so far: the range's open row
-    if (seen) {
-        const double v = before + head;                                 // the run that ends at this lane's first row start
-        if (prefix == 0 && !mine) *carry = v;                           // ... began before the range
-        else emit(R0 + prefix - 1, v);                                  // (prefix == 0: the row open since an earlier tile of the range)
+    const double vhead = before + head;                                 // the run that ends at this lane's first row start
+    // ---- out, window by window: row end number o of the tile (o = 0: the range's open row) is compact row R0 - 1 + o ----
+    for (uint32_t lo = 0; lo < nf; lo += STG) {                         // wave-uniform
+#pragma unroll
+        for (int q = 0; q < EPL; ++q) {
+            if ((fb >> q) & 1u) {
+                const uint32_t below = fb & ((1u << q) - 1u);
+                const uint32_t o = prefix + (uint32_t)__popc(below) - lo;
+                if (o < (uint32_t)STG) stage[o] = below ? ev[q] : vhead;
+            }
+        }
+        wave_lds_fence();
+        pd.cnt = nf - lo < (uint32_t)STG ? nf - lo : (uint32_t)STG;
+        pd.row0 = R0 - 1u + lo;
+        pd.first_to_carry = lo == 0 && !mine;                           // ... began before the range
+        if (!DEFER || lo + STG < nf) band_flush(pd, lane, carry, stage, out);
     }
     const double s63 = band_read_lane63(S);
     open = nf ? s63 : open + s63;
@@ -215,19 +267,28 @@ __device__ __forceinline__ void band_tile_sums(const double (&pr)[EPL], uint32_t
 // next segment.  (Round 2 launched one workgroup per 131 072 entries: 2 146 workgroups of unequal slices, 8.4 rounds
 // on 256 CUs and a tail of ~7 %; with equal shares every CU streams until the end.)
 // ---------------------------------------------------------------------------------------------
+// 96 VGPRs: the 4 waves per SIMD of this kernel then leave room for TWO 64-register waves of the gather kernels beside them
+// (at 98 it was one, and the cold launch crawled beside the hot one: 370 us instead of 86 alone, profiles/r05h)
 template <int XT_LOG2>
-__global__ __launch_bounds__(HOT_THREADS) void band_hot_kernel(const BandPiece *__restrict__ pieces, const HotSeg *__restrict__ segs,
-                                                               const uint32_t *__restrict__ wg_seg, const Range *__restrict__ ranges,
-                                                               const double *__restrict__ vals, const uint16_t *__restrict__ cid,
-                                                               const double *__restrict__ xp, double *__restrict__ carry) {
+__global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kernel(const BandPiece *__restrict__ pieces, const Seg *__restrict__ segs,
+                                                               const uint32_t *__restrict__ wg_seg, const double *__restrict__ vals,
+                                                               const uint16_t *__restrict__ cid, const double *__restrict__ xp,
+                                                               double *__restrict__ carry, uint32_t dbg) {
     constexpr int XT = 1 << XT_LOG2;
-    __shared__ __attribute__((aligned(16))) double xs[XT];
+    // dynamic LDS (hot_lds_bytes): with the size known at compile time the compiler sees that only 4 waves per SIMD fit and
+    // spends up to 128 registers; it is asked for 5 (96 registers) so that two gather waves fit beside each hot wave
+#ifdef SPRS_HIP_EMU
+    static double lds[XT + HOT_WAVES * STG];
+#else
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+#endif
+    double *xs = lds;                                                    // XT doubles: the x tile
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    double *stage = lds + XT + wave * STG;                              // the wave's window for outgoing sums
     const uint32_t s0 = wg_seg[blockIdx.x], s1 = wg_seg[blockIdx.x + 1];
     for (uint32_t s = s0; s < s1; ++s) {
-        const HotSeg seg = segs[s];
+        const Seg seg = segs[s];
         const PieceView d(pieces[seg.piece]);
-        const Range rg = ranges[seg.range0 + wave];
         if (s != s0) __syncthreads();                                    // every wave is done with the previous x tile
         {   // x tile of the slice -> LDS (xp is padded to a whole number of tiles)
             const dbl2 *src = (const dbl2 *)(xp + d.x0);
@@ -237,7 +298,8 @@ __global__ __launch_bounds__(HOT_THREADS) void band_hot_kernel(const BandPiece *
 #pragma unroll
             for (int q = 0; q < XT / (2 * HOT_THREADS); ++q) *(dbl2 *)&xs[2 * (q * HOT_THREADS + tid)] = v[q];
         }
-        // the first tile of the range is requested before the barrier
+        // the wave's tiles, in the order it walks them: ranges r = wave, wave + 16, ...; inside a range tile after tile
+        const uint32_t run = seg.run, n = seg.ntiles;
         dbl2 av[WPASS];
         u32x4 cw = {0u, 0u, 0u, 0u};
         uint32_t R0n = 0;
@@ -248,35 +310,78 @@ __global__ __launch_bounds__(HOT_THREADS) void band_hot_kernel(const BandPiece *
             cw = __builtin_nontemporal_load((const u32x4 *)(cid + g + lane * EPL));
             R0n = d.tile_row[w];
         };
-        const uint32_t tend = rg.tile0 + rg.ntiles;
-        if (rg.ntiles) request(rg.tile0);
+        uint32_t r = wave;                                               // current range
+        uint32_t t = r * run;                                            // current tile, relative to the segment
+        if (t < n) request(seg.tile0 + t);                               // the first tile is requested before the barrier
         __syncthreads();                                                 // xs complete
         double open = 0.0;
         bool mine = false;
         uint32_t last = 0;
-        SPRS_GLOBAL_AS double *cslot = (SPRS_GLOBAL_AS double *)carry + seg.range0 + wave;
-        for (uint32_t w = rg.tile0; w < tend; ++w) {                     // wave-uniform
+        Pending pd;
+        SPRS_GLOBAL_AS double *pd_slot = (SPRS_GLOBAL_AS double *)carry;
+        while (t < n) {                                                  // wave-uniform
+            const uint32_t w = seg.tile0 + t;
             const uint64_t base = (uint64_t)w * WT;
             const uint32_t cnt = d.nnz - base < (uint64_t)WT ? (uint32_t)(d.nnz - base) : (uint32_t)WT;
-            double pr[EPL];
+            double pr[EPL], xv[EPL];
             uint32_t fb = 0;
+            // all eight LDS gathers are issued before the first product needs one (a conditional read per entry compiles to
+            // eight branches with a full LDS wait each)
 #pragma unroll
             for (int p = 0; p < WPASS; ++p) {
                 const uint32_t c2 = cw[p];
-                const uint32_t i0 = lane * EPL + 2 * p;
-                pr[2 * p] = i0 < cnt ? av[p][0] * xs[c2 & (XT - 1)] : 0.0;
-                pr[2 * p + 1] = i0 + 1 < cnt ? av[p][1] * xs[(c2 >> 16) & (XT - 1)] : 0.0;
+                xv[2 * p] = xs[c2 & (XT - 1)];
+                xv[2 * p + 1] = xs[(c2 >> 16) & (XT - 1)];
                 fb |= ((c2 >> 15) & 1u) << (2 * p);
                 fb |= ((c2 >> 31) & 1u) << (2 * p + 1);
             }
+#pragma unroll
+            for (int p = 0; p < WPASS; ++p) {
+                pr[2 * p] = av[p][0] * xv[2 * p];
+                pr[2 * p + 1] = av[p][1] * xv[2 * p + 1];
+            }
+            if (cnt < (uint32_t)WT) {                                    // last tile of a slice (wave-uniform): the padding (value 0, id 0) must not
+#pragma unroll                                                           // turn an infinite x[first label] into a NaN
+                for (int q = 0; q < EPL; ++q) pr[q] = lane * EPL + q < cnt ? pr[q] : 0.0;
+            }
             const uint32_t R0 = R0n;
-            if (w + 1 < tend) request(w + 1);                            // the next tile streams while this one is summed
-            band_tile_sums(pr, fb, lane, R0, open, mine, last, cslot, [&](uint32_t r, double v) { d.out[r] = v; });
+            // the tile after this one: the next of the range, or the first of the wave's next range
+            const uint32_t rend = (r + 1) * run < n ? (r + 1) * run : n;
+            const bool range_ends = t + 1 >= rend;
+            const uint32_t tn = range_ends ? (r + HOT_WAVES) * run : t + 1;
+            SPRS_GLOBAL_AS double *cslot = (SPRS_GLOBAL_AS double *)carry + seg.range0 + r;
+            auto out = [&](uint32_t row, double v) {
+                if (DEVTOOLS && (dbg & 1u)) return;                      // no stores of the row sums
+                __builtin_nontemporal_store(v, &d.out[row]);              // read again by the reduction, a few GB of traffic later
+
+            };
+            if (pd.cnt) band_flush(pd, lane, pd_slot, stage, out);        // the previous tile's sums, before this tile's loads are asked for
+            if (tn < n) request(seg.tile0 + tn);                         // streams while this tile is summed
+            if constexpr (DEVTOOLS) {                                    // timing experiments (option spmv_band_debug): WRONG results
+                if (dbg & 2u) fb &= 0x01u;                               // at most one row start per lane
+                if (dbg & 4u) fb = 0;                                    // no row starts at all
+            }
+            if (DEVTOOLS && (dbg & 8u)) {
+                band_tile_sums<false>(pr, fb, lane, R0, open, mine, last, cslot, stage, pd, out);
+            } else {
+                band_tile_sums<true>(pr, fb, lane, R0, open, mine, last, cslot, stage, pd, out);
+                pd_slot = cslot;
+            }
+            if (range_ends) {
+                if (lane == 0) {
+                    if (mine) d.out[last] = open;                        // the row still open at the end of the range: its sum so far
+                    else *cslot = open;                                  // no row starts in the whole range: all of it belongs to an earlier row
+                }
+                open = 0.0;
+                mine = false;
+                r += HOT_WAVES;
+            }
+            t = tn;
         }
-        if (rg.ntiles && lane == 0) {
-            if (mine) d.out[last] = open;                                // the row still open at the end of the range: its sum so far
-            else *cslot = open;                                          // no row starts in the whole range: all of it belongs to an earlier row
-        }
+        if (pd.cnt) band_flush(pd, lane, pd_slot, stage, [&](uint32_t row, double v) {
+            if (DEVTOOLS && (dbg & 1u)) return;
+            d.out[row] = v;
+        });
     }
 }
 
@@ -289,22 +394,24 @@ __global__ __launch_bounds__(HOT_THREADS) void band_hot_kernel(const BandPiece *
 // cid[512 w + 256 p + 4 l + e].  Pieces start at multiples of 512 entries and are padded with (label 0, value 0).
 // The short piece (to_y) writes y[rowidx[r]] instead of a partial sum.
 // ---------------------------------------------------------------------------------------------
-// WPS = waves per SIMD the kernel is compiled for: 8 (64 VGPRs, a few dwords of scratch) or 7 (72 VGPRs, none).
-// (Non-temporal and device-scope gathers were measured slower in round 2 — 2.29 ms per SpMV / no change — and are gone.)
-template <bool ACC, int WPS>
-__global__ __launch_bounds__(CNT, WPS) void band_cold_kernel(const BandPiece *__restrict__ pieces, const ColdGroup *__restrict__ groups,
+// 8 waves per SIMD (64 VGPRs, 20 bytes of scratch): the gathers live on the number of waves in flight, and two such waves fit
+// beside each wave of the hot kernel.  (Non-temporal and device-scope gathers were measured slower in round 2.)
+template <bool ACC, bool TOY>
+__global__ __launch_bounds__(CNT, 8) void band_cold_kernel(const BandPiece *__restrict__ pieces, const ColdGroup *__restrict__ groups,
                                                         uint32_t ngroups, const double *__restrict__ vals,
                                                         const uint32_t *__restrict__ cid, const double *__restrict__ xp,
                                                         double *__restrict__ y, double *__restrict__ carry, uint32_t block0, uint32_t ct) {
     constexpr int WPB = CNT / WAVE;
+    __shared__ __attribute__((aligned(16))) double stage_s[WPB][STG];
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+    double *stage = stage_s[wave];
     const uint32_t bid = blockIdx.x + block0;
     uint32_t g = 0;
     while (g + 1 < ngroups && bid >= groups[g + 1].first_block) ++g;     // block-uniform
     const ColdGroup cg = groups[g];
     const uint32_t lb = bid - cg.first_block;
     const uint32_t pi = cg.first_piece + (cg.npieces == 1 ? 0u : (lb & 7u));
-    const uint32_t r = (cg.npieces == 1 ? lb : (lb >> 3)) * WPB + wave;  // range of the piece
+    const uint32_t r = (cg.npieces == 1 ? lb : (lb >> 3)) * WPB + wave;  // range of the piece (= of its segment)
     const PieceView d(pieces[pi]);
     const uint32_t t0 = r * ct;
     if (t0 >= d.ntiles) return;                                          // wave-uniform; no workgroup barrier below
@@ -325,16 +432,12 @@ __global__ __launch_bounds__(CNT, WPS) void band_cold_kernel(const BandPiece *__
     bool mine = false;
     uint32_t last = 0;
     SPRS_GLOBAL_AS double *cslot = (SPRS_GLOBAL_AS double *)carry + d.range0 + r;
-    const bool to_y = d.to_y != 0;
-    auto emit = [&](uint32_t row, double v) {
-        if (to_y) {
-            const uint32_t yr = d.rowidx[row];
-            if constexpr (ACC) y[yr] = y[yr] + v;                        // every compact row has entries: empty rows are never touched (prod.rs:120-126)
-            else y[yr] = v;
-        } else {
-            d.out[row] = v;
-        }
+    auto emit_y = [&](uint32_t row, double v) {
+        const uint32_t yr = d.rowidx[row];
+        if constexpr (ACC) y[yr] = y[yr] + v;                            // every compact row has entries: empty rows are never touched (prod.rs:120-126)
+        else y[yr] = v;
     };
+    auto emit_p = [&](uint32_t row, double v) { d.out[row] = v; };
     for (uint32_t w = t0; w < tend; ++w) {
         const uint64_t base = (uint64_t)w * WT;
         const uint32_t cnt = d.nnz - base < (uint64_t)WT ? (uint32_t)(d.nnz - base) : (uint32_t)WT;
@@ -343,73 +446,132 @@ __global__ __launch_bounds__(CNT, WPS) void band_cold_kernel(const BandPiece *__
 #pragma unroll
         for (int q = 0; q < EPL; ++q) {
             const uint32_t c = lw[q / 4][q % 4];
-            xv[q] = xp[c & ~ROW_START32];             // padding: label 0, value 0, never summed into a row
+            xv[q] = xp[c & ~ROW_START32];                                // padding: label 0, value 0, never summed into a row
             fb |= (c >> 31) << q;
         }
         double pr[EPL];
 #pragma unroll
-        for (int q = 0; q < EPL; ++q) pr[q] = lane * EPL + q < cnt ? av[q / 2][q % 2] * xv[q] : 0.0;
+        for (int q = 0; q < EPL; ++q) pr[q] = av[q / 2][q % 2] * xv[q];
+        if (cnt < (uint32_t)WT) {                                        // last tile of the piece (wave-uniform): see band_hot_kernel
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) pr[q] = lane * EPL + q < cnt ? pr[q] : 0.0;
+        }
         // (no prefetch of the next tile here: its 24 registers would halve the waves per SIMD, and the gathers live on those)
-        band_tile_sums(pr, fb, lane, R0n, open, mine, last, cslot, emit);
+        Pending pd;
+        if constexpr (TOY) band_tile_sums<false>(pr, fb, lane, R0n, open, mine, last, cslot, stage, pd, emit_y);
+        else band_tile_sums<false>(pr, fb, lane, R0n, open, mine, last, cslot, stage, pd, emit_p);
         if (w + 1 < tend) request(w + 1);
     }
     if (lane == 0) {
-        if (mine) emit(last, open);
-        else *cslot = open;
+        if (!mine) *cslot = open;
+        else if constexpr (TOY) emit_y(last, open);
+        else emit_p(last, open);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // The row that is open at the START of a range began in an earlier range: the part of it each range holds (its HEAD) was
-// left in carry[range].  One thread per range: the first range of a run of ranges that continue the same row adds their
-// heads, in range order, to that row's sum (a (row, piece) partial, or y for the short rows).  Which ranges have a head,
-// and whose, is read off the plan (the first entry's row-start flag, tile_row).
+// left in carry[range].  The first range of a run of ranges that continue the same row adds their heads, in range order,
+// to that row's sum (a (row, piece) partial, or y for the short rows).  Which ranges have a head, and whose, is read off the
+// plan (the first entry's row-start flag, tile_row) ONCE, when the plan is built: bp_spill_kernel leaves one record per run.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool range_has_head(const BandPiece &d, const Range &rg, const uint16_t *__restrict__ cid_hot,
-                                               const uint32_t *__restrict__ cid_cold, uint32_t nhot) {
-    const uint64_t e = d.ent0 + (uint64_t)rg.tile0 * WT;                 // entry 0 of lane 0 sits first in both layouts
-    return rg.piece < nhot ? !(cid_hot[e] & ROW_START) : !(cid_cold[e] & ROW_START32);
+struct RangeRef {
+    uint32_t piece, tile0;
+    bool valid;
+};
+
+__device__ __forceinline__ RangeRef range_of(const Seg *__restrict__ segs, uint32_t nsegs, uint32_t i) {
+    uint32_t lo = 0, hi = nsegs;                                         // last segment with range0 <= i
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (segs[mid].range0 <= i) lo = mid;
+        else hi = mid;
+    }
+    const Seg sg = segs[lo];
+    const uint32_t t = (i - sg.range0) * sg.run;
+    return RangeRef{sg.piece, sg.tile0 + t, t < sg.ntiles};
 }
 
-__global__ __launch_bounds__(256) void band_carry_kernel(const Range *__restrict__ ranges, uint32_t nranges,
-                                                         const BandPiece *__restrict__ pieces, uint32_t nhot,
-                                                         const uint16_t *__restrict__ cid_hot, const uint32_t *__restrict__ cid_cold,
-                                                         const double *__restrict__ carry, double *__restrict__ y) {
+__device__ __forceinline__ bool range_has_head(const BandPiece &d, uint32_t piece, uint32_t tile0, const uint16_t *__restrict__ cid_hot,
+                                               const uint32_t *__restrict__ cid_cold, uint32_t nhot) {
+    const uint64_t e = d.ent0 + (uint64_t)tile0 * WT;                    // entry 0 of lane 0 sits first in both layouts
+    return piece < nhot ? !(cid_hot[e] & ROW_START) : !(cid_cold[e] & ROW_START32);
+}
+
+// One record per run of ranges that continue one row, found once when the plan is built.
+struct Spill {
+    uint64_t dst;               // index into the partial sums, or row of y for the short piece
+    uint32_t first, n;          // carry slots first .. first + n - 1
+    uint32_t to_y, pad;
+};
+
+__global__ __launch_bounds__(256) void bp_spill_kernel(const Seg *__restrict__ segs, uint32_t nsegs, uint32_t nranges,
+                                                       const BandPiece *__restrict__ pieces, const uint64_t *__restrict__ pair_off,
+                                                       uint32_t nhot, const uint16_t *__restrict__ cid_hot,
+                                                       const uint32_t *__restrict__ cid_cold, Spill *__restrict__ spills,
+                                                       unsigned int *__restrict__ count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nranges) return;
-    const Range rg = ranges[i];
-    if (!rg.ntiles) return;
+    const RangeRef rg = range_of(segs, nsegs, i);
+    if (!rg.valid) return;
     const BandPiece d = pieces[rg.piece];
-    if (!range_has_head(d, rg, cid_hot, cid_cold, nhot)) return;
+    if (!range_has_head(d, rg.piece, rg.tile0, cid_hot, cid_cold, nhot)) return;
     const uint32_t row = d.tile_row[rg.tile0] - 1;                        // the row open at the start of the range (a piece begins with a row start)
-    // a leader has no predecessor that continues the same row
-    for (uint32_t j = i; j-- > 0;) {
-        const Range pj = ranges[j];
-        if (!pj.ntiles) continue;                                        // (waves of a short hot segment without tiles)
-        if (pj.piece == rg.piece && d.tile_row[pj.tile0] - 1 == row && range_has_head(d, pj, cid_hot, cid_cold, nhot)) return;
-        break;
+    // a leader has no predecessor that continues the same row (ranges of one piece follow each other in tile order)
+    if (i > 0) {
+        const RangeRef pj = range_of(segs, nsegs, i - 1);
+        if (pj.valid && pj.piece == rg.piece && d.tile_row[pj.tile0] - 1 == row && range_has_head(d, pj.piece, pj.tile0, cid_hot, cid_cold, nhot))
+            return;
     }
-    double *dst = d.to_y ? y + d.rowidx[row] : d.out + row;
+    uint32_t n = 1;
+    for (uint32_t j = i + 1; j < nranges; ++j, ++n) {
+        const RangeRef nj = range_of(segs, nsegs, j);
+        if (!nj.valid || nj.piece != rg.piece || d.tile_row[nj.tile0] - 1 != row || !range_has_head(d, nj.piece, nj.tile0, cid_hot, cid_cold, nhot))
+            break;
+    }
+    const unsigned int slot = atomicAdd(count, 1u);
+    spills[slot] = Spill{d.to_y ? (uint64_t)d.rowidx[row] : pair_off[rg.piece] + row, i, n, d.to_y, 0u};
+}
+
+// per SpMV: the heads of a record's ranges are added to the row's sum in range order
+__global__ __launch_bounds__(256) void band_carry_kernel(const Spill *__restrict__ spills, uint32_t nspills, const double *__restrict__ carry,
+                                                         double *__restrict__ partial, double *__restrict__ y) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nspills) return;
+    const Spill sp = spills[i];
+    double *dst = (sp.to_y ? y : partial) + sp.dst;
     double acc = *dst;
-    acc += carry[i];
-    for (uint32_t j = i + 1; j < nranges; ++j) {
-        const Range nj = ranges[j];
-        if (!nj.ntiles) continue;
-        if (nj.piece != rg.piece || d.tile_row[nj.tile0] - 1 != row || !range_has_head(d, nj, cid_hot, cid_cold, nhot)) break;
-        acc += carry[j];
-    }
+    for (uint32_t k = 0; k < sp.n; ++k) acc += carry[sp.first + k];
     *dst = acc;
 }
 
+// xp[label[c]] = x[c] for the labels from first_label on, y cleared: four consecutive columns / rows per thread (16-byte
+// loads; one column per thread left this kernel latency-bound beside the hot kernel: 360 us instead of 50, profiles/r05e)
 __global__ __launch_bounds__(256) void band_permute_kernel(const double *__restrict__ x, const uint32_t *__restrict__ perm,
                                                            uint64_t cols, double *__restrict__ xp, double *__restrict__ y_zero,
                                                            uint64_t rows, uint32_t first_label) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < cols) {
-        const uint32_t l = perm[j];
-        if (l >= first_label) xp[l] = x[j];     // labels below first_label were gathered by band_gather_hot_kernel
+    const uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j + 4 <= cols && (((uintptr_t)x | (uintptr_t)perm) & 15) == 0) {
+        const u32x4 l = *(const u32x4 *)(perm + j);
+        const dbl2 a = *(const dbl2 *)(x + j), b = *(const dbl2 *)(x + j + 2);
+        if (l[0] >= first_label) xp[l[0]] = a[0];     // labels below first_label were gathered by band_gather_hot_kernel
+        if (l[1] >= first_label) xp[l[1]] = a[1];
+        if (l[2] >= first_label) xp[l[2]] = b[0];
+        if (l[3] >= first_label) xp[l[3]] = b[1];
+    } else {
+        for (uint64_t c = j; c < cols && c < j + 4; ++c) {
+            const uint32_t l = perm[c];
+            if (l >= first_label) xp[l] = x[c];
+        }
     }
-    if (y_zero && j < rows) y_zero[j] = 0.0;
+    if (y_zero) {
+        if (j + 4 <= rows && ((uintptr_t)y_zero & 15) == 0) {
+            *(dbl2 *)(y_zero + j) = dbl2{0.0, 0.0};
+            *(dbl2 *)(y_zero + j + 2) = dbl2{0.0, 0.0};
+        } else {
+            for (uint64_t r = j; r < rows && r < j + 4; ++r) y_zero[r] = 0.0;
+        }
+    }
 }
 
 // The hot kernel only reads the labels of the hot slices: those are gathered first, through the inverse of the labelling
@@ -431,22 +593,36 @@ __global__ __launch_bounds__(256) void band_gather_hot_kernel(const double *__re
 // them out.  Round 2 split the pieces of a row block over the 4 waves of a workgroup and combined through LDS behind a
 // barrier — each wave was two dependent round trips long and the kernel ran at half the bandwidth of its traffic.
 // ---------------------------------------------------------------------------------------------
-constexpr int RU = 16;       // partials in flight per lane
+constexpr int RU = 16;       // partials in flight per lane; the table rows are padded to a multiple of it (absent pieces: mask 0)
+
+// lane's bit of a wave-uniform mask as a condition, and the number of mask bits below the lane
+__device__ __forceinline__ bool band_mask_bit(uint32_t m_lo, uint32_t m_hi, uint32_t lane) {
+#ifdef SPRS_HIP_EMU
+    return (((unsigned long long)m_hi << 32 | m_lo) >> lane) & 1ull;
+#else
+    (void)lane;
+    return __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)m_hi << 32) | m_lo);     // the mask becomes EXEC / VCC as it is
+#endif
+}
+__device__ __forceinline__ uint32_t band_mask_rank(uint32_t m_lo, uint32_t m_hi, uint32_t lane) {
+#ifdef SPRS_HIP_EMU
+    return (uint32_t)__popcll(((unsigned long long)m_hi << 32 | m_lo) & ((1ull << lane) - 1ull));
+#else
+    (void)lane;
+    return __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+#endif
+}
+
 template <bool ACC>
 __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restrict__ partial, const unsigned long long *__restrict__ wmask,
                                                           const uint32_t *__restrict__ wbase, const uint32_t *__restrict__ long_rows,
-                                                          double *__restrict__ y, uint32_t n_long, uint32_t npieces, uint32_t np_pad,
-                                                          uint32_t nwb) {
+                                                          double *__restrict__ y, uint32_t n_long, uint32_t np_pad, uint32_t nwb) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     // wave -> row block: block b runs on XCD b % 8 (observed; only speed depends on it): every XCD gets a CONTIGUOUS range
     // of row blocks (neighbouring row blocks read neighbouring partials of every piece, often the same 128-byte line)
-    const uint32_t gw = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;        // global wave
-    const uint32_t nwaves = gridDim.x * (blockDim.x / WAVE);
     const uint32_t wpb = blockDim.x / WAVE;
     const uint32_t xcd = blockIdx.x & 7u, inx = (blockIdx.x >> 3) * wpb + threadIdx.x / WAVE;   // wave number inside the XCD
-    const uint32_t per_xcd = (nwb + 7u) / 8u, waves_per_xcd = nwaves / 8u;
-    (void)gw;
-    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t per_xcd = (nwb + 7u) / 8u, waves_per_xcd = (gridDim.x >> 3) * wpb;
     for (uint32_t i = inx; i < per_xcd; i += waves_per_xcd) {            // wave-uniform
         const uint32_t wb = xcd * per_xcd + i;
         if (wb >= nwb) break;
@@ -455,21 +631,21 @@ __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restri
         const unsigned long long *mrow = wmask + (uint64_t)wb * np_pad;
         const uint32_t *brow = wbase + (uint64_t)wb * np_pad;
         double s = 0.0;
-        for (uint32_t k0 = 0; k0 < npieces; k0 += WAVE) {
-            const bool in = k0 + lane < npieces;
-            const unsigned long long mk = in ? mrow[k0 + lane] : 0ull;
+        for (uint32_t k0 = 0; k0 < np_pad; k0 += WAVE) {
+            const bool in = k0 + lane < np_pad;
+            const unsigned long long mk = in ? mrow[k0 + lane] : 0ull;   // lane l: the table row of piece k0 + l
             const uint32_t bs = in ? brow[k0 + lane] : 0u;
-            const uint32_t nk = npieces - k0 < (uint32_t)WAVE ? npieces - k0 : (uint32_t)WAVE;
-            for (uint32_t kk = 0; kk < nk; kk += RU) {
+            const uint32_t mk_lo = (uint32_t)mk, mk_hi = (uint32_t)(mk >> 32);
+#pragma unroll
+            for (int kk = 0; kk < WAVE; kk += RU) {
+                if (k0 + kk >= np_pad) break;                            // wave-uniform
                 double v[RU];
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
-                    const int src = (int)(kk + u < nk ? kk + u : nk - 1);                          // wave-uniform
-                    const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mk >> 32), src) << 32) |
-                                                 (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, src);
-                    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bs, src);
-                    const bool have = kk + u < nk && ((m >> lane) & 1ull);
-                    v[u] = have ? partial[b + (uint32_t)__popcll(m & below)] : 0.0;
+                    const uint32_t m_lo = (uint32_t)__builtin_amdgcn_readlane((int)mk_lo, kk + u);
+                    const uint32_t m_hi = (uint32_t)__builtin_amdgcn_readlane((int)mk_hi, kk + u);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bs, kk + u);
+                    v[u] = band_mask_bit(m_lo, m_hi, lane) ? partial[b + band_mask_rank(m_lo, m_hi, lane)] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < RU; ++u) s += v[u];              // ascending pieces (absent ones add +0.0)

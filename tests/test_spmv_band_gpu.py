@@ -26,9 +26,10 @@ def hip():
 
 
 class band_options:
-    def __init__(self, hip, hot, phases, rounds=0, split=0, tile=0, cold_tiles=0):
+    def __init__(self, hip, hot, phases, rounds=0, split=0, tile=0, cold_tiles=0, hot_run=0):
         self.hip, self.vals = hip, dict(spmv_band=1, spmv_band_hot=hot, spmv_band_phases=phases, spmv_band_rounds=rounds,
-                                        spmv_band_split=split, spmv_band_tile=tile, spmv_band_cold_tiles=cold_tiles)
+                                        spmv_band_split=split, spmv_band_tile=tile, spmv_band_cold_tiles=cold_tiles,
+                                        spmv_band_hot_run=hot_run)
 
     def __enter__(self):
         for k, v in self.vals.items():
@@ -83,12 +84,12 @@ def test_rmat_vs_oracle(hip, idx, ptr, hot, phases, tile):
 def test_hub_rows_and_many_segments(hip):
     """3 dense rows (20 000 entries each: every hot slice sees rows that span several tiles, ranges and workgroups ->
     register carries inside a range, head carries between ranges, runs of ranges without a row start) and 7 000 rows of
-    33 entries (tiles in which every lane holds several row starts), short and empty rows in between; one, three and
-    forty hot workgroups per CU, one to seven tiles per cold range."""
+    33 entries (tiles in which every lane holds several row starts), short and empty rows in between; one to forty
+    hot workgroups per CU, ranges of one tile up to a whole segment, one to seven tiles per cold range."""
     lens = [0, 20000, 3, 0] + [33] * 3500 + [20000] + [1, 0, 31, 32] * 50 + [33] * 3500 + [20000, 0, 0, 7]
     shape, ip, ix, dt = ragged_csr(lens, 20000, seed=3)
-    for rounds, tile, ct in ((1, 8192, 4), (3, 16384, 1), (40, 8192, 7)):
-        with band_options(hip, 2, 2, rounds=rounds, tile=tile, cold_tiles=ct):
+    for rounds, tile, ct, run in ((1, 8192, 4, 0), (3, 16384, 1, 1), (40, 8192, 7, 3), (2, 16384, 2, 1000)):
+        with band_options(hip, 2, 2, rounds=rounds, tile=tile, cold_tiles=ct, hot_run=run):
             check_band(hip, shape, ip, ix, dt, seed=rounds)
 
 
