@@ -160,9 +160,10 @@ def main():
     ap.add_argument("--workload", default="rmat10m")
     ap.add_argument("--idx-bytes", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", default="torch", choices=("torch", "lib"),
-                    help="N > 1: all-gather-v of y through torch.distributed (grouped send/recv on RCCL; default) or inside the "
-                         "library (sprs_hip_dist_*: sub-block pipeline, RCCL loaded by the library itself)")
+    ap.add_argument("--exchange", default="lib", choices=("torch", "lib"),
+                    help="N > 1: all-gather-v of y inside the library (sprs_hip_dist_*: sub-block pipeline, RCCL loaded by the "
+                         "library itself; default, what `value` times) or through torch.distributed (grouped send/recv on RCCL); "
+                         "the other route and the multiply without any exchange are timed after the K steps and reported beside it")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the short spgemm5 object")
     ap.add_argument("--permute-cols", type=int, default=0,
                     help="experiment: relabel the columns by a random permutation (seed given) before the run")
@@ -180,13 +181,21 @@ def main():
                          "then come from HBM, not from the 256 MiB Infinity Cache (SURVEY 8d, config 2)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -291,17 +300,36 @@ def main():
 
     sh = RowShardedSpMV((n, n), indptr, indices, data, local_spmv)
     libdist = None
-    if world > 1 and args.exchange == "lib":
-        from sprs_amd.dist import DistSpMV
-        rb = sh.block
-        libdist = DistSpMV((n, n), DeviceCsMat.wrap_torch((rb[0], rb[1]), rb[2], rb[3], rb[4]), sh.cuts, rank, world,
-                           unique_id=DistSpMV.broadcast_id(dev), nsub=2)
-        yv_all = DeviceVec.borrow(sh.y)
 
-        def lib_step(xv):
-            libdist.spmv(DeviceVec.borrow(xv), yv_all, stream=stream)
-            return sh.y
-        sh.step = lib_step
+    def torch_step(xv):                                 # multiply, then torch.distributed's grouped send/recv
+        sh.local_spmv(sh.block, xv, sh.y[sh.r0:sh.r1])
+        sh.exchange()
+        return sh.y
+
+    def multiply_only(xv):
+        sh.local_spmv(sh.block, xv, sh.y[sh.r0:sh.r1])
+        return sh.y
+
+    step = torch_step
+    if world > 1:
+        try:
+            from sprs_amd.dist import DistSpMV
+            rb = sh.block
+            libdist = DistSpMV((n, n), DeviceCsMat.wrap_torch((rb[0], rb[1]), rb[2], rb[3], rb[4]), sh.cuts, rank, world,
+                               unique_id=DistSpMV.broadcast_id(dev), nsub=2)
+            yv_all = DeviceVec.borrow(sh.y)
+        except Exception as e:                          # the library route needs librccl: say so, fall back to the torch route
+            if args.exchange == "lib" and rank == 0:
+                print("bench.py: library exchange unavailable (%s); timing the torch.distributed route" % repr(e)[:200], file=sys.stderr)
+            libdist = None
+
+    def lib_step(xv):                                   # multiply + exchange inside the library, sub-blocks pipelined
+        libdist.spmv(DeviceVec.borrow(xv), yv_all, stream=stream)
+        return sh.y
+
+    use_lib = libdist is not None and args.exchange == "lib"
+    if use_lib:
+        step = lib_step
     del indptr, indices, data   # only the rank's block stays resident
     torch.cuda.empty_cache()
 
@@ -311,7 +339,7 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        sh.step(x)
+        step(x)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -324,8 +352,8 @@ def main():
         if flush is not None:
             flush.add_(1.0)   # reads and writes 1 GiB: evicts L2 and the Infinity Cache; part of ms_per_step, not of the kernel events
         ev[s][0].record(stream)
-        if libdist is not None:
-            sh.step(x)                                  # multiply + exchange inside the library, pipelined
+        if use_lib:
+            lib_step(x)                                 # multiply + exchange inside the library, pipelined
             ev[s][1].record(stream)
         else:
             sh.local_spmv(sh.block, x, sh.y[sh.r0:sh.r1])   # kernel(s) on `stream`, bracketed by HIP events
@@ -342,6 +370,33 @@ def main():
         t_total = float(tt.item())
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     kern_avg_ms = float(np.mean(kern_ms))
+
+    # ---- N > 1: the other exchange route and the multiply alone, after the K timed steps (with and without the gather) ----
+    exchange_times = None
+    if world > 1:
+        import torch.distributed as dist
+
+        def timed_ms(fn, k):
+            torch.cuda.synchronize()
+            barrier()
+            t = time.perf_counter()
+            for _ in range(k):
+                fn(x)
+            torch.cuda.synchronize()
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return round(float(tt.item()) * 1e3 / k, 5)
+        k2 = max(3, args.steps // 2)
+        exchange_times = {"timed_route": "lib" if use_lib else "torch", "steps_each": k2}
+        for label, fn in (("multiply_only_ms", multiply_only), ("torch_route_ms", torch_step),
+                          ("lib_route_ms", lib_step if libdist is not None else None)):
+            try:
+                exchange_times[label] = timed_ms(fn, k2) if fn is not None else None
+            except Exception as e:                      # the headline line must not depend on a secondary measurement
+                exchange_times[label] = "failed: " + repr(e)[:120]
+        if isinstance(exchange_times.get("multiply_only_ms"), float) and use_lib:
+            kern_avg_ms = exchange_times["multiply_only_ms"]      # the roofline object prices the local multiply, not the exchange
 
     ms_per_step = t_total * 1e3 / args.steps
     gflops = 2.0 * nnz_total * args.steps / t_total / 1e9
@@ -387,7 +442,7 @@ def main():
             "rows": n, "cols": n, "nnz": nnz_total,
             "index_bytes": args.idx_bytes, "indptr_bytes": args.idx_bytes,
             "partition": ("cost-balanced (nnz + 8/row) contiguous row blocks x%d, direct all-gather-v of y (%s)" %
-                          (world, "sprs_hip_dist_*, RCCL inside the library" if args.exchange == "lib" else "torch.distributed grouped send/recv on RCCL"))
+                          (world, "sprs_hip_dist_*, RCCL inside the library" if use_lib else "torch.distributed grouped send/recv on RCCL"))
                          if world > 1 else "single GPU",
             "generate_s": round(gen_s, 2),
         },
@@ -408,6 +463,9 @@ def main():
             "cold_cache": bool(args.cold_cache),
         },
     }
+
+    if exchange_times is not None:
+        out["exchange"] = exchange_times
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on the host cores -------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -140,7 +140,13 @@ impl DeviceCsMat {
         let indices = widen(&ix_raw, ib);
         // the checked constructor: a few passes over the host copy, and no undefined behaviour if the device side ever
         // handed back something malformed
-        CsMatI::try_new_from_storage(storage, (rows, cols), indptr, indices, data).map_err(|e| format!("{:?}", e))
+        // (sprs has one checked constructor per storage — `try_new` / `try_new_csc`, csmat.rs:235-256; both hand the vectors
+        // back beside the StructureError, its fourth tuple element)
+        let built = match storage {
+            sprs::CompressedStorage::CSR => CsMatI::try_new((rows, cols), indptr, indices, data),
+            sprs::CompressedStorage::CSC => CsMatI::try_new_csc((rows, cols), indptr, indices, data),
+        };
+        built.map_err(|(_, _, _, e)| format!("{:?}", e))
     }
 }
 

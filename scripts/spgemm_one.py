@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 (C = A*A, R-MAT 1M x 1M ~8 nnz/row), NOTHING ELSE: generation + <products> products.  The profiling
+target of the SpGEMM counter passes (rocprofv3 --pmc serialises and instruments every dispatch: anything beside the
+product — parity checks over 3.3e9 entries, a second product — only makes the pass miss its time budget).
+usage: spgemm_one.py [products=1] [idx_bytes=8]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sprs_amd import gen, smmp                      # noqa: E402
+from sprs_amd.device import DeviceCsMat              # noqa: E402
+
+
+def main():
+    products = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    idx_bytes = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    dev = torch.device("cuda", 0)
+    n = 1_000_000
+    idt = torch.int64 if idx_bytes == 8 else torch.int32
+    indptr, indices, data = gen.rmat_csr(n, 8, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)
+    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    torch.cuda.synchronize()
+    times, c = [], None
+    for _ in range(products):
+        c = None
+        t0 = time.perf_counter()
+        c = smmp.mul_csr_csr(a, a)
+        torch.cuda.synchronize()
+        times.append(round(time.perf_counter() - t0, 4))
+    print(json.dumps({"products": products, "seconds": times, "nnz_c": int(c.nnz()), "idx_bytes": idx_bytes}))
+
+
+if __name__ == "__main__":
+    main()

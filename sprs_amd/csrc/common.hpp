@@ -170,6 +170,7 @@ struct sprs_hip_csmat {
     void *indices = nullptr;   // device, nnz entries
     double *data = nullptr;    // device, nnz entries
     bool owns = false;
+    bool one_shot = false;     // the handle multiplies once (sprs_hip_spmv_f64_host): plain plan, no copies of the matrix
     uint64_t cap_indices = 0, cap_data = 0;   // bytes of the owned blocks (>= what nnz needs: blocks come from the pool)
     int device = 0;
     std::recursive_mutex mu;   // guards plan / mm: held from the look-up (or rebuild) of a plan until the kernels that read it are launched

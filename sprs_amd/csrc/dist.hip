@@ -72,6 +72,28 @@ int32_t rccl(Rccl **out) {
                                 (R)->GetErrorString ? (R)->GetErrorString(r__) : "?", #expr);                       \
     } while (0)
 
+// Inside ncclGroupStart / ncclGroupEnd a failing call must not return at once: the group would stay open and every later
+// RCCL call of the process would be queued into it.  The first failure is kept, the group is closed, then it is reported.
+struct GroupStatus {
+    ncclResult_t first = 0;
+    const char *what = nullptr;
+    void note(ncclResult_t r, const char *expr) {
+        if (r != 0 && first == 0) {
+            first = r;
+            what = expr;
+        }
+    }
+};
+#define SPRS_GROUP_CALL(G, expr) (G).note((expr), #expr)
+
+int32_t close_group(Rccl *R, GroupStatus &g) {
+    const ncclResult_t e = R->GroupEnd();
+    g.note(e, "ncclGroupEnd");
+    if (g.first != 0)
+        SPRS_FAIL(SPRS_HIP_HIP_ERROR, "RCCL error %d (%s) in %s", g.first, R->GetErrorString ? R->GetErrorString(g.first) : "?", g.what);
+    return SPRS_HIP_OK;
+}
+
 }  // namespace
 
 }  // namespace sprs_hip
@@ -172,7 +194,9 @@ int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world
     }
     d->sub_starts.push_back(r0 + lrows);
     // ---- communicator, second stream, events -------------------------------------------------------------------------------
-    if (world > 1) {
+    // (a world of ONE with an id given goes through RCCL as well — an empty exchange: what a 1-GPU box can exercise of this path)
+    if (world > 1 || unique_id128) {
+        if (!unique_id128) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "multi-GPU: the RCCL unique id is missing (sprs_hip_dist_unique_id on one rank, handed to all)");
         Rccl *R = nullptr;
         SPRS_TRY(rccl(&R));
         NcclId id;
@@ -195,12 +219,15 @@ int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world
         } fr{dev};
         SPRS_TRY_HIP(hipMemcpy(dev + (size_t)rank * tab, mine.data(), tab * 8, hipMemcpyHostToDevice));
         SPRS_TRY_NCCL(R, R->GroupStart());
-        for (int32_t p = 0; p < world; ++p) {
-            if (p == rank) continue;
-            SPRS_TRY_NCCL(R, R->Send(dev + (size_t)rank * tab, tab, NCCL_FLOAT64, p, d->comm, d->comm_stream));   // (8-byte words)
-            SPRS_TRY_NCCL(R, R->Recv(dev + (size_t)p * tab, tab, NCCL_FLOAT64, p, d->comm, d->comm_stream));
+        {
+            GroupStatus g;
+            for (int32_t p = 0; p < world; ++p) {
+                if (p == rank) continue;
+                SPRS_GROUP_CALL(g, R->Send(dev + (size_t)rank * tab, tab, NCCL_FLOAT64, p, d->comm, d->comm_stream));   // (8-byte words)
+                SPRS_GROUP_CALL(g, R->Recv(dev + (size_t)p * tab, tab, NCCL_FLOAT64, p, d->comm, d->comm_stream));
+            }
+            SPRS_TRY(close_group(R, g));
         }
-        SPRS_TRY_NCCL(R, R->GroupEnd());
         SPRS_TRY_HIP(hipStreamSynchronize(d->comm_stream));
         std::vector<uint64_t> all((size_t)world * tab);
         SPRS_TRY_HIP(hipMemcpy(all.data(), dev, all.size() * 8, hipMemcpyDeviceToHost));
@@ -221,14 +248,14 @@ int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world
 // for the exchange.  Every rank must call this with the same sequence of calls (collective).
 int32_t dist_spmv(sprs_hip_dist *d, const double *x, double *y, hipStream_t stream) {
     Rccl *R = nullptr;
-    if (d->world > 1) SPRS_TRY(rccl(&R));
-    const size_t groups = d->world > 1 ? d->peer_starts[0].size() - 1 : d->sub.size();
+    if (d->comm) SPRS_TRY(rccl(&R));
+    const size_t groups = d->comm ? d->peer_starts[0].size() - 1 : d->sub.size();
     for (size_t s = 0; s < groups; ++s) {
         if (s < d->sub.size()) {
             sprs_hip_csmat *m = d->sub[s];
             if (m->rows) SPRS_TRY(spmv_f64(m, x, y + d->sub_starts[s], false, stream));
         }
-        if (d->world == 1) continue;
+        if (!d->comm) continue;
         // sub-block s is done: its rows go to every peer, the peers' sub-block s arrives — on the second stream, while the
         // caller's stream goes on with sub-block s + 1
         const size_t ev = s < d->done.size() ? s : d->done.size() - 1;
@@ -236,15 +263,16 @@ int32_t dist_spmv(sprs_hip_dist *d, const double *x, double *y, hipStream_t stre
         SPRS_TRY_HIP(hipStreamWaitEvent(d->comm_stream, d->done[ev], 0));
         const std::vector<uint64_t> &me = d->peer_starts[d->rank];
         SPRS_TRY_NCCL(R, R->GroupStart());
+        GroupStatus g;
         for (int32_t p = 0; p < d->world; ++p) {
             if (p == d->rank) continue;
             const std::vector<uint64_t> &pe = d->peer_starts[p];
-            if (me[s + 1] > me[s]) SPRS_TRY_NCCL(R, R->Send(y + me[s], me[s + 1] - me[s], NCCL_FLOAT64, p, d->comm, d->comm_stream));
-            if (pe[s + 1] > pe[s]) SPRS_TRY_NCCL(R, R->Recv(y + pe[s], pe[s + 1] - pe[s], NCCL_FLOAT64, p, d->comm, d->comm_stream));
+            if (me[s + 1] > me[s]) SPRS_GROUP_CALL(g, R->Send(y + me[s], me[s + 1] - me[s], NCCL_FLOAT64, p, d->comm, d->comm_stream));
+            if (pe[s + 1] > pe[s]) SPRS_GROUP_CALL(g, R->Recv(y + pe[s], pe[s + 1] - pe[s], NCCL_FLOAT64, p, d->comm, d->comm_stream));
         }
-        SPRS_TRY_NCCL(R, R->GroupEnd());
+        SPRS_TRY(close_group(R, g));
     }
-    if (d->world > 1) {
+    if (d->comm) {
         SPRS_TRY_HIP(hipEventRecord(d->gathered, d->comm_stream));
         SPRS_TRY_HIP(hipStreamWaitEvent(stream, d->gathered, 0));      // y is complete for whatever the caller queues next
     }

@@ -29,7 +29,8 @@
 // History of what was measured (profiles/): per-row windows + LDS accumulators 1.96 s -> 0.50 s on
 // config 5; bucket table, LDS staging, prefetch -> 0.454 s (waves owning column ranges, one k at a time); entry-parallel
 // expansion with order tags -> 0.22 s (round 1); row tasks, LDS-ordered adds, wave-per-row kernel -> 0.112 s (round 2).
-// Option spgemm_prof prints per-class / per-phase timings of the numeric kernels.
+// Developer builds (make DEVTOOLS=1): option spgemm_prof prints per-class / per-phase timings of the numeric kernels; the
+// release library compiles the timers and the printout out.
 #include "common.hpp"
 #include "scan.hpp"
 
@@ -629,7 +630,7 @@ __device__ __forceinline__ void lds_store_f64(double *p, double v) { *(lds_vf64 
 #endif
 
 __device__ __forceinline__ void token_wait(uint32_t *token, uint32_t turn) {
-    if (turn == 0xFFFFFFFFu) return;       // timing experiments only (option spgemm_debug & 1): no ordering
+    if (DEVTOOLS && turn == 0xFFFFFFFFu) return;       // timing experiments only (developer builds, option spgemm_debug & 1): no ordering
     while (lds_load_u32(token) != turn) SPRS_POLL_PAUSE();
     asm volatile("" ::: "memory");
     wave_sync_lds();      // (no instruction; in the CPU emulator, where the lanes of a wave run one after the other, it keeps lane 0
@@ -710,11 +711,11 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                                                              unsigned long long *__restrict__ prof,
                                                              const uint64_t *__restrict__ ub_dbg,
                                                              unsigned int *__restrict__ next_row) {
-    long long t_prev = prof ? (long long)wall_clock64() : 0;
+    long long t_prev = (DEVTOOLS && prof) ? (long long)wall_clock64() : 0;
     const long long t_kernel = t_prev;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto mark = [&](int phase) {                                        // lane 0's view of the phases (debug option spgemm_prof)
-        if (prof && (threadIdx.x & (WAVE - 1)) == 0) {
+        if (DEVTOOLS && prof && (threadIdx.x & (WAVE - 1)) == 0) {
             const long long now = (long long)wall_clock64();
             ph[phase] += (unsigned long long)(now - t_prev);
             t_prev = now;
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
         if constexpr (NUMERIC) out = off[t];
         uint32_t fresh = 0;
         mark(0);
-        const long long t_row = prof ? (long long)wall_clock64() : 0;
+        const long long t_row = (DEVTOOLS && prof) ? (long long)wall_clock64() : 0;
         for (uint64_t w = 0; w < nwin; ++w) {
             const uint64_t win_lo = w << MID_WL;
             const uint32_t win_s = cur, win_e = q0;
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             const uint64_t tot = wave_sum_u64(fresh);
             if (lane == 0) count[t] = tot;
         }
-        if (prof && lane == 0) {
+        if (DEVTOOLS && prof && lane == 0) {
             const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - t_row);
             const uint64_t u = ub_dbg[r];
             const int c = u < 2048 ? 0 : u < 8192 ? 1 : u < 32768 ? 2 : 3;
@@ -960,7 +961,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             atomicMax(&prof[16], dt);
         }
     }
-    if (prof && lane == 0) {
+    if (DEVTOOLS && prof && lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], ph[i]);
         atomicMax(&prof[17], (unsigned long long)((long long)wall_clock64() - t_kernel));   // longest wave
         atomicAdd(&prof[18], (unsigned long long)((long long)wall_clock64() - t_kernel));
@@ -1029,11 +1030,11 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                                                               unsigned long long *__restrict__ prof,
                                                               const uint64_t *__restrict__ ub_dbg) {
     using Cfg = LgCfg<WL>;
-    const long long t_begin = prof ? (long long)wall_clock64() : 0;     // debug option spgemm_prof: 100 MHz ticks per task
+    const long long t_begin = (DEVTOOLS && prof) ? (long long)wall_clock64() : 0;     // debug option spgemm_prof: 100 MHz ticks per task
     long long t_prev = t_begin;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto mark = [&](int phase) {                                        // thread 0's view of the phases
-        if (prof && threadIdx.x == 0) {
+        if (DEVTOOLS && prof && threadIdx.x == 0) {
             const long long now = (long long)wall_clock64();
             ph[phase] += (unsigned long long)(now - t_prev);
             t_prev = now;
@@ -1068,7 +1069,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const bool values = NUMERIC && c_data != nullptr;
     const bool lds_atomic = (flags & 1u) != 0;
     const bool retain_ok = values && (flags & 2u) != 0;
-    const bool no_order = (flags & 4u) != 0, no_emit = (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
+    const bool no_order = DEVTOOLS && (flags & 4u) != 0, no_emit = DEVTOOLS && (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
     const uint32_t ntok = 1u << ((flags >> 4) & 3u);                          // 1, 2 or 4 token chains (option spgemm_tokens)
     // a row whose k's fit one staged group: thread j keeps k_j, the bounds of B's row k_j and a_ik for the whole task
     const bool mine_k = one_group && tid < (uint32_t)(ae - as) && w_begin < w_end;
@@ -1249,7 +1250,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             mark(5);
         }
     }
-    if (prof && tid == 0) {
+    if (DEVTOOLS && prof && tid == 0) {
         prof[blockIdx.x] = (unsigned long long)((long long)wall_clock64() - t_begin);
         const double per = (double)ub_dbg[r] / (double)nt;
         const int cls = per < 8192 ? 0 : per < 32768 ? 1 : per < 131072 ? 2 : per < 524288 ? 3 : 4;
@@ -1571,7 +1572,7 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
                        pl->ntasks.as<uint64_t>(), (const uint8_t *)pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, \
                        c_values, pl->xcd_chunk, flags, prof.as<unsigned long long>(), pl->ub.as<uint64_t>())
         DevBuf prof;
-        if (options().spgemm_prof) {
+        if (DEVTOOLS && options().spgemm_prof) {
             SPRS_TRY_HIP(prof.alloc((n_large + 40) * 8));
             SPRS_TRY_HIP(hipMemsetAsync(prof.p, 0, (n_large + 40) * 8, stream));
         }
@@ -1583,7 +1584,7 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
             default: if (occ3) SPRS_LG_NUM(17, 6); else SPRS_LG_NUM(17, 4); break;
         }
 #undef SPRS_LG_NUM
-        if (prof.p) {
+        if (DEVTOOLS && prof.p) {
             // debug: 100 MHz ticks per large task, by block (= position in the launch order)
             SPRS_TRY_HIP(hipStreamSynchronize(stream));
             unsigned long long phs[40];
@@ -1644,7 +1645,7 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
         uint64_t g = (n_mid + MID_WAVES - 1) / MID_WAVES;
         if (g > 256 * 12) g = 256 * 12;
         DevBuf mprof;
-        if (options().spgemm_prof) {
+        if (DEVTOOLS && options().spgemm_prof) {
             SPRS_TRY_HIP(mprof.alloc(256));
             SPRS_TRY_HIP(hipMemsetAsync(mprof.p, 0, 256, stream));
         }
@@ -1659,7 +1660,7 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
             default: SPRS_MID_NUM(14); break;
         }
 #undef SPRS_MID_NUM
-        if (mprof.p) {
+        if (DEVTOOLS && mprof.p) {
             unsigned long long h[32];
             SPRS_TRY_HIP(hipStreamSynchronize(stream));
             (void)hipMemcpy(h, mprof.p, 256, hipMemcpyDeviceToHost);

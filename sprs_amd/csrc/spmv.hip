@@ -591,10 +591,10 @@ static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
     const PTR *ip = (const PTR *)a->indptr;
 
     // auto: worth it only when x is much larger than one L2 and the matrix is big enough to amortise
-    bool want = o.spmv_xcs == 1 || (o.spmv_xcs == 0 && a->cols * 8 >= (16ull << 20) && nnz >= (1ull << 22));
+    bool want = !a->one_shot && (o.spmv_xcs == 1 || (o.spmv_xcs == 0 && a->cols * 8 >= (16ull << 20) && nnz >= (1ull << 22)));
     // the banded plan (spmv_band.hip) takes such matrices when it applies (its own test of the row lengths)
     // (it pays from smaller x on than the XCD-sliced plan: R-MAT 1M, x = 8 MB, cold caches: 0.101 vs 0.156 ms, profiles/r02p)
-    const bool want_band = o.spmv_band == 1 || (o.spmv_band == 0 && o.spmv_xcs != 2 && a->cols * 8 >= (4ull << 20) && nnz >= (1ull << 22));
+    const bool want_band = !a->one_shot && (o.spmv_band == 1 || (o.spmv_band == 0 && o.spmv_xcs != 2 && a->cols * 8 >= (4ull << 20) && nnz >= (1ull << 22)));
     if (want_band) {
         const int32_t st = band_build(a, stream, &pl.band);
         // auto mode: a matrix the banded plan cannot be built for (its temporaries did not fit) keeps the plans below;

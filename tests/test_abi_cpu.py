@@ -85,6 +85,14 @@ def test_argument_checks_need_no_device():
     ix2 = np.array([1, 0], dtype=np.uint64)
     st = _ffi.lib.sprs_hip_csmat_upload(C.byref(h), 0, 1, 2, vp(bad), 8, vp(ix2), 8, vp(np.ones(2)), 1)
     assert st == _ffi.BAD_STRUCTURE and b"not sorted" in _ffi.lib.sprs_hip_last_error()
+    # 2-byte index types (u16 / i16, indexing.rs:124-130): a NULL indices / data pointer with entries to read is refused
+    # before the widening loop touches it (it used to crash)
+    ip16 = np.array([0, 1], dtype=np.uint16)
+    ix16 = np.array([0], dtype=np.uint16)
+    st = _ffi.lib.sprs_hip_csmat_upload(C.byref(h), 0, 1, 1, vp(ip16), 2, None, 2, vp(dt), 1)
+    assert st == _ffi.INVALID_ARG and b"NULL indices" in _ffi.lib.sprs_hip_last_error()
+    st = _ffi.lib.sprs_hip_csmat_upload(C.byref(h), 0, 1, 1, vp(ip16), 2, vp(ix16), 2, None, 1)
+    assert st == _ffi.INVALID_ARG
     st = _ffi.lib.sprs_hip_spmv_f64(None, None, 0, None, 0, 0, None)
     assert st == _ffi.INVALID_ARG
     st = _ffi.lib.sprs_hip_spmv_f64_host(2, 2, vp(ip), 8, vp(ix), 8, vp(dt), vp(dt), 1, vp(dt), 2, 0)

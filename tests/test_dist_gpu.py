@@ -43,6 +43,31 @@ def test_world_of_one(hip, nsub):
     assert e.value.status == hip._ffi.DIM_MISMATCH
 
 
+def test_world_of_one_through_rccl(hip):
+    """what a 1-GPU box can run of the RCCL route: the library loads librccl itself, makes the id, initialises a communicator
+    of one rank, runs its (empty) grouped exchanges on the second stream behind every sub-block and joins back"""
+    from oracle import oracle
+    from sprs_amd import gen
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    from sprs_amd.dist import DistSpMV
+    n = 40000
+    indptr, indices, data = gen.rmat_csr(n, 10, seed=5)
+    ip, ix, dt = indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy()
+    a = DeviceCsMat.from_host((n, n), ip, ix, dt)
+    uid = DistSpMV.unique_id()
+    assert len(uid) == 128 and any(uid)
+    d = DistSpMV((n, n), a, [0, n], rank=0, world=1, unique_id=uid, nsub=3)
+    x = gen.dense_vector(n, seed=6).numpy()
+    ref = np.zeros(n)
+    oracle.mul_acc_mat_vec_csr((n, n), ip, ix, dt, x, ref)
+    xv = DeviceVec.from_host(x)
+    for _ in range(3):                                  # the events / second stream are reused call after call
+        y = DeviceVec.from_host(np.full(n, np.nan))
+        d.spmv(xv, y)
+        assert rel_err(y.to_host(), ref) <= 1e-10
+    del d
+
+
 def _rank_main(rank, world, port, n, out):
     import os
     import torch
