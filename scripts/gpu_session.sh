@@ -65,14 +65,14 @@ for step in "$@"; do
               echo "== group $i: $grp" | tee -a $OUT/spgemm_pmc.txt
               if [ -n "$f" ]; then python3 $ROOT/scripts/rocprof_summary.py "$f" sprs_hip | sed -n '/PMC counters/,$p' | grep -E "rows_kernel|PMC|kernel " | cut -c1-250 | tee -a $OUT/spgemm_pmc.txt; fi
             done ;;
-    spgemm_parity) timeout 900 python scripts/spgemm_whole_parity.py $OUT/spgemm5_whole_parity.json ${arg:-20000} 2>&1 | grep -v amdgpu.ids | cut -c1-600 ;;
+    spgemm_parity) timeout -s KILL ${PARITY_TIMEOUT:-420} python scripts/spgemm_whole_parity.py $OUT/spgemm5_whole_parity.json ${arg:-20000} 2>&1 | grep -v amdgpu.ids | cut -c1-600 ;;
     spgemm_stats)  # per-kernel times of ONE config-5 product
-            ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spgemm_one.py 2 > $OUT/spgemm_one.json 2>/dev/null; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|^#|sprs_hip" | cut -c1-200 | tee $OUT/spgemm_kernel_stats.txt ;;
+            ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spgemm_one.py 2 > $OUT/spgemm_one.json 2>/dev/null; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|^#|sprs_hip" | cut -c1-200 | tee $OUT/spgemm_kernel_stats.txt ;;
     spgemm_traffic1) # FETCH_SIZE and WRITE_SIZE, one counter per pass, ONE product, only the library's kernels instrumented
             python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print('csrc_sha16:', bench.csrc_sha16())" > $OUT/spgemm_traffic.txt
             for ctr in FETCH_SIZE WRITE_SIZE; do
               rm -rf /tmp/pt
-              ( cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --kernel-include-regex "sprs_hip" -d /tmp/pt -o pmc -- python $ROOT/scripts/spgemm_one.py 1 > $OUT/spgemm_traffic_$ctr.json 2>/dev/null )
+              ( cd /tmp && timeout -s KILL 200 rocprofv3 --pmc $ctr --kernel-trace --kernel-include-regex "sprs_hip" -d /tmp/pt -o pmc -- python $ROOT/scripts/spgemm_one.py 1 > $OUT/spgemm_traffic_$ctr.json 2>/dev/null )
               f=$(find /tmp/pt -name "*.db" | head -1)
               if [ -n "$f" ]; then python3 $ROOT/scripts/rocprof_summary.py "$f" sprs_hip | sed -n '/PMC counters/,$p' | cut -c1-250 >> $OUT/spgemm_traffic.txt; else echo "no db for $ctr" >> $OUT/spgemm_traffic.txt; fi
             done

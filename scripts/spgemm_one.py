@@ -24,6 +24,7 @@ def main():
     indptr, indices, data = gen.rmat_csr(n, 8, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)
     a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
     torch.cuda.synchronize()
+    print("generated: nnz(A) = %d" % indices.numel(), file=sys.stderr, flush=True)
     times, c = [], None
     for _ in range(products):
         c = None

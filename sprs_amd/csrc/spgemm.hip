@@ -630,7 +630,7 @@ __device__ __forceinline__ void lds_store_f64(double *p, double v) { *(lds_vf64 
 #endif
 
 __device__ __forceinline__ void token_wait(uint32_t *token, uint32_t turn) {
-    if (DEVTOOLS && turn == 0xFFFFFFFFu) return;       // timing experiments only (developer builds, option spgemm_debug & 1): no ordering
+    if (turn == 0xFFFFFFFFu) return;       // timing experiments only (option spgemm_debug & 1, developer builds): no ordering
     while (lds_load_u32(token) != turn) SPRS_POLL_PAUSE();
     asm volatile("" ::: "memory");
     wave_sync_lds();      // (no instruction; in the CPU emulator, where the lanes of a wave run one after the other, it keeps lane 0
@@ -711,11 +711,11 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                                                              unsigned long long *__restrict__ prof,
                                                              const uint64_t *__restrict__ ub_dbg,
                                                              unsigned int *__restrict__ next_row) {
-    long long t_prev = (DEVTOOLS && prof) ? (long long)wall_clock64() : 0;
+    long long t_prev = prof ? (long long)wall_clock64() : 0;
     const long long t_kernel = t_prev;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto mark = [&](int phase) {                                        // lane 0's view of the phases (debug option spgemm_prof)
-        if (DEVTOOLS && prof && (threadIdx.x & (WAVE - 1)) == 0) {
+        if (prof && (threadIdx.x & (WAVE - 1)) == 0) {
             const long long now = (long long)wall_clock64();
             ph[phase] += (unsigned long long)(now - t_prev);
             t_prev = now;
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
         if constexpr (NUMERIC) out = off[t];
         uint32_t fresh = 0;
         mark(0);
-        const long long t_row = (DEVTOOLS && prof) ? (long long)wall_clock64() : 0;
+        const long long t_row = prof ? (long long)wall_clock64() : 0;
         for (uint64_t w = 0; w < nwin; ++w) {
             const uint64_t win_lo = w << MID_WL;
             const uint32_t win_s = cur, win_e = q0;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             const uint64_t tot = wave_sum_u64(fresh);
             if (lane == 0) count[t] = tot;
         }
-        if (DEVTOOLS && prof && lane == 0) {
+        if (prof && lane == 0) {
             const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - t_row);
             const uint64_t u = ub_dbg[r];
             const int c = u < 2048 ? 0 : u < 8192 ? 1 : u < 32768 ? 2 : 3;
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             atomicMax(&prof[16], dt);
         }
     }
-    if (DEVTOOLS && prof && lane == 0) {
+    if (prof && lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], ph[i]);
         atomicMax(&prof[17], (unsigned long long)((long long)wall_clock64() - t_kernel));   // longest wave
         atomicAdd(&prof[18], (unsigned long long)((long long)wall_clock64() - t_kernel));
@@ -1030,11 +1030,11 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                                                               unsigned long long *__restrict__ prof,
                                                               const uint64_t *__restrict__ ub_dbg) {
     using Cfg = LgCfg<WL>;
-    const long long t_begin = (DEVTOOLS && prof) ? (long long)wall_clock64() : 0;     // debug option spgemm_prof: 100 MHz ticks per task
+    const long long t_begin = prof ? (long long)wall_clock64() : 0;     // debug option spgemm_prof: 100 MHz ticks per task
     long long t_prev = t_begin;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto mark = [&](int phase) {                                        // thread 0's view of the phases
-        if (DEVTOOLS && prof && threadIdx.x == 0) {
+        if (prof && threadIdx.x == 0) {
             const long long now = (long long)wall_clock64();
             ph[phase] += (unsigned long long)(now - t_prev);
             t_prev = now;
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const bool values = NUMERIC && c_data != nullptr;
     const bool lds_atomic = (flags & 1u) != 0;
     const bool retain_ok = values && (flags & 2u) != 0;
-    const bool no_order = DEVTOOLS && (flags & 4u) != 0, no_emit = DEVTOOLS && (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
+    const bool no_order = (flags & 4u) != 0, no_emit = (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
     const uint32_t ntok = 1u << ((flags >> 4) & 3u);                          // 1, 2 or 4 token chains (option spgemm_tokens)
     // a row whose k's fit one staged group: thread j keeps k_j, the bounds of B's row k_j and a_ik for the whole task
     const bool mine_k = one_group && tid < (uint32_t)(ae - as) && w_begin < w_end;
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             mark(5);
         }
     }
-    if (DEVTOOLS && prof && tid == 0) {
+    if (prof && tid == 0) {
         prof[blockIdx.x] = (unsigned long long)((long long)wall_clock64() - t_begin);
         const double per = (double)ub_dbg[r] / (double)nt;
         const int cls = per < 8192 ? 0 : per < 32768 ? 1 : per < 131072 ? 2 : per < 524288 ? 3 : 4;
