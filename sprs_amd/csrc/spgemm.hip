@@ -711,14 +711,20 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                                                              unsigned long long *__restrict__ prof,
                                                              const uint64_t *__restrict__ ub_dbg,
                                                              unsigned int *__restrict__ next_row) {
-    long long t_prev = prof ? (long long)wall_clock64() : 0;
-    const long long t_kernel = t_prev;
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // the phase timers of option spgemm_prof (developer builds) live in LDS and are touched only when prof is set: kept in
+    // registers (ten 64-bit values per lane) they cost the numeric kernel 92 bytes of scratch per lane, i.e. ~20 GB of spill
+    // traffic per config-5 product (profiles/r05m: 40 GB written for 18 GB of output)
+    __shared__ unsigned long long ph_s[MID_BLOCK / WAVE][10];           // [wave][0..7 phases, 8 previous mark, 9 kernel start]
+    unsigned long long *ph = ph_s[threadIdx.x / WAVE];
+    if (prof && (threadIdx.x & (WAVE - 1)) == 0) {
+        for (int i = 0; i < 8; ++i) ph[i] = 0;
+        ph[8] = ph[9] = (unsigned long long)wall_clock64();
+    }
     auto mark = [&](int phase) {                                        // lane 0's view of the phases (debug option spgemm_prof)
         if (prof && (threadIdx.x & (WAVE - 1)) == 0) {
-            const long long now = (long long)wall_clock64();
-            ph[phase] += (unsigned long long)(now - t_prev);
-            t_prev = now;
+            const unsigned long long now = (unsigned long long)wall_clock64();
+            ph[phase] += now - ph[8];
+            ph[8] = now;
         }
     };
     constexpr int MID_WORDS = 1 << (MID_WL - 6);      // bitmap words of a window; lane l takes words l, l + 64, ...
@@ -963,8 +969,8 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
     }
     if (prof && lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], ph[i]);
-        atomicMax(&prof[17], (unsigned long long)((long long)wall_clock64() - t_kernel));   // longest wave
-        atomicAdd(&prof[18], (unsigned long long)((long long)wall_clock64() - t_kernel));
+        atomicMax(&prof[17], (unsigned long long)wall_clock64() - ph[9]);   // longest wave
+        atomicAdd(&prof[18], (unsigned long long)wall_clock64() - ph[9]);
         atomicAdd(&prof[19], 1ull);
     }
 }
@@ -1030,14 +1036,17 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                                                               unsigned long long *__restrict__ prof,
                                                               const uint64_t *__restrict__ ub_dbg) {
     using Cfg = LgCfg<WL>;
-    const long long t_begin = prof ? (long long)wall_clock64() : 0;     // debug option spgemm_prof: 100 MHz ticks per task
-    long long t_prev = t_begin;
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // phase timers of option spgemm_prof (developer builds): in LDS, touched only when prof is set (see mid_rows_kernel)
+    __shared__ unsigned long long ph[10];                               // 0..7 phases, 8 previous mark, 9 task start (100 MHz ticks)
+    if (prof && threadIdx.x == 0) {
+        for (int i = 0; i < 8; ++i) ph[i] = 0;
+        ph[8] = ph[9] = (unsigned long long)wall_clock64();
+    }
     auto mark = [&](int phase) {                                        // thread 0's view of the phases
         if (prof && threadIdx.x == 0) {
-            const long long now = (long long)wall_clock64();
-            ph[phase] += (unsigned long long)(now - t_prev);
-            t_prev = now;
+            const unsigned long long now = (unsigned long long)wall_clock64();
+            ph[phase] += now - ph[8];
+            ph[8] = now;
         }
     };
     constexpr int WORDS = Cfg::WORDS, WPT = Cfg::WPT, NSUPER = Cfg::NSUPER, ACC_CAP = Cfg::ACC_CAP, K_CAP = Cfg::K_CAP;
@@ -1251,7 +1260,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
         }
     }
     if (prof && tid == 0) {
-        prof[blockIdx.x] = (unsigned long long)((long long)wall_clock64() - t_begin);
+        prof[blockIdx.x] = (unsigned long long)wall_clock64() - ph[9];
         const double per = (double)ub_dbg[r] / (double)nt;
         const int cls = per < 8192 ? 0 : per < 32768 ? 1 : per < 131072 ? 2 : per < 524288 ? 3 : 4;
         for (int i = 0; i < 6; ++i) atomicAdd(&prof[gridDim.x + cls * 8 + i], ph[i]);
