@@ -294,6 +294,10 @@ struct BandScratch {        // per stream
     // the gather-bound kernels (cold pieces, short rows: L2 -> L1 fills) run beside the HBM-bound hot kernel on a second stream
     hipStream_t aux = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    // the first hot slices are reduced on a third stream while the hot kernel streams the others
+    double *ysum = nullptr;                        // one running sum per long row between the two parts of the reduction
+    hipStream_t aux2 = nullptr;
+    hipEvent_t first_done = nullptr, first_reduced = nullptr;
 };
 
 struct BandPlan {
@@ -311,8 +315,10 @@ struct BandPlan {
     Seg *segs = nullptr;                           // hot segments (workgroup by workgroup), then one segment per cold piece, the short piece
     uint32_t *wg_seg = nullptr;                    // hot workgroup b takes segments wg_seg[b] .. wg_seg[b + 1] - 1
     uint32_t nranges = 0, nsegs = 0, hot_wgs = 0, cold_tiles = 4, hot_run = 4;
-    void *spills = nullptr;                        // Spill records (device)
-    uint32_t nspills = 0;
+    void *spills = nullptr, *spills_first = nullptr;   // Spill records (device): of the first hot slices (below hot_cut), of everything else
+    uint32_t nspills = 0, nspills_first = 0;
+    uint32_t hot_cut = 0;                          // hot slices [0, hot_cut) are launched (and reduced) first; 0: one launch, one reduction
+    uint32_t hot_wgs_first = 0;                    // workgroups of the first hot launch (the others: hot_wgs - hot_wgs_first)
     ColdGroup *groups = nullptr;
     unsigned long long *wmask = nullptr;           // per (64 long rows, piece): which rows have a partial
     uint32_t *wbase = nullptr;                     //                            and where the first one is
@@ -342,6 +348,7 @@ void band_free(BandPlan *bp) {
     drop(bp->tile_row_all);
     drop(bp->segs);
     drop(bp->spills);
+    drop(bp->spills_first);
     drop(bp->wg_seg);
     drop(bp->groups);
     drop(bp->wmask);
@@ -351,6 +358,10 @@ void band_free(BandPlan *bp) {
         drop(kv.second.carry);
         drop(kv.second.xp);
         drop(kv.second.pieces);
+        drop(kv.second.ysum);
+        if (kv.second.first_done) (void)hipEventDestroy(kv.second.first_done);
+        if (kv.second.first_reduced) (void)hipEventDestroy(kv.second.first_reduced);
+        if (kv.second.aux2) (void)hipStreamDestroy(kv.second.aux2);
         if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
         if (kv.second.join) (void)hipEventDestroy(kv.second.join);
         if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
@@ -611,22 +622,41 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         SPRS_TRY_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, a->device));
         if (ncu < 1) ncu = 1;
         const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : 2;   // 2: median 1.048 against 1.072 ms with 1 (profiles/r05j)
-        uint64_t nwg = (uint64_t)ncu * rounds;
-        if (nwg > hot_tiles) nwg = hot_tiles;
-        const uint64_t Q = (hot_tiles + nwg - 1) / nwg;           // wave tiles per workgroup
-        uint32_t k = 0;
-        uint64_t k_first = 0;                                      // global number of slice k's first tile
-        for (uint64_t b = 0; b * Q < hot_tiles; ++b) {
-            uint64_t t = b * Q;
-            const uint64_t t_end = std::min(hot_tiles, t + Q);
-            while (t < t_end) {
-                while (k_first + bp->host_pieces[k].ntiles <= t) k_first += bp->host_pieces[k++].ntiles;   // (slices without tiles are skipped)
-                const uint64_t s_end = std::min(t_end, k_first + bp->host_pieces[k].ntiles);
-                add_seg(k, (uint32_t)(t - k_first), (uint32_t)(s_end - t), bp->hot_run);
-                t = s_end;
-            }
-            wg_seg.push_back((uint32_t)segs.size());
+        // Option spmv_band_hot_cut = c: two hot launches, slices [0, c) then [c, nh), and the first slices' carries and their part
+        // of every row's sum on a third stream beside the second launch (the first 64 of 128 slices of R-MAT 10M hold 94 % of
+        // the hot entries and 78 % of the partial sums).  Measured NEGATIVE, so off by default: the reduction then competes
+        // with the gather kernels and the second launch for the same fabric — 1.060 .. 1.090 ms for c = 32 .. 80 against
+        // 1.045 ms in one part (medians of 3, profiles/r05o); bit-identical results either way (tests/test_spmv_band_gpu.py).
+        uint32_t cut = 0;
+        if (o.spmv_band_hot_cut > 0) {
+            cut = (uint32_t)o.spmv_band_hot_cut / RU * RU;
+            if (cut >= nh) cut = 0;
         }
+        bp->hot_cut = cut;
+        auto split = [&](uint32_t k_lo, uint32_t k_hi) {             // equal shares of the tiles of slices [k_lo, k_hi) per workgroup
+            uint64_t tiles = 0;
+            for (uint32_t k = k_lo; k < k_hi; ++k) tiles += bp->host_pieces[k].ntiles;
+            if (!tiles) return;
+            uint64_t nwg = (uint64_t)ncu * rounds;
+            if (nwg > tiles) nwg = tiles;
+            const uint64_t Q = (tiles + nwg - 1) / nwg;               // wave tiles per workgroup
+            uint32_t k = k_lo;
+            uint64_t k_first = 0;                                     // number (inside the group) of slice k's first tile
+            for (uint64_t b = 0; b * Q < tiles; ++b) {
+                uint64_t t = b * Q;
+                const uint64_t t_end = std::min(tiles, t + Q);
+                while (t < t_end) {
+                    while (k_first + bp->host_pieces[k].ntiles <= t) k_first += bp->host_pieces[k++].ntiles;   // (slices without tiles are skipped)
+                    const uint64_t s_end = std::min(t_end, k_first + bp->host_pieces[k].ntiles);
+                    add_seg(k, (uint32_t)(t - k_first), (uint32_t)(s_end - t), bp->hot_run);
+                    t = s_end;
+                }
+                wg_seg.push_back((uint32_t)segs.size());
+            }
+        };
+        split(0, cut ? cut : (uint32_t)nh);
+        bp->hot_wgs_first = (uint32_t)(wg_seg.size() - 1);
+        if (cut) split(cut, (uint32_t)nh);
         bp->hot_wgs = (uint32_t)(wg_seg.size() - 1);
     }
     for (uint32_t k = (uint32_t)nh; k <= NP; ++k) {
@@ -669,17 +699,22 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         TmpBuf pcs_d, poff_d, cnt_d;
         SPRS_TRY_HIP(pcs_d.alloc(bp->host_pieces.size() * sizeof(BandPiece)));
         SPRS_TRY_HIP(poff_d.alloc(bp->pair_off.size() * 8));
-        SPRS_TRY_HIP(cnt_d.alloc(4));
+        SPRS_TRY_HIP(cnt_d.alloc(8));
         SPRS_TRY_HIP(hipMemcpyAsync(pcs_d.p, bp->host_pieces.data(), bp->host_pieces.size() * sizeof(BandPiece), hipMemcpyHostToDevice, stream));
         SPRS_TRY_HIP(hipMemcpyAsync(poff_d.p, bp->pair_off.data(), bp->pair_off.size() * 8, hipMemcpyHostToDevice, stream));
-        SPRS_TRY_HIP(hipMemsetAsync(cnt_d.p, 0, 4, stream));
+        SPRS_TRY_HIP(hipMemsetAsync(cnt_d.p, 0, 8, stream));
         SPRS_TRY_HIP(hipMalloc(&bp->spills, ((uint64_t)nranges + 1) * sizeof(Spill)));     // at most one per range
+        SPRS_TRY_HIP(hipMalloc(&bp->spills_first, ((uint64_t)nranges + 1) * sizeof(Spill)));
         hipLaunchKernelGGL(bp_spill_kernel, dim3((nranges + 255) / 256), dim3(256), 0, stream, (const Seg *)bp->segs, bp->nsegs, nranges,
                            (const BandPiece *)pcs_d.p, (const uint64_t *)poff_d.p, bp->nh, (const uint16_t *)bp->cid_hot,
-                           (const uint32_t *)bp->cid_cold, (Spill *)bp->spills, (unsigned int *)cnt_d.p);
+                           (const uint32_t *)bp->cid_cold, bp->hot_cut, (Spill *)bp->spills_first, (Spill *)bp->spills,
+                           (unsigned int *)cnt_d.p);
         SPRS_TRY_HIP(hipGetLastError());
-        SPRS_TRY_HIP(hipMemcpy(&bp->nspills, cnt_d.p, 4, hipMemcpyDeviceToHost));
-        bp->bytes += (uint64_t)bp->nspills * sizeof(Spill);
+        uint32_t counts[2] = {0, 0};
+        SPRS_TRY_HIP(hipMemcpy(counts, cnt_d.p, 8, hipMemcpyDeviceToHost));
+        bp->nspills_first = counts[0];
+        bp->nspills = counts[1];
+        bp->bytes += ((uint64_t)counts[0] + counts[1]) * sizeof(Spill);
     }
     SPRS_TRY_HIP(hipStreamSynchronize(stream));   // plan complete, temporaries (and the host vectors above) may go
     if (getenv("SPRS_HIP_DEBUG")) {
@@ -714,6 +749,12 @@ int32_t band_scratch(BandPlan *bp, hipStream_t stream, BandScratch **out) {
         SPRS_TRY_HIP(hipStreamCreateWithFlags(&sc.aux, hipStreamNonBlocking));
         SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.fork, hipEventDisableTiming));
         SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.join, hipEventDisableTiming));
+        if (bp->hot_cut) {
+            SPRS_TRY_HIP(hipMalloc((void **)&sc.ysum, ((uint64_t)bp->n_long + 1) * 8));
+            SPRS_TRY_HIP(hipStreamCreateWithFlags(&sc.aux2, hipStreamNonBlocking));
+            SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.first_done, hipEventDisableTiming));
+            SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.first_reduced, hipEventDisableTiming));
+        }
         it = bp->scratch.emplace((void *)stream, sc).first;
     }
     *out = &it->second;
@@ -780,11 +821,15 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         }
     }
     if (overlap) SPRS_TRY_HIP(hipEventRecord(sc->join, sc->aux));
-    if (bp->hot_wgs) {
+    const uint32_t nwb = (bp->n_long + WAVE - 1) / WAVE;
+    const uint32_t per_xcd = (nwb + 7) / 8;
+    const dim3 rg(((per_xcd + 3) / 4) * 8), rb(256);                 // reduction: one wave per block of 64 long rows, XCD by XCD
+    auto launch_hot = [&](uint32_t wg0, uint32_t nwg) -> int32_t {
+        if (!nwg) return SPRS_HIP_OK;
         const uint32_t lds = hot_lds_bytes(bp->xt_log2);
 #ifndef SPRS_HIP_EMU
         static std::once_flag once;                                  // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
-        hipError_t attr_err = hipSuccess;
+        static hipError_t attr_err = hipSuccess;
         std::call_once(once, [&] {
             attr_err = hipFuncSetAttribute((const void *)band_hot_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds_bytes(13));
             if (attr_err == hipSuccess)
@@ -793,35 +838,55 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         SPRS_TRY_HIP(attr_err);
 #endif
         if (bp->xt_log2 == 13)
-            hipLaunchKernelGGL((band_hot_kernel<13>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
-                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg,
+            hipLaunchKernelGGL((band_hot_kernel<13>), dim3(nwg), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
+                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg + wg0,
                                (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry,
                                (uint32_t)options().spmv_band_debug);
         else
-            hipLaunchKernelGGL((band_hot_kernel<14>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
-                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg,
+            hipLaunchKernelGGL((band_hot_kernel<14>), dim3(nwg), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
+                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg + wg0,
                                (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry,
                                (uint32_t)options().spmv_band_debug);
         SPRS_TRY_HIP(hipGetLastError());
-    }
-    if (overlap) SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->join, 0));
-    if (bp->nspills) {
-        hipLaunchKernelGGL(band_carry_kernel, dim3((bp->nspills + 255) / 256), dim3(256), 0, stream, (const Spill *)bp->spills,
-                           bp->nspills, (const double *)sc->carry, sc->partial, y);
+        return SPRS_HIP_OK;
+    };
+    auto launch_carry = [&](const void *spills, uint32_t n, hipStream_t st) -> int32_t {
+        if (!n) return SPRS_HIP_OK;
+        hipLaunchKernelGGL(band_carry_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)spills, n, (const double *)sc->carry,
+                           sc->partial, y);
         SPRS_TRY_HIP(hipGetLastError());
+        return SPRS_HIP_OK;
+    };
+    auto launch_reduce = [&](uint32_t k0, uint32_t k1, const double *init, double *ysum_out, hipStream_t st) -> int32_t {
+        if (acc)
+            hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, st, (const double *)sc->partial, (const unsigned long long *)bp->wmask,
+                               (const uint32_t *)bp->wbase, (const uint32_t *)bp->long_rows, y, init, ysum_out, bp->n_long, bp->np_pad, nwb, k0, k1);
+        else
+            hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, st, (const double *)sc->partial, (const unsigned long long *)bp->wmask,
+                               (const uint32_t *)bp->wbase, (const uint32_t *)bp->long_rows, y, init, ysum_out, bp->n_long, bp->np_pad, nwb, k0, k1);
+        SPRS_TRY_HIP(hipGetLastError());
+        return SPRS_HIP_OK;
+    };
+    const bool two_part = bp->hot_cut != 0 && sc->aux2 != nullptr && options().spmv_band_overlap != 2;
+    SPRS_TRY(launch_hot(0, bp->hot_wgs_first));
+    if (two_part) {
+        // the first slices are complete: their carries and their part of every row's sum on the third stream ...
+        SPRS_TRY_HIP(hipEventRecord(sc->first_done, stream));
+        SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux2, sc->first_done, 0));
+        SPRS_TRY(launch_carry(bp->spills_first, bp->nspills_first, sc->aux2));
+        SPRS_TRY(launch_reduce(0, bp->hot_cut, nullptr, sc->ysum, sc->aux2));
+        SPRS_TRY_HIP(hipEventRecord(sc->first_reduced, sc->aux2));
     }
-    const uint32_t nwb = (bp->n_long + WAVE - 1) / WAVE;
-    const uint32_t per_xcd = (nwb + 7) / 8;
-    const dim3 rg(((per_xcd + 3) / 4) * 8), rb(256);                 // one wave per block of 64 long rows, XCD by XCD
-    if (acc)
-        hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, stream, (const double *)sc->partial,
-                           (const unsigned long long *)bp->wmask, (const uint32_t *)bp->wbase,
-                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->np_pad, nwb);
-    else
-        hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, stream, (const double *)sc->partial,
-                           (const unsigned long long *)bp->wmask, (const uint32_t *)bp->wbase,
-                           (const uint32_t *)bp->long_rows, y, bp->n_long, bp->np_pad, nwb);
-    SPRS_TRY_HIP(hipGetLastError());
+    SPRS_TRY(launch_hot(bp->hot_wgs_first, bp->hot_wgs - bp->hot_wgs_first));     // ... while the other slices stream
+    if (overlap) SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->join, 0));
+    if (!two_part) SPRS_TRY(launch_carry(bp->spills_first, bp->nspills_first, stream));
+    SPRS_TRY(launch_carry(bp->spills, bp->nspills, stream));
+    if (two_part) {
+        SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->first_reduced, 0));
+        SPRS_TRY(launch_reduce(bp->hot_cut, bp->np_pad, sc->ysum, nullptr, stream));
+    } else {
+        SPRS_TRY(launch_reduce(0, bp->np_pad, nullptr, nullptr, stream));
+    }
     return SPRS_HIP_OK;
 }
 

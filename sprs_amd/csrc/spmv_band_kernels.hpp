@@ -508,7 +508,8 @@ struct Spill {
 __global__ __launch_bounds__(256) void bp_spill_kernel(const Seg *__restrict__ segs, uint32_t nsegs, uint32_t nranges,
                                                        const BandPiece *__restrict__ pieces, const uint64_t *__restrict__ pair_off,
                                                        uint32_t nhot, const uint16_t *__restrict__ cid_hot,
-                                                       const uint32_t *__restrict__ cid_cold, Spill *__restrict__ spills,
+                                                       const uint32_t *__restrict__ cid_cold, uint32_t first_cut,
+                                                       Spill *__restrict__ spills_first, Spill *__restrict__ spills_rest,
                                                        unsigned int *__restrict__ count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nranges) return;
@@ -529,8 +530,10 @@ __global__ __launch_bounds__(256) void bp_spill_kernel(const Seg *__restrict__ s
         if (!nj.valid || nj.piece != rg.piece || d.tile_row[nj.tile0] - 1 != row || !range_has_head(d, nj.piece, nj.tile0, cid_hot, cid_cold, nhot))
             break;
     }
-    const unsigned int slot = atomicAdd(count, 1u);
-    spills[slot] = Spill{d.to_y ? (uint64_t)d.rowidx[row] : pair_off[rg.piece] + row, i, n, d.to_y, 0u};
+    // two lists: the hot slices below first_cut (reduced first, while the hot kernel still streams the others) and the rest
+    const bool first = rg.piece < first_cut;
+    const unsigned int slot = atomicAdd(count + (first ? 0 : 1), 1u);
+    (first ? spills_first : spills_rest)[slot] = Spill{d.to_y ? (uint64_t)d.rowidx[row] : pair_off[rg.piece] + row, i, n, d.to_y, 0u};
 }
 
 // per SpMV: the heads of a record's ranges are added to the row's sum in range order
@@ -613,10 +616,16 @@ __device__ __forceinline__ uint32_t band_mask_rank(uint32_t m_lo, uint32_t m_hi,
 #endif
 }
 
+// The pieces [k_begin, k_end) of every row (both multiples of RU).  The reduction may run in two parts — the first hot
+// slices while the hot kernel still streams the others, band_spmv — that continue ONE chain of additions: the first part
+// leaves its sums in ysum (one per long row), the second starts from them: the same bits as a single pass.
+//   init: sums to start from (null: 0.0);  ysum_out: where the sums go (null: they are final, y[long_rows[j]] (+)= sum)
 template <bool ACC>
 __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restrict__ partial, const unsigned long long *__restrict__ wmask,
                                                           const uint32_t *__restrict__ wbase, const uint32_t *__restrict__ long_rows,
-                                                          double *__restrict__ y, uint32_t n_long, uint32_t np_pad, uint32_t nwb) {
+                                                          double *__restrict__ y, const double *__restrict__ init,
+                                                          double *__restrict__ ysum_out, uint32_t n_long, uint32_t np_pad, uint32_t nwb,
+                                                          uint32_t k_begin, uint32_t k_end) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     // wave -> row block: block b runs on XCD b % 8 (observed; only speed depends on it): every XCD gets a CONTIGUOUS range
     // of row blocks (neighbouring row blocks read neighbouring partials of every piece, often the same 128-byte line)
@@ -627,18 +636,19 @@ __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restri
         const uint32_t wb = xcd * per_xcd + i;
         if (wb >= nwb) break;
         const uint64_t j = (uint64_t)wb * WAVE + lane;
-        const uint32_t r = long_rows[j < n_long ? j : n_long - 1];      // (requested early: needed only at the very end)
+        const uint64_t jc = j < n_long ? j : n_long - 1;
+        const uint32_t r = ysum_out ? 0u : long_rows[jc];               // (requested early: needed only at the very end)
+        double s = init ? init[jc] : 0.0;
         const unsigned long long *mrow = wmask + (uint64_t)wb * np_pad;
         const uint32_t *brow = wbase + (uint64_t)wb * np_pad;
-        double s = 0.0;
-        for (uint32_t k0 = 0; k0 < np_pad; k0 += WAVE) {
-            const bool in = k0 + lane < np_pad;
+        for (uint32_t k0 = k_begin; k0 < k_end; k0 += WAVE) {
+            const bool in = k0 + lane < k_end;
             const unsigned long long mk = in ? mrow[k0 + lane] : 0ull;   // lane l: the table row of piece k0 + l
             const uint32_t bs = in ? brow[k0 + lane] : 0u;
             const uint32_t mk_lo = (uint32_t)mk, mk_hi = (uint32_t)(mk >> 32);
 #pragma unroll
             for (int kk = 0; kk < WAVE; kk += RU) {
-                if (k0 + kk >= np_pad) break;                            // wave-uniform
+                if (k0 + kk >= k_end) break;                             // wave-uniform
                 double v[RU];
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
@@ -652,7 +662,8 @@ __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restri
             }
         }
         if (j < n_long) {
-            if constexpr (ACC) y[r] = y[r] + s;
+            if (ysum_out) ysum_out[j] = s;
+            else if constexpr (ACC) y[r] = y[r] + s;
             else y[r] = s;
         }
     }

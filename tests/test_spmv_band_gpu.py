@@ -26,10 +26,10 @@ def hip():
 
 
 class band_options:
-    def __init__(self, hip, hot, phases, rounds=0, split=0, tile=0, cold_tiles=0, hot_run=0):
+    def __init__(self, hip, hot, phases, rounds=0, split=0, tile=0, cold_tiles=0, hot_run=0, hot_cut=0):
         self.hip, self.vals = hip, dict(spmv_band=1, spmv_band_hot=hot, spmv_band_phases=phases, spmv_band_rounds=rounds,
                                         spmv_band_split=split, spmv_band_tile=tile, spmv_band_cold_tiles=cold_tiles,
-                                        spmv_band_hot_run=hot_run)
+                                        spmv_band_hot_run=hot_run, spmv_band_hot_cut=hot_cut)
 
     def __enter__(self):
         for k, v in self.vals.items():
@@ -91,6 +91,27 @@ def test_hub_rows_and_many_segments(hip):
     for rounds, tile, ct, run in ((1, 8192, 4, 0), (3, 16384, 1, 1), (40, 8192, 7, 3), (2, 16384, 2, 1000)):
         with band_options(hip, 2, 2, rounds=rounds, tile=tile, cold_tiles=ct, hot_run=run):
             check_band(hip, shape, ip, ix, dt, seed=rounds)
+
+
+def test_two_part_reduction(hip):
+    """many hot slices, the first 16 / 32 of them launched and reduced FIRST (their carries and their part of every row's
+    sum on a third stream while the second hot launch runs), the rest continuing the same chain of additions: the result
+    must equal the one-part run bit for bit, and the oracle within tolerance"""
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    rng = np.random.default_rng(21)
+    rows, cols = 1500, 300000
+    lens = rng.integers(30, 400, size=rows)
+    lens[::97] = 5000                                          # a few hub rows: runs that span ranges in the early slices
+    lens[3::50] = 0
+    shape, ip, ix, dt = ragged_csr(list(lens), cols, seed=22)
+    x = rng.random(cols) + 0.5
+    out = {}
+    for cut in (-1, 16, 32):
+        with band_options(hip, 36, 1, tile=8192, hot_cut=cut, rounds=3, hot_run=2):
+            y = check_band(hip, shape, ip, ix, dt, seed=4)
+            a = DeviceCsMat.from_host(shape, ip, ix, dt)
+            out[cut] = (a * DeviceVec.from_host(x)).to_host()
+    assert np.array_equal(out[16], out[-1]) and np.array_equal(out[32], out[-1])
 
 
 def test_split_and_empty_pieces(hip):
