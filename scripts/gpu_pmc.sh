@@ -16,7 +16,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC
   if [ -n "$PMC_ONLY" ] && [ $i -ne $PMC_ONLY ]; then continue; fi
   if [ $i -gt ${PMC_GROUPS:-6} ]; then break; fi
   rm -rf /tmp/pmc_$i
-  timeout 600 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc_$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/p$i.json 2> $OUT/p$i.err
+  timeout -s KILL 240 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc_$i -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/p$i.json 2> $OUT/p$i.err
   f=$(find /tmp/pmc_$i -name "*.db" | head -1)
   echo "== group $i: $grp" | tee -a $OUT/pmc_summary.txt
   if [ -n "$f" ]; then python3 $GRAFT_REPO_ROOT/scripts/rocprof_summary.py "$f" sprs_hip | sed -n '/PMC counters/,$p' | tee -a $OUT/pmc_summary.txt; else tail -3 $OUT/p$i.err; fi

@@ -37,7 +37,7 @@ for step in "$@"; do
     bench)  timeout 900 python bench.py $arg 2>/dev/null | tee -a $OUT/bench.jsonl ;;
     sweep)  IFS='|' read -ra CFG <<< "$arg"; timeout 900 python scripts/spmv_sweep.py --steps 30 --oracle "${CFG[@]}" 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tee -a $OUT/sweep.jsonl ;;
     trace)  ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace -d /tmp/st -o s -- python $ROOT/scripts/spmv_sweep.py --steps 10 "$arg" > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_seq.py $(prof_db /tmp/st) band_ spmv_ ) 2>&1 | cut -c1-200 | tee -a $OUT/kernel_seq.txt ;;
-    stats)  ( cd /tmp && rm -rf /tmp/st && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/bench.py --no-cpu-baseline $arg > $OUT/stats_bench.json 2>/dev/null; f=$(prof_db /tmp/st); python3 $ROOT/scripts/rocprof_summary.py $f sprs_hip | grep -E "^kernel|^#|sprs_hip" | cut -c1-190; python3 $ROOT/scripts/rocprof_seq.py $f band_ | cut -c1-200 ) 2>&1 | tee -a $OUT/kernel_stats.txt ;;
+    stats)  ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/bench.py --no-cpu-baseline $arg > $OUT/stats_bench.json 2>/dev/null; f=$(prof_db /tmp/st); python3 $ROOT/scripts/rocprof_summary.py $f sprs_hip | grep -E "^kernel|^#|sprs_hip" | cut -c1-190; python3 $ROOT/scripts/rocprof_seq.py $f band_ | cut -c1-200 ) 2>&1 | tee -a $OUT/kernel_stats.txt ;;
     pmc)    PMC_GROUPS=${PMC_GROUPS:-3} bash scripts/gpu_pmc.sh $TAG/pmc $arg > /dev/null 2>&1; grep -E "csrc_sha16|band_|spmv_" $OUT/pmc/pmc_summary.txt | cut -c1-200 ;;
     spgemm) timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds" | tee -a $OUT/spgemm.jsonl
             ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/tests/spgemm_bench.py 1000000 8 8 1 > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|sprs_hip" | cut -c1-200 | head -16 | tee -a $OUT/spgemm_kernels.txt

@@ -26,11 +26,14 @@ def main():
             continue
         parts = line.split()
         name = parts[0]
-        kern = re.sub(r"[<(].*", "", line.replace("sprs_hip::", "").replace("(anonymous namespace)::", "").split()[0])
+        full = line.replace("sprs_hip::", "").replace("(anonymous namespace)::", "")
+        kern = re.sub(r"[<(].*", "", full.split()[0])
         if kern not in PER_SPMV:
             continue
         counter, n, mean = parts[-5], int(parts[-4]), float(parts[-3])
-        key = (kern, counter)
+        inst = re.sub(r"\(.*", "", full).strip()          # with template arguments: band_cold_kernel<false, false> and <false, true> are two launches
+        inst = re.sub(r"\s+\S+\s+\d+\s+\S+\s+\S+\s+\S+$", "", inst).strip() if "(" not in full else inst
+        key = (inst, counter)
         if key in per_kernel:
             continue                      # the summary repeats groups; first wins
         per_kernel[key] = mean

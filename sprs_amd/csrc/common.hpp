@@ -57,7 +57,6 @@ constexpr bool DEVTOOLS = false;
     X(spmv_relabel, 0, 0, 2, 0)         /* sliced plan: columns relabelled by count class: 0 auto (on), 1 on, 2 off */             \
     X(spmv_tile, 0, 0, 4096, 0)         /* nnz per workgroup tile: 0 auto, 2048 or 4096 */                                        \
     X(spmv_lds_pad, 0, 0, 100000, 0)    /* extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning) */              \
-    X(spmv_graph, 0, 0, 2, 0)           /* multi-launch SpMV plans replayed as a hipGraph per (handle, stream): 0 auto, 1 on, 2 off */ \
     X(spmv_xmask, -1, INT64_MIN, INT64_MAX, 1) /* TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1) */      \
     X(spmv_band, 0, 0, 2, 0)            /* banded plan (hot columns from LDS, spmv_band.hip): 0 auto (on), 1 on, 2 off */          \
     X(spmv_band_hot, 0, 0, 384, 0)      /* hot slices (0 = default 128) */                                                        \
@@ -88,7 +87,6 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_winlog, 17, 16, 19, 0)     /* log2 of the widest column window of a large-row task */                                \
     X(spgemm_minwin, 13, 11, 16, 0)     /* log2 of the narrowest column window of a heavy row */                                  \
     X(spgemm_heavy, 131072, 1024, INT64_MAX, 0) /* a row of more products is cut into one task per (narrower) column window */    \
-    X(spgemm_order, 0, 0, 1, 0)         /* order of the additions into one C(i,j): 0 strict (the reference's k-ascending chain, bit-exact), 1 relaxed (deterministic, any k order; within 1e-10) */ \
     X(pool, 1, 0, 1, 0)                 /* keep released result blocks (>= 1 MiB) for the next result instead of hipFree */        \
     X(pool_max_bytes, 128ll << 30, 0, INT64_MAX, 0) /* cap on the bytes the pool may hold */
 

@@ -317,6 +317,7 @@ struct BandPlan {
     uint32_t nranges = 0, nsegs = 0, hot_wgs = 0, cold_tiles = 4, hot_run = 4;
     void *spills = nullptr, *spills_first = nullptr;   // Spill records (device): of the first hot slices (below hot_cut), of everything else
     uint32_t nspills = 0, nspills_first = 0;
+    bool small = false;                            // few tiles per CU: the launches of one SpMV stay on one stream (the fork / join costs more than it hides)
     uint32_t hot_cut = 0;                          // hot slices [0, hot_cut) are launched (and reduced) first; 0: one launch, one reduction
     uint32_t hot_wgs_first = 0;                    // workgroups of the first hot launch (the others: hot_wgs - hot_wgs_first)
     ColdGroup *groups = nullptr;
@@ -621,7 +622,14 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         int ncu = 0;
         SPRS_TRY_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, a->device));
         if (ncu < 1) ncu = 1;
-        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : 2;   // 2: median 1.048 against 1.072 ms with 1 (profiles/r05j)
+        // workgroups per CU, ranges: a big matrix (R-MAT 10M: 2 180 tiles per CU) takes 2 rounds of long shares in ranges of 4 tiles
+        // (median 1.048 against 1.072 ms with 1 round, profiles/r05j); a small one (R-MAT 1M: 104 tiles per CU) is latency
+        // bound — every wave gets only a few tiles — and does better with more, shorter shares and single-tile ranges
+        // (hot kernel 45 against 61 us, profiles/r05p)
+        const bool small_hot = hot_tiles < 400ull * (uint64_t)ncu;
+        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : (small_hot ? 4 : 2);
+        if (o.spmv_band_hot_run <= 0 && small_hot) bp->hot_run = 1;
+        bp->small = small_hot;
         // Option spmv_band_hot_cut = c: two hot launches, slices [0, c) then [c, nh), and the first slices' carries and their part
         // of every row's sum on a third stream beside the second launch (the first 64 of 128 slices of R-MAT 10M hold 94 % of
         // the hot entries and 78 % of the partial sums).  Measured NEGATIVE, so off by default: the reduction then competes
@@ -658,6 +666,13 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         bp->hot_wgs_first = (uint32_t)(wg_seg.size() - 1);
         if (cut) split(cut, (uint32_t)nh);
         bp->hot_wgs = (uint32_t)(wg_seg.size() - 1);
+    }
+    {   // cold pieces + short rows: few tiles (R-MAT 1M: 4 600) want one tile per wave, or the launch is a handful of waves per CU
+        uint64_t gather_tiles = 0;
+        int ncu2 = 0;
+        SPRS_TRY_HIP(hipDeviceGetAttribute(&ncu2, hipDeviceAttributeMultiprocessorCount, a->device));
+        for (uint32_t k = (uint32_t)nh; k <= NP; ++k) gather_tiles += bp->host_pieces[k].ntiles;
+        if (o.spmv_band_cold_tiles <= 0 && gather_tiles < 128ull * (uint64_t)(ncu2 > 0 ? ncu2 : 1)) bp->cold_tiles = 1;
     }
     for (uint32_t k = (uint32_t)nh; k <= NP; ++k) {
         BandPiece &d = bp->host_pieces[k];
@@ -783,7 +798,8 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         std::lock_guard<std::recursive_mutex> lock(a->mu);
         SPRS_TRY(band_scratch(bp, stream, &sc));
     }
-    const bool overlap = options().spmv_band_overlap != 2 && bp->hot_wgs && bp->cold_blocks;
+    // (a small plan keeps to one stream unless the overlap is asked for: R-MAT 1M 0.092 against 0.096 ms, profiles/r05p)
+    const bool overlap = options().spmv_band_overlap != 2 && bp->hot_wgs && bp->cold_blocks && (!bp->small || options().spmv_band_overlap == 1);
     const bool split_permute = overlap && options().spmv_band_split_permute != 2 && bp->hot_labels;
     const uint64_t span = acc ? bp->cols : (bp->cols > a->rows ? bp->cols : a->rows);
     hipStream_t cstream = overlap ? sc->aux : stream;
@@ -828,14 +844,16 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         if (!nwg) return SPRS_HIP_OK;
         const uint32_t lds = hot_lds_bytes(bp->xt_log2);
 #ifndef SPRS_HIP_EMU
-        static std::once_flag once;                                  // more than 64 KiB of dynamic LDS has to be asked for, once per kernel
-        static hipError_t attr_err = hipSuccess;
-        std::call_once(once, [&] {
-            attr_err = hipFuncSetAttribute((const void *)band_hot_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds_bytes(13));
-            if (attr_err == hipSuccess)
-                attr_err = hipFuncSetAttribute((const void *)band_hot_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds_bytes(14));
-        });
-        SPRS_TRY_HIP(attr_err);
+        {   // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
+            static std::mutex mu;
+            static std::unordered_map<int, bool> done;
+            std::lock_guard<std::mutex> lock(mu);
+            if (!done[a->device]) {
+                SPRS_TRY_HIP(hipFuncSetAttribute((const void *)band_hot_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds_bytes(13)));
+                SPRS_TRY_HIP(hipFuncSetAttribute((const void *)band_hot_kernel<14>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hot_lds_bytes(14)));
+                done[a->device] = true;
+            }
+        }
 #endif
         if (bp->xt_log2 == 13)
             hipLaunchKernelGGL((band_hot_kernel<13>), dim3(nwg), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
