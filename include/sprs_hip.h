@@ -157,7 +157,9 @@ int32_t sprs_hip_spmv_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t
                           double *y_dev, uint64_t y_len, int32_t accumulate, void *stream);
 
 /* One-shot host form (upload, multiply, download, synchronous): what a plain
- * `prod::mul_acc_mat_vec_csr(mat.view(), &x[..], &mut y[..])` call maps to. */
+ * `prod::mul_acc_mat_vec_csr(mat.view(), &x[..], &mut y[..])` call maps to.  The handle lives for one multiply, so it
+ * runs on the plain nnz-tiled plan: no re-laid-out copy of the matrix is built (the banded plan of a kept handle takes
+ * ~0.1 s to build on a 3e8-entry matrix for a 1 ms SpMV). */
 int32_t sprs_hip_spmv_f64_host(uint64_t rows, uint64_t cols, const void *indptr,
                                int32_t iptr_bytes, const void *indices, int32_t idx_bytes,
                                const double *data, const double *x, uint64_t x_len, double *y,
@@ -301,7 +303,14 @@ int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const 
  * name = "spmv_xcs_idx32": 1 (default): the sliced plan's own copies hold 32-bit column ids when cols < 2^32;
  * name = "spmv_sort_tiles": 1: tiles of the sliced plan's copies are stored sorted by column (default 0: measured slower);
  * name = "spmv_tile":      nnz per workgroup tile: 0 auto (default), 2048 or 4096;
- * name = "spmv_xmask":     timing experiments only (gathers x[col & mask]; results are wrong unless -1).
+ * name = "spmv_band*":     the banded plan (hot columns from LDS): spmv_band 0 auto / 1 on / 2 off, spmv_band_hot (slices, default
+ *                          128), spmv_band_tile (labels per slice: 16384 or 8192), spmv_band_split (row length from which a row
+ *                          is cut into pieces, default 24), spmv_band_rounds, spmv_band_hot_run, spmv_band_cold_tiles,
+ *                          spmv_band_overlap, spmv_band_split_permute, spmv_band_phases, spmv_band_hot_cut;
+ * name = "spgemm_*", "spmm_long_row", "pool", "pool_max_bytes": INTEGRATION.md, "Options".
+ * The whole table (name, default, range) is SPRS_HIP_OPTIONS in sprs_amd/csrc/common.hpp.  Developer switches — timing
+ * experiments with WRONG results (spgemm_debug, spmv_xmask, spmv_band_debug) and the profiling printout spgemm_prof — exist
+ * only in libraries built with -DSPRS_HIP_DEVTOOLS; this one rejects them.  get_option("devtools") tells which build it is.
  * Process-wide.  Unknown names / bad values return SPRS_HIP_INVALID_ARG. */
 int32_t sprs_hip_set_option(const char *name, int64_t value);
 int32_t sprs_hip_get_option(const char *name, int64_t *value);
