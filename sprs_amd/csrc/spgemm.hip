@@ -711,17 +711,20 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                                                              unsigned long long *__restrict__ prof,
                                                              const uint64_t *__restrict__ ub_dbg,
                                                              unsigned int *__restrict__ next_row) {
-    // the phase timers of option spgemm_prof (developer builds) live in LDS and are touched only when prof is set: kept in
-    // registers (ten 64-bit values per lane) they cost the numeric kernel 92 bytes of scratch per lane, i.e. ~20 GB of spill
-    // traffic per config-5 product (profiles/r05m: 40 GB written for 18 GB of output)
+    // The phase timers of option spgemm_prof (developer builds) live in LDS and are touched only when prof is set: kept in
+    // registers (ten 64-bit values per lane) they cost the numeric kernel 92 bytes of scratch per lane.  The release library
+    // compiles them out of the numeric kernel — NOT out of the counting kernel: without its (dead) timer branches that one
+    // kernel hangs on the hardware at config-5 size (49 instead of 70 VGPRs; small products and the CPU emulator pass; bisected
+    // kernel by kernel in round 3, cause not found), so there the branches stay, never taken.
+    constexpr bool TIMERS = DEVTOOLS || !NUMERIC;
     __shared__ unsigned long long ph_s[MID_BLOCK / WAVE][10];           // [wave][0..7 phases, 8 previous mark, 9 kernel start]
     unsigned long long *ph = ph_s[threadIdx.x / WAVE];
-    if (prof && (threadIdx.x & (WAVE - 1)) == 0) {
+    if (TIMERS && prof && (threadIdx.x & (WAVE - 1)) == 0) {
         for (int i = 0; i < 8; ++i) ph[i] = 0;
         ph[8] = ph[9] = (unsigned long long)wall_clock64();
     }
     auto mark = [&](int phase) {                                        // lane 0's view of the phases (debug option spgemm_prof)
-        if (prof && (threadIdx.x & (WAVE - 1)) == 0) {
+        if (TIMERS && prof && (threadIdx.x & (WAVE - 1)) == 0) {
             const unsigned long long now = (unsigned long long)wall_clock64();
             ph[phase] += now - ph[8];
             ph[8] = now;
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
         if constexpr (NUMERIC) out = off[t];
         uint32_t fresh = 0;
         mark(0);
-        const long long t_row = prof ? (long long)wall_clock64() : 0;
+        const long long t_row = (TIMERS && prof) ? (long long)wall_clock64() : 0;
         for (uint64_t w = 0; w < nwin; ++w) {
             const uint64_t win_lo = w << MID_WL;
             const uint32_t win_s = cur, win_e = q0;
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             const uint64_t tot = wave_sum_u64(fresh);
             if (lane == 0) count[t] = tot;
         }
-        if (prof && lane == 0) {
+        if (TIMERS && prof && lane == 0) {
             const unsigned long long dt = (unsigned long long)((long long)wall_clock64() - t_row);
             const uint64_t u = ub_dbg[r];
             const int c = u < 2048 ? 0 : u < 8192 ? 1 : u < 32768 ? 2 : 3;
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             atomicMax(&prof[16], dt);
         }
     }
-    if (prof && lane == 0) {
+    if (TIMERS && prof && lane == 0) {
         for (int i = 0; i < 6; ++i) atomicAdd(&prof[i], ph[i]);
         atomicMax(&prof[17], (unsigned long long)wall_clock64() - ph[9]);   // longest wave
         atomicAdd(&prof[18], (unsigned long long)wall_clock64() - ph[9]);
@@ -1036,14 +1039,15 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                                                               unsigned long long *__restrict__ prof,
                                                               const uint64_t *__restrict__ ub_dbg) {
     using Cfg = LgCfg<WL>;
-    // phase timers of option spgemm_prof (developer builds): in LDS, touched only when prof is set (see mid_rows_kernel)
+    // phase timers of option spgemm_prof (developer builds only: compiled out of the release library): in LDS (see mid_rows_kernel)
+    constexpr bool TIMERS = DEVTOOLS;
     __shared__ unsigned long long ph[10];                               // 0..7 phases, 8 previous mark, 9 task start (100 MHz ticks)
-    if (prof && threadIdx.x == 0) {
+    if (TIMERS && prof && threadIdx.x == 0) {
         for (int i = 0; i < 8; ++i) ph[i] = 0;
         ph[8] = ph[9] = (unsigned long long)wall_clock64();
     }
     auto mark = [&](int phase) {                                        // thread 0's view of the phases
-        if (prof && threadIdx.x == 0) {
+        if (TIMERS && prof && threadIdx.x == 0) {
             const unsigned long long now = (unsigned long long)wall_clock64();
             ph[phase] += now - ph[8];
             ph[8] = now;
@@ -1078,7 +1082,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const bool values = NUMERIC && c_data != nullptr;
     const bool lds_atomic = (flags & 1u) != 0;
     const bool retain_ok = values && (flags & 2u) != 0;
-    const bool no_order = (flags & 4u) != 0, no_emit = (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
+    const bool no_order = DEVTOOLS && (flags & 4u) != 0, no_emit = DEVTOOLS && (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
     const uint32_t ntok = 1u << ((flags >> 4) & 3u);                          // 1, 2 or 4 token chains (option spgemm_tokens)
     // a row whose k's fit one staged group: thread j keeps k_j, the bounds of B's row k_j and a_ik for the whole task
     const bool mine_k = one_group && tid < (uint32_t)(ae - as) && w_begin < w_end;
@@ -1259,7 +1263,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             mark(5);
         }
     }
-    if (prof && tid == 0) {
+    if (TIMERS && prof && tid == 0) {
         prof[blockIdx.x] = (unsigned long long)wall_clock64() - ph[9];
         const double per = (double)ub_dbg[r] / (double)nt;
         const int cls = per < 8192 ? 0 : per < 32768 ? 1 : per < 131072 ? 2 : per < 524288 ? 3 : 4;
