@@ -155,6 +155,107 @@ class DistSpMV:
             self._h = None
 
 
+class RowShardedBiCGSTAB:
+    """`sprs::linalg::bicgstab::BiCGSTAB` (sprs/src/sparse/linalg/bicgstab.rs:117-229) over the row-sharded SpMV: the
+    reason the all-gather of y exists — the gathered product of one iteration feeds the next.  Every rank owns the rows
+    [r_g, r_{g+1}) of A and the same block of every solver vector (x, r, rhat, p, v, s, t, b); an SpMV gathers the full
+    operand first (the driver's direct all-gather-v), multiplies the local row block, and leaves the result sharded; the
+    four dot products of an iteration are local sums + one all_reduce each.  Control flow, restarts and the order of the
+    scalar operations are the reference's (`step`, `soft_restart`, `hard_restart`, `solve`); the dots are summed block by
+    block, so the iterates equal the serial solver's to rounding, not bit for bit.
+
+    sh: a RowShardedSpMV of the (square) matrix.  x0 / b: FULL vectors (torch, on the rank's device); the solution comes
+    back gathered (`x()`)."""
+
+    def __init__(self, sh, x0, b, soft_restart_threshold=0.1):
+        if sh.rows != sh.cols or x0.numel() != sh.cols or b.numel() != sh.rows:
+            raise ValueError("Dimension mismatch")
+        self.sh, self.group = sh, sh.group
+        self.r0, self.r1 = sh.r0, sh.r1
+        self.full = torch.zeros(sh.cols, dtype=torch.float64, device=x0.device)      # the gathered operand of an SpMV
+        self.iteration_count = self.soft_restart_count = self.hard_restart_count = 0
+        self.soft_restart_threshold = soft_restart_threshold
+        self.b = b[self.r0:self.r1].clone()
+        self.x = x0[self.r0:self.r1].clone()
+        self.r = self.b - self._matvec(self.x)                       # new(): r = b - A x0 (bicgstab.rs:124)
+        self.rhat = self.r.clone()
+        self.p = self.r.clone()
+        self.err = self._dot(self.r, self.r) ** 0.5
+        self.rho = self.err * self.err
+
+    # ---- the two distributed primitives -----------------------------------------------------------------------------
+    def _matvec(self, v_block):
+        """(A v)[r0:r1] from the rank's block of v: all-gather-v of v, then the local row-block multiply"""
+        sh = self.sh
+        sh.y[self.r0:self.r1].copy_(v_block)          # the exchange gathers sh.y: borrow it for the operand
+        sh.exchange()
+        self.full.copy_(sh.y)
+        out = torch.empty_like(v_block)
+        sh.local_spmv(sh.block, self.full, out)
+        return out
+
+    def _dot(self, u, v):
+        t = torch.dot(u, v).reshape(1)
+        if self.sh.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
+
+    # ---- the reference's solver, operand for operand ------------------------------------------------------------------
+    def soft_restart(self):
+        self.soft_restart_count += 1
+        self.rhat = self.r.clone()
+        self.rho = self.err * self.err
+        self.p = self.r.clone()
+
+    def hard_restart(self):
+        self.hard_restart_count += 1
+        self.r = self.b - self._matvec(self.x)
+        self.err = self._dot(self.r, self.r) ** 0.5
+        self.soft_restart()
+        self.soft_restart_count -= 1
+
+    def step(self):
+        self.iteration_count += 1
+        v = self._matvec(self.p)
+        alpha = self.rho / self._dot(self.rhat, v)
+        h = self.x + self.p * alpha
+        s = self.r - v * alpha
+        t = self._matvec(s)
+        omega = self._dot(t, s) / self._dot(t, t)
+        self.x = h + s * omega
+        self.r = s - t * omega
+        self.err = self._dot(self.r, self.r) ** 0.5
+        rho_prev = self.rho
+        self.rho = self._dot(self.rhat, self.r)
+        if abs(self.rho) / (self.err * self.err) < self.soft_restart_threshold:
+            self.soft_restart()
+        else:
+            beta = (self.rho / rho_prev) * (alpha / omega)
+            self.p = self.r + (self.p - v * omega) * beta
+        return self.err
+
+    @classmethod
+    def solve(cls, sh, x0, b, tol, max_iter, soft_restart_threshold=0.1):
+        """BiCGSTAB::solve (bicgstab.rs:148-171); `converged` tells Ok from Err (iteration limit reached, results kept)"""
+        solver = cls(sh, x0, b, soft_restart_threshold)
+        solver.converged = False
+        for _ in range(max_iter):
+            solver.step()
+            if solver.err < tol:
+                solver.hard_restart()             # the true residual, before convergence is claimed
+                if solver.err < tol:
+                    solver.converged = True
+                    break
+        return solver
+
+    def x_full(self):
+        """the solution, gathered on every rank"""
+        sh = self.sh
+        sh.y[self.r0:self.r1].copy_(self.x)
+        sh.exchange()
+        return sh.y.clone()
+
+
 def hip_local_spgemm(a_block, b):
     """the HIP SpGEMM on torch-resident operands (borrowed, no copy); returns a DeviceCsMat"""
     from . import smmp

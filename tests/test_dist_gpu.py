@@ -68,6 +68,44 @@ def test_world_of_one_through_rccl(hip):
     del d
 
 
+def test_row_sharded_bicgstab_on_the_hip_kernels(hip):
+    """the row-sharded BiCGSTAB driver (sprs_amd/dist.py, twin of linalg/bicgstab.rs:117-229) with the HIP SpMV as its local
+    kernel — a world of one: every SpMV of the solver goes through the device path; iterates equal the serial oracle's to
+    rounding"""
+    import torch
+    from oracle import oracle
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    from sprs_amd.dist import RowShardedBiCGSTAB, RowShardedSpMV
+    dev = torch.device("cuda", 0)
+    grid = 96
+    n = grid * grid
+    indptr, indices, data = gen.grid_laplacian(grid, grid, device=dev)
+    data = data.clone()
+    rows_of = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]))
+    diag = indices == rows_of
+    data[diag] = data[diag].abs() + 1.5
+    data[indices > rows_of] *= 0.7
+    handles = {}
+
+    def local_spmv(block, xv, y_block):
+        if id(block) not in handles:
+            rows_b, cols_b, ip, ix, dt = block
+            handles[id(block)] = DeviceCsMat.wrap_torch((rows_b, cols_b), ip, ix, dt)
+        prod.csmat_mul_vec(handles[id(block)], DeviceVec.borrow(xv), out=DeviceVec.borrow(y_block))
+        torch.cuda.synchronize()
+
+    sh = RowShardedSpMV((n, n), indptr, indices, data, local_spmv)
+    b = gen.dense_vector(n, seed=5, device=dev)
+    x0 = torch.zeros(n, dtype=torch.float64, device=dev)
+    sol = RowShardedBiCGSTAB.solve(sh, x0, b, 1e-10, 600)
+    x_ref, info = oracle.bicgstab((n, n), indptr.cpu().numpy().astype(np.uint64), indices.cpu().numpy().astype(np.uint64),
+                                  data.cpu().numpy(), x0.cpu().numpy(), b.cpu().numpy(), 1e-10, 600)
+    assert sol.converged and info["converged"]
+    assert abs(sol.iteration_count - info["iteration_count"]) <= 2
+    assert rel_err(sol.x_full().cpu().numpy(), x_ref) <= 1e-8
+
+
 def _rank_main(rank, world, port, n, out):
     import os
     import torch
