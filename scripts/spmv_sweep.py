@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--oracle", action="store_true", help="check the first configuration against the CPU oracle")
     ap.add_argument("--repeat", type=int, default=1, help="run the whole list of configurations this many times, in rotation (run-to-run "
                                                           "drift of a box is several per cent: compare medians)")
+    ap.add_argument("--row-block", default="", help="g/G: only the g-th of G cost-balanced row blocks (what rank g of a G-GPU run multiplies)")
     ap.add_argument("configs", nargs="+")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -50,13 +51,22 @@ def main():
     else:
         sys.exit("unknown workload")
     indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=idt)
+    rows = n
+    if args.row_block:
+        g, G = (int(v) for v in args.row_block.split("/"))
+        cuts = gen.balanced_row_blocks(indptr, G, row_weight=8.0)
+        r0, r1 = cuts[g], cuts[g + 1]
+        lo, hi = int(indptr[r0]), int(indptr[r1])
+        indptr = (indptr[r0:r1 + 1] - indptr[r0]).contiguous()
+        indices, data = indices[lo:hi].clone(), data[lo:hi].clone()
+        rows = r1 - r0
     nnz = indices.numel()
     x = gen.dense_vector(n, seed=3, device=dev)
-    y = torch.zeros(n, dtype=torch.float64, device=dev)
-    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    y = torch.zeros(rows, dtype=torch.float64, device=dev)
+    a = DeviceCsMat.wrap_torch((rows, n), indptr, indices, data)
     xv, yv = DeviceVec.borrow(x), DeviceVec.borrow(y)
     stream = torch.cuda.current_stream()
-    alg = nnz * (8 + args.idx_bytes) + (n + 1) * args.idx_bytes + 2 * n * 8
+    alg = nnz * (8 + args.idx_bytes) + (rows + 1) * args.idx_bytes + (n + rows) * 8
     first = None
     for spec in args.configs:
         for kv in filter(None, spec.partition(":")[2].split(",")):
@@ -95,8 +105,8 @@ def main():
             if args.oracle:
                 from oracle import oracle   # checker only
                 npdt = np.uint64 if args.idx_bytes == 8 else np.uint32
-                yh = np.zeros(n)
-                oracle.mul_acc_mat_vec_csr((n, n), indptr.cpu().numpy().view(npdt), indices.cpu().numpy().view(npdt),
+                yh = np.zeros(rows)
+                oracle.mul_acc_mat_vec_csr((rows, n), indptr.cpu().numpy().view(npdt), indices.cpu().numpy().view(npdt),
                                            data.cpu().numpy(), x.cpu().numpy(), yh)
                 yg = y.cpu().numpy()
                 den = np.maximum(np.abs(yh), np.abs(yg))

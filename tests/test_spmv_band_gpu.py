@@ -159,3 +159,34 @@ def test_band_equals_sliced_and_plain_within_rounding(hip):
     for name, y in out.items():
         assert rel_err(y, ref) <= TOL, name
     assert rel_err(out["band"], out["plain"]) <= 1e-13 and rel_err(out["band"], out["sliced"]) <= 1e-13
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_shapes_and_plan_options(hip, seed):
+    """seeded random ragged matrices (empty rows, rows of one entry, rows around the split, hub rows, a column range nobody
+    references) under random plan geometries — tile size, slices, phases, rounds, range lengths, cold range lengths, the
+    two-part reduction — all against the oracle, the accumulate form and the bit-identical repeat included (check_band)"""
+    rng = np.random.default_rng(1000 + seed)
+    rows = int(rng.integers(200, 1500))
+    cols = int(rng.integers(9000, 70000))
+    kinds = rng.integers(0, 6, size=rows)
+    lens = np.where(kinds == 0, 0, np.where(kinds == 1, 1, np.where(kinds == 2, rng.integers(20, 30, size=rows),
+                    np.where(kinds == 3, rng.integers(2, 24, size=rows), rng.integers(24, 200, size=rows)))))
+    hubs = rng.choice(rows, size=3, replace=False)
+    lens[hubs] = rng.integers(2000, min(cols, 9000), size=3)
+    shape, ip, ix, dt = ragged_csr([int(v) for v in lens], cols, seed=seed)
+    ix = (ix.astype(np.int64) * 7 // 8).astype(ix.dtype)                 # the top eighth of the columns is never referenced ...
+    for r in range(rows):                                                # ... (keep the rows strictly increasing)
+        seg = ix[int(ip[r]):int(ip[r + 1])]
+        if seg.size and np.any(np.diff(seg.astype(np.int64)) <= 0):
+            ix[int(ip[r]):int(ip[r + 1])] = np.unique(seg)[:1].repeat(seg.size) + np.arange(seg.size, dtype=ix.dtype)
+    ix = np.minimum(ix, cols - 1)
+    ok = all(np.all(np.diff(ix[int(ip[r]):int(ip[r + 1])].astype(np.int64)) > 0) for r in range(rows))
+    if not ok:
+        pytest.skip("degenerate draw")
+    tile = int(rng.choice([8192, 16384]))
+    hot = int(rng.integers(1, max(2, cols // tile + 1)))
+    opts = dict(rounds=int(rng.integers(1, 6)), tile=tile, cold_tiles=int(rng.integers(1, 6)), hot_run=int(rng.integers(1, 6)),
+                split=int(rng.choice([2, 8, 24, 40])))
+    with band_options(hip, hot, int(rng.integers(1, 4)), **opts):
+        check_band(hip, shape, ip, ix, dt, seed=seed)
