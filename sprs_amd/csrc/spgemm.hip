@@ -713,10 +713,8 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                                                              unsigned int *__restrict__ next_row) {
     // The phase timers of option spgemm_prof (developer builds) live in LDS and are touched only when prof is set: kept in
     // registers (ten 64-bit values per lane) they cost the numeric kernel 92 bytes of scratch per lane.  The release library
-    // compiles them out of the numeric kernel — NOT out of the counting kernel: without its (dead) timer branches that one
-    // kernel hangs on the hardware at config-5 size (49 instead of 70 VGPRs; small products and the CPU emulator pass; bisected
-    // kernel by kernel in round 3, cause not found), so there the branches stay, never taken.
-    constexpr bool TIMERS = DEVTOOLS || !NUMERIC;
+    // compiles them out.
+    constexpr bool TIMERS = DEVTOOLS;
     __shared__ unsigned long long ph_s[MID_BLOCK / WAVE][10];           // [wave][0..7 phases, 8 previous mark, 9 kernel start]
     unsigned long long *ph = ph_s[threadIdx.x / WAVE];
     if (TIMERS && prof && (threadIdx.x & (WAVE - 1)) == 0) {
@@ -755,11 +753,16 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
     wave_sync_lds();
     // The waves draw rows from a counter (the list is sorted by cost, costliest first): which wave takes which row changes
     // nothing in the result — every row is computed by one wave on its own, into its own piece of C.
-    for (;;) {
+    // (Written as `for (;;) { q = draw; if (q >= n_mid) break; ... }` this loop was compiled — once the dead timer branches of
+    // the developer option were gone from the counting kernel — into a nested loop whose inner level re-entered with the drawn
+    // number reset to 0: config 5 never finished on the hardware.  Bisected kernel by kernel in round 3; with the draw in the
+    // loop header the same code is compiled as one loop.)
+    auto draw_row = [&]() -> uint64_t {
         unsigned int qq = 0;
         if (lane == 0) qq = atomicAdd(next_row, 1u);
-        const uint64_t q = (uint64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)qq);
-        if (q >= n_mid) break;
+        return (uint64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)qq);
+    };
+    for (uint64_t q = draw_row(); q < n_mid; q = draw_row()) {
         const uint64_t t = mid_list[q];
         const uint64_t r = task_row[t];
         const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
