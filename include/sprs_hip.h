@@ -206,6 +206,39 @@ int32_t sprs_hip_bicgstab_f64(sprs_hip_csmat *a, const double *x0_dev, const dou
                               double tol, uint64_t max_iter, double soft_restart_threshold, double *x_dev,
                               sprs_hip_bicgstab_info *info, void *stream);
 
+/* ---- Gauss-Seidel: the other caller that loops on the SpMV -- */
+
+/* What gauss_seidel() of the reference's heat example returns (sprs/examples/heat.rs:103-139):
+ * Ok((it, error)) -> converged = 1, iterations = it (index of the sweep after which error < eps);
+ * Err(error)      -> converged = 0, iterations = max_iter.  levels = length of the longest chain of
+ * rows that must be swept one after the other (what bounds a sweep on the device). */
+typedef struct sprs_hip_gauss_seidel_info {
+    uint64_t iterations;
+    double error;
+    int32_t converged;
+    uint64_t levels;
+} sprs_hip_gauss_seidel_info;
+
+/* Twin of gauss_seidel(mat, x, rhs, max_iter, eps) (heat.rs:103-139) with device-resident vectors:
+ * up to max_iter sweeps  x[row] = (rhs[row] - sum_{col != row} val * x[col]) / diag  over the rows in
+ * order, x updated IN PLACE (x_dev is the start vector and the result), each followed by the
+ * reference's convergence test  error = sqrt(sum_i ((A x)_i - rhs_i)) < eps  (the SIGNED sum of the
+ * residual, as the reference has it: a negative sum gives NaN and the sweeps go on).  A sweep is a
+ * recurrence over the rows; on the device the rows run in dependency-level order (computed once per
+ * handle) and a row reads this sweep's value of an earlier row as soon as that row has published
+ * it, so every x[row] is computed from the same operands in the same order as on the CPU: the
+ * iterates are bit-identical to the reference's.  `error` is A x by sprs_hip_spmv_f64 and a fixed
+ * tree sum (ndarray's eight-accumulator sum rounds differently: equal to ~1e-13 of sum |r_i|).
+ * A: square CSR handle with fewer than 2^32 rows (SPRS_HIP_STORAGE_MISMATCH for CSC: the reference's
+ * outer_iterator would sweep the transpose); x_dev, rhs_dev: n doubles, not aliased.
+ * SPRS_HIP_DIM_MISMATCH unless A.rows == A.cols == n (heat.rs:109-110); SPRS_HIP_BAD_STRUCTURE for a
+ * row without a stored diagonal entry when a sweep would reach it (`diag.unwrap()`, heat.rs:127).
+ * Running out of sweeps is not an error (Err(error) in the reference): status OK, converged = 0.
+ * Blocks until done (the convergence test needs `error` on the host).  Deterministic. */
+int32_t sprs_hip_gauss_seidel_f64(sprs_hip_csmat *a, double *x_dev, const double *rhs_dev, uint64_t n,
+                                  uint64_t max_iter, double eps, sprs_hip_gauss_seidel_info *info,
+                                  void *stream);
+
 /* ---- SpGEMM ------------------------------------------------------------- */
 
 /* Twin of smmp::mul_csr_csr (smmp.rs:196-416): C = A * B, all CSR, same index

@@ -292,6 +292,25 @@ def bicgstab(shape, indptr, indices, data, x0, b, tol, max_iter, soft_restart_th
     return x, {k: getattr(info, k) for k, _ in BicgstabInfo._fields_}
 
 
+class GaussSeidelInfo(C.Structure):
+    _fields_ = [("iterations", C.c_uint64), ("error", C.c_double), ("converged", C.c_int32)]
+
+
+def gauss_seidel(shape, indptr, indices, data, x, rhs, max_iter, eps):
+    """gauss_seidel (sprs/examples/heat.rs:103-139) on a CSR matrix: sweeps in place over a COPY of x.
+    Returns (x, info dict): converged 1 = Ok((iterations, error)), 0 = Err(error)."""
+    n = shape[0]
+    assert shape[0] == shape[1] == np.asarray(x).size == np.asarray(rhs).size
+    indptr, indices, data = _canon(indptr, indices, data)
+    x = np.array(x, dtype=np.float64, copy=True)
+    rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+    info = GaussSeidelInfo()
+    f = getattr(lib(), "oracle_gauss_seidel_" + _suffix(indices, indptr))
+    _chk(f(C.c_uint64(n), _p(indptr), _p(indices), _p(data), _p(x), _p(rhs), C.c_uint64(max_iter), C.c_double(eps),
+           C.byref(info)))
+    return x, {k: getattr(info, k) for k, _ in GaussSeidelInfo._fields_}
+
+
 def triplets_to_cs(shape, row_inds, col_inds, data, storage="CSR", idx_dtype=np.uint64):
     """TriMatIter::into_cs (sprs/src/sparse/triplet_iter.rs:127-224): sort the triplets by (outer, inner),
     fold equal (row, col) neighbours with `slot = slot + next` (left to right, :168-171), fill indptr.

@@ -578,3 +578,85 @@ int SUF(oracle_bicgstab)(uint64_t n, const PTR_T *ip, const IDX_T *ix, const dou
     free(r);
     return ORACLE_OK;
 }
+
+
+/* ---- Gauss-Seidel sweep of the heat example (the other caller that loops on the SpMV) ----
+ * gauss_seidel()  (sprs/examples/heat.rs:103-139), statement for statement:
+ *   for every sweep: for every row in order: sigma = sum of val * x[col] over the stored entries with col != row, in entry
+ *   order, reading x IN PLACE (columns before the row already hold this sweep's values); diag = the entry with col == row
+ *   (`diag.unwrap()`: a row without one panics, heat.rs:127 -> ORACLE_BAD_STRUCTURE); x[row] = (rhs[row] - sigma) / diag;
+ *   after the sweep  error = (&mat * &x - rhs).sum().sqrt()  — the SIGNED sum of the residual, as the reference has it
+ *   (a negative sum gives NaN, and `NaN < eps` keeps iterating) — and Ok((it, error)) as soon as error < eps, Err(error)
+ *   after max_iter sweeps.  (The error computed before the first sweep, heat.rs:111, is only returned when max_iter = 0.)
+ * `&mat * &x` is csr_mulacc_dense_colmaj on a zeroed vector (csmat.rs:2119-2158, prod.rs:274-298): the SpMV hot path.
+ * `.sum()` of a contiguous ndarray is numeric_util::unrolled_fold — THIRD-PARTY crate ndarray (sprs/Cargo.toml:24,
+ * ">=0.15.0, <0.18"; not vendored under /root/reference): eight interleaved partial sums p0..p7 over blocks of eight,
+ * combined as ((((0 + (p0+p4)) + (p1+p5)) + (p2+p6)) + (p3+p7)), then the < 8 trailing elements one by one.  Restated
+ * from the published source of ndarray 0.15 / 0.16 (src/numeric_util.rs); PARITY UNPINNED for this one function: the
+ * example asserts nothing and no Rust toolchain is here, so the tests compare `error` to 1e-10 of sum |r_i| only, and pin x by
+ * an independent line-by-line Python restatement and a dense solve (tests/test_oracle_golden.py).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t iterations;   /* Ok((it, _)): index of the sweep after which error < eps; Err: max_iter */
+    double error;
+    int32_t converged;     /* Ok = 1, Err = 0 */
+} SUF(oracle_gauss_seidel_info);
+
+static double SUF(ndarray_sum)(const double *xs, uint64_t n)
+{
+    double acc = 0.0, p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0, p5 = 0.0, p6 = 0.0, p7 = 0.0;
+    while (n >= 8) {
+        p0 = p0 + xs[0]; p1 = p1 + xs[1]; p2 = p2 + xs[2]; p3 = p3 + xs[3];
+        p4 = p4 + xs[4]; p5 = p5 + xs[5]; p6 = p6 + xs[6]; p7 = p7 + xs[7];
+        xs += 8; n -= 8;
+    }
+    acc = acc + (p0 + p4);
+    acc = acc + (p1 + p5);
+    acc = acc + (p2 + p6);
+    acc = acc + (p3 + p7);
+    for (uint64_t i = 0; i < n; ++i) acc = acc + xs[i];
+    return acc;
+}
+
+static double SUF(gs_error)(uint64_t n, const PTR_T *ip, const IDX_T *ix, const double *dt, const double *x,
+                            const double *rhs, double *work)
+{
+    SUF(bicg_spmv)(n, ip, ix, dt, x, work);                    /* &mat * &x: 0 + products in entry order */
+    for (uint64_t i = 0; i < n; ++i) work[i] = work[i] - rhs[i];
+    return sqrt(SUF(ndarray_sum)(work, n));
+}
+
+int SUF(oracle_gauss_seidel)(uint64_t n, const PTR_T *ip, const IDX_T *ix, const double *dt, double *x,
+                             const double *rhs, uint64_t max_iter, double eps, SUF(oracle_gauss_seidel_info) *info)
+{
+    double *work = (double *)malloc(8 * n + 64);
+    if (!work) return ORACLE_BAD_STRUCTURE;
+    double error = SUF(gs_error)(n, ip, ix, dt, x, rhs, work);                         /* heat.rs:111 */
+    for (uint64_t it = 0; it < max_iter; ++it) {
+        for (uint64_t row = 0; row < n; ++row) {                                       /* outer_iterator().enumerate() */
+            double sigma = 0.0, diag = 0.0;
+            int have = 0;
+            for (uint64_t p = (uint64_t)ip[row]; p < (uint64_t)ip[row + 1]; ++p) {
+                const uint64_t col = (uint64_t)ix[p];
+                if (col != row) {
+                    const double prod = dt[p] * x[col];
+                    sigma = sigma + prod;                                              /* sigma += val * x[[col_ind]] */
+                } else {
+                    diag = dt[p];
+                    have = 1;
+                }
+            }
+            if (!have) { free(work); return ORACLE_BAD_STRUCTURE; }                    /* diag.unwrap() */
+            x[row] = (rhs[row] - sigma) / diag;
+        }
+        error = SUF(gs_error)(n, ip, ix, dt, x, rhs, work);
+        if (error < eps) {
+            info->iterations = it; info->error = error; info->converged = 1;
+            free(work);
+            return ORACLE_OK;
+        }
+    }
+    info->iterations = max_iter; info->error = error; info->converged = 0;
+    free(work);
+    return ORACLE_OK;
+}

@@ -42,6 +42,16 @@ pub struct sprs_hip_bicgstab_info {
     pub converged: i32,
 }
 
+/// result of gauss_seidel (include/sprs_hip.h; the reference's examples/heat.rs:103-139)
+#[repr(C)]
+#[derive(Debug, Clone, Copy, Default)]
+pub struct sprs_hip_gauss_seidel_info {
+    pub iterations: u64,
+    pub error: f64,
+    pub converged: i32,
+    pub levels: u64,
+}
+
 extern "C" {
     pub fn sprs_hip_last_error() -> *const c_char;
     pub fn sprs_hip_last_hip_code() -> i32;
@@ -59,6 +69,8 @@ extern "C" {
     pub fn sprs_hip_bicgstab_f64(a: *mut sprs_hip_csmat, x0_dev: *const f64, b_dev: *const f64, n: u64, tol: f64,
                                  max_iter: u64, soft_restart_threshold: f64, x_dev: *mut f64,
                                  info: *mut sprs_hip_bicgstab_info, stream: *mut c_void) -> i32;
+    pub fn sprs_hip_gauss_seidel_f64(a: *mut sprs_hip_csmat, x_dev: *mut f64, rhs_dev: *const f64, n: u64, max_iter: u64,
+                                     eps: f64, info: *mut sprs_hip_gauss_seidel_info, stream: *mut c_void) -> i32;
     pub fn sprs_hip_csmat_upload(
         out: *mut *mut sprs_hip_csmat, storage: i32, rows: u64, cols: u64,
         indptr: *const c_void, iptr_bytes: i32, indices: *const c_void, idx_bytes: i32,

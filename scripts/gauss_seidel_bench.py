@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Gauss-Seidel sweep (twin of gauss_seidel() of the reference's heat example, heat.rs:103-139) on the heat system of a
+G x G grid: time per sweep on the device (sweep kernel + the residual SpMV + the convergence scalar, as the reference's loop
+has them), the one-time plan (level order on the host, SpMV plan), the CPU oracle's time per sweep beside it, and parity:
+the iterate after K sweeps bit for bit against the oracle (at the full size: the oracle sweeps 1.7e7 rows in ~0.4 s).
+usage: gauss_seidel_bench.py [G] [K] [blocks_per_cu ...]     (defaults 4096 3 and the library's default)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sprs_amd                                               # noqa: E402
+from sprs_amd.device import DeviceCsMat, DeviceVec           # noqa: E402
+from sprs_amd.linalg import gauss_seidel                      # noqa: E402
+from oracle import oracle                                     # noqa: E402  (the checker and the CPU baseline, nothing else)
+
+
+def main():
+    g = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    blocks = [int(v) for v in sys.argv[3:]] or [0]
+    shape, ip, ix, dt = oracle.grid_laplacian(g, g)
+    n = g * g
+    i, j = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+    border = (i == 0) | (i == g - 1) | (j == 0) | (j == g - 1)
+    rhs = np.where(border, (i + j).astype(np.float64), 0.0).reshape(-1)
+    del i, j, border
+    x0 = np.zeros(n)
+    a = DeviceCsMat.from_host(shape, ip, ix, dt)
+    d_rhs = DeviceVec.from_host(rhs)
+    t0 = time.perf_counter()
+    x = DeviceVec.from_host(x0)
+    r = gauss_seidel(a, x, d_rhs, 1, -1.0)
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    x_ref, info = oracle.gauss_seidel(shape, ip, ix, dt, x0, rhs, k, -1.0)
+    cpu = (time.perf_counter() - t0) / max(k, 1)
+    alg = ix.size * (8 + ix.itemsize) + (n + 1) * ip.itemsize + 4 * n * 8      # matrix once, x old + new, rhs, order (4 B) ~ per sweep
+    for b in blocks:
+        sprs_amd.set_option("gauss_seidel_blocks", b)
+        x = DeviceVec.from_host(x0)
+        gauss_seidel(a, x, d_rhs, 1, -1.0)                     # warm
+        times = {}
+        for kk in (k, 4 * k):
+            x = DeviceVec.from_host(x0)
+            t0 = time.perf_counter()
+            res = gauss_seidel(a, x, d_rhs, kk, -1.0)
+            times[kk] = time.perf_counter() - t0
+            if kk == k:
+                got = x.to_host()
+        per = (times[4 * k] - times[k]) / (3 * k)
+        same = bool(np.array_equal(got, x_ref))
+        print(json.dumps({"grid": g, "rows": n, "nnz": int(ix.size), "levels": res.levels, "blocks_per_cu": b or "default",
+                          "ms_per_sweep_with_residual": round(per * 1e3, 3), "us_per_level": round(per * 1e6 / res.levels, 3),
+                          "first_call_s_plans_included": round(first, 3), "oracle_ms_per_sweep_with_residual": round(cpu * 1e3, 1),
+                          "speedup_vs_one_core": round(cpu / per, 1), "streamed_GBs": round(alg / per / 1e9, 1),
+                          "iterate_after_%d_sweeps_bit_identical" % k: same}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

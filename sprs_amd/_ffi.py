@@ -50,6 +50,7 @@ SIGNATURES = {
     "sprs_hip_spgemm_plan_numeric": (i32, [vp, vp, vp, vp]),
     "sprs_hip_spgemm_plan_free": (i32, [vp]),
     "sprs_hip_bicgstab_f64": (i32, [vp, vp, vp, u64, C.c_double, u64, C.c_double, vp, vp, vp]),
+    "sprs_hip_gauss_seidel_f64": (i32, [vp, vp, vp, u64, u64, C.c_double, vp, vp]),
     "sprs_hip_csmat_upload": (i32, [P(vp), i32, u64, u64, vp, i32, vp, i32, vp, i32]),
     "sprs_hip_csmat_wrap_device": (i32, [P(vp), i32, u64, u64, u64, vp, i32, vp, i32, vp]),
     "sprs_hip_csmat_info": (i32, [vp, P(u64), P(u64), P(u64), P(i32), P(i32), P(i32)]),

@@ -534,6 +534,7 @@ int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m) {
     std::lock_guard<std::recursive_mutex> lock(m->mu);
     m->plan.release();
     m->mm.release();
+    m->gs.release();
     return SPRS_HIP_OK;
 }
 
@@ -589,6 +590,7 @@ int32_t sprs_hip_csmat_free(sprs_hip_csmat *m) {
     if (!m) return SPRS_HIP_OK;
     m->plan.release();
     m->mm.release();
+    m->gs.release();
     if (m->owns) {
         if (m->indptr) (void)hipFree(m->indptr);
         pool_free(m->indices, m->cap_indices, m->device);
@@ -691,6 +693,7 @@ int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
     c->mm.release();
+    c->gs.release();                        // (the level order reads the structure only, but "has a diagonal" may change with it)
     return spgemm_numeric(a, b, c);
 }
 
@@ -735,6 +738,7 @@ int32_t sprs_hip_spgemm_plan_numeric(sprs_hip_spgemm_plan *plan, const sprs_hip_
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
     c->mm.release();
+    c->gs.release();                        // (the level order reads the structure only, but "has a diagonal" may change with it)
     return spgemm_plan_numeric(plan, a, b, c);
 }
 
@@ -757,6 +761,17 @@ int32_t sprs_hip_bicgstab_f64(sprs_hip_csmat *a, const double *x0_dev, const dou
         return SPRS_HIP_OK;
     }
     return bicgstab_f64(a, x0_dev, b_dev, n, tol, max_iter, soft_restart_threshold, x_dev, info, (hipStream_t)stream);
+}
+
+int32_t sprs_hip_gauss_seidel_f64(sprs_hip_csmat *a, double *x_dev, const double *rhs_dev, uint64_t n, uint64_t max_iter,
+                                  double eps, sprs_hip_gauss_seidel_info *info, void *stream) {
+    clear_error();
+    if (!a) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    if (a->rows != a->cols || a->rows != n) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");   // heat.rs:109-110
+    if (a->storage != SPRS_HIP_CSR) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Gauss-Seidel sweeps the rows of a CSR matrix");
+    if (n && (!x_dev || !rhs_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL vector");
+    if (x_dev && x_dev == rhs_dev) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "x_dev may not alias rhs_dev");
+    return gauss_seidel_f64(a, x_dev, rhs_dev, n, max_iter, eps, info, (hipStream_t)stream);
 }
 
 int32_t sprs_hip_spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c) {

@@ -87,6 +87,7 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_winlog, 17, 16, 19, 0)     /* log2 of the widest column window of a large-row task */                                \
     X(spgemm_minwin, 13, 11, 16, 0)     /* log2 of the narrowest column window of a heavy row */                                  \
     X(spgemm_heavy, 131072, 1024, INT64_MAX, 0) /* a row of more products is cut into one task per (narrower) column window */    \
+    X(gauss_seidel_blocks, 0, 0, 32, 0) /* workgroups (4 waves) per CU of the Gauss-Seidel sweep kernel (0 = default 2) */             \
     X(pool, 1, 0, 1, 0)                 /* keep released result blocks (>= 1 MiB) for the next result instead of hipFree */        \
     X(pool_max_bytes, 128ll << 30, 0, INT64_MAX, 0) /* cap on the bytes the pool may hold */
 
@@ -152,6 +153,15 @@ struct SpmmPlan {
     void release();
 };
 
+// ---- Gauss-Seidel plan: the rows in dependency-level order (gauss_seidel.hip) ---------------------
+struct GsPlan {
+    bool built = false;
+    uint32_t *order = nullptr;         // device, rows entries: row swept at position q (levels ascending, rows ascending inside a level)
+    uint64_t nlevels = 0;
+    uint64_t no_diag_row = UINT64_MAX; // first row without a stored diagonal entry (the reference's diag.unwrap() panics there)
+    void release();
+};
+
 }  // namespace sprs_hip
 
 // Device twin of CsMatBase (sprs/src/sparse.rs:94-122).
@@ -175,6 +185,7 @@ struct sprs_hip_csmat {
     std::recursive_mutex mu;   // guards plan / mm: held from the look-up (or rebuild) of a plan until the kernels that read it are launched
     sprs_hip::SpmvPlan plan;
     sprs_hip::SpmmPlan mm;
+    sprs_hip::GsPlan gs;
 
     uint64_t outer() const { return storage == SPRS_HIP_CSR ? rows : cols; }
     uint64_t inner() const { return storage == SPRS_HIP_CSR ? cols : rows; }
@@ -223,6 +234,9 @@ int32_t to_other_storage(const sprs_hip_csmat *m, sprs_hip_csmat **out);
 // bicgstab.hip
 int32_t bicgstab_f64(sprs_hip_csmat *a, const double *x0, const double *b, uint64_t n, double tol, uint64_t max_iter,
                      double soft_restart_threshold, double *x, sprs_hip_bicgstab_info *info, hipStream_t stream);
+// gauss_seidel.hip
+int32_t gauss_seidel_f64(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uint64_t max_iter, double eps,
+                         sprs_hip_gauss_seidel_info *info, hipStream_t stream);
 int32_t slice_outer(const sprs_hip_csmat *m, uint64_t start, uint64_t end, sprs_hip_csmat **out);
 // abi.hip
 int32_t alloc_csmat(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64_t cols, uint64_t nnz,

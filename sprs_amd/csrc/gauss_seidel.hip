@@ -1,0 +1,373 @@
+// Device Gauss-Seidel: twin of gauss_seidel() in the reference's heat example (sprs/examples/heat.rs:103-139) —
+// SURVEY §8 (f3), the second "caller that loops on the SpMV": every sweep is followed by the residual `&mat * &x - rhs`,
+// which is the SpMV hot path (csmat.rs:2119-2158 -> prod::csr_mulacc_dense_colmaj).
+//
+// The sweep itself is a recurrence: row i reads, for every stored column c < i, the value row c has just been given IN THIS
+// sweep, and for c > i the value of the previous sweep (heat.rs:113-131 updates x in place).  What can run side by side is
+// fixed by the structure alone: level(i) = 1 + max level(c) over the stored c < i (0 without any).  Rows of one level do
+// not read each other.  The plan (built once per handle) sorts the rows by level; the sweep kernel then is ONE launch:
+//   * a wave draws the next 64 positions of that order from a counter (in order, so every row a wave can ever wait for has
+//     been drawn by a wave that is already running: no wave waits for one that has not started — no co-residency needed);
+//   * a lane owns one row and walks its entries in the reference's order, eight at a time: the eight x values are requested
+//     together (previous iterate: plain loads; this sweep's values: 8-byte agent-scope loads of the NEXT iterate, which the
+//     host filled with a bit pattern no arithmetic produces), the products are added in entry order as far as the values
+//     have arrived, the rest is polled again;
+//   * x[row] = (rhs[row] - sigma) / diag is published with one 8-byte agent-scope store: value and "ready" are the same
+//     granule, so there is no flag to order against the data (MI355X_MICROARCH.md, hand-off by data-tagged granules).
+// Same operands, same order, unfused multiply-add (-ffp-contract=off), IEEE division: x is bit-identical to the CPU sweep.
+// Double buffered (the previous iterate must stay readable for the columns after the row), so a sweep also costs one
+// memset of n doubles; the user's x_dev receives the last iterate.
+//
+// Bound: the chain of levels, one publish -> poll hop (~1 us) each — 8 191 levels for the 5-point Laplacian of a 4096 x 4096
+// grid — not bandwidth (the matrix streams once per sweep: 1.6 GB = 0.2 ms).  DESIGN.md §4.5.
+//
+// Safety net: a lane that polls longer than GS_SPIN_LIMIT rounds raises a status word that every wave looks at, and the
+// kernel ends with an error instead of hanging (cannot happen with a correct level order; it guards the order, not the data).
+#include "common.hpp"
+#include "scan.hpp"
+
+#include <cmath>
+#include <vector>
+
+namespace sprs_hip {
+
+void GsPlan::release() {
+    if (order) (void)hipFree(order);
+    order = nullptr;
+    built = false;
+    nlevels = 0;
+    no_diag_row = UINT64_MAX;
+}
+
+namespace {
+
+constexpr int GS_BLOCK = 256;
+constexpr int GS_B = 8;                                       // entries of a row requested together
+constexpr unsigned long long GS_PENDING = ~0ull;              // "row not swept yet" in the next iterate: memset 0xFF, a NaN no arithmetic yields
+constexpr unsigned long long GS_QNAN = 0x7FF8000000000000ull;
+constexpr uint32_t GS_SPIN_LIMIT = 1u << 22;
+constexpr unsigned int GS_NO_DIAG = 1u, GS_TIMEOUT = 2u;
+constexpr uint64_t SUM_CHUNK = 8192;
+
+#ifdef SPRS_HIP_EMU
+#define GS_TOUCH(v) ((void)(v))
+#else
+#define GS_TOUCH(v) asm volatile("" ::"v"(v))
+#endif
+
+__device__ __forceinline__ unsigned long long gs_peek(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename IDX, typename PTR>
+__global__ __launch_bounds__(GS_BLOCK) void gs_sweep_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
+                                                            const double *__restrict__ data,
+                                                            const uint32_t *__restrict__ order,
+                                                            const double *__restrict__ x_old, unsigned long long *x_new,
+                                                            const double *__restrict__ rhs, uint64_t n,
+                                                            unsigned int *next_chunk, unsigned int *status) {
+    const uint32_t lane = threadIdx.x & 63u;
+    auto draw = [&]() -> uint64_t {
+        unsigned int q = 0;
+        if (lane == 0) q = atomicAdd(next_chunk, 1u);
+        return (uint64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)q) * 64u;
+    };
+    for (uint64_t base = draw(); base < n; base = draw()) {
+        const uint64_t pos = base + lane;
+        bool done = pos >= n;
+        uint32_t row = 0;
+        uint64_t p = 0, end = 0;
+        double b = 0.0;
+        if (!done) {
+            row = order[pos];
+            p = (uint64_t)indptr[row];
+            end = (uint64_t)indptr[row + 1];
+            b = rhs[row];
+        }
+        double sigma = 0.0, diag = 0.0;
+        bool has_diag = false;
+        uint32_t col[GS_B];
+        double val[GS_B], xv[GS_B];
+        uint32_t nb = 0, used = 0, ready = 0, spins = 0;
+        bool more = true;
+        while (more) {
+            bool moved = false;
+            if (!done) {
+                if (used == nb && p < end) {                   // the next (up to) eight entries of my row
+                    nb = end - p < (uint64_t)GS_B ? (uint32_t)(end - p) : (uint32_t)GS_B;
+#pragma unroll
+                    for (int u = 0; u < GS_B; ++u)
+                        if ((uint32_t)u < nb) {
+                            col[u] = (uint32_t)indices[p + u];
+                            val[u] = data[p + u];
+                        }
+                    p += nb;
+                    used = 0;
+                    ready = 0;
+                    // The column ids are needed NOW (they address the x loads below).  Without a use at this point the compiler
+                    // waits for them in front of every single x load with a count that must hold on every path (vmcnt(1)): the
+                    // eight x loads then go out one after the other instead of together.
+                    uint32_t touch = 0;
+#pragma unroll
+                    for (int u = 0; u < GS_B; ++u)
+                        if ((uint32_t)u < nb) touch |= col[u];
+                    GS_TOUCH(touch);
+                }
+                // request what has not arrived yet, all at once
+                unsigned long long bits[GS_B];
+#pragma unroll
+                for (int u = 0; u < GS_B; ++u) {
+                    bits[u] = GS_PENDING;
+                    if ((uint32_t)u >= used && (uint32_t)u < nb && !((ready >> u) & 1u)) {
+                        const uint32_t c = col[u];
+                        if (c < row) bits[u] = gs_peek(x_new + c);                                    // this sweep's value, once published
+                        else if (c > row) bits[u] = (unsigned long long)__double_as_longlong(x_old[c]);   // the previous iterate
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GS_B; ++u)
+                    if ((uint32_t)u >= used && (uint32_t)u < nb && !((ready >> u) & 1u)) {
+                        const uint32_t c = col[u];
+                        if (c == row) {
+                            ready |= 1u << u;
+                        } else if (c > row || bits[u] != GS_PENDING) {
+                            xv[u] = __longlong_as_double((long long)bits[u]);
+                            ready |= 1u << u;
+                        }
+                    }
+                // add in entry order as far as the operands are there (heat.rs:117-123)
+#pragma unroll
+                for (int u = 0; u < GS_B; ++u)
+                    if ((uint32_t)u == used && (uint32_t)u < nb && ((ready >> u) & 1u)) {
+                        if (col[u] == row) {
+                            diag = val[u];
+                            has_diag = true;
+                        } else {
+                            const double prod = val[u] * xv[u];
+                            sigma = sigma + prod;
+                        }
+                        ++used;
+                        moved = true;
+                    }
+                if (used == nb && p == end) {
+                    double xr = (b - sigma) / diag;             // heat.rs:128-130
+                    unsigned long long out = (unsigned long long)__double_as_longlong(xr);
+                    if (!has_diag) {                            // diag.unwrap() of None: the host turns this into an error
+                        atomicOr(status, GS_NO_DIAG);
+                        out = GS_QNAN;
+                    }
+                    if (out == GS_PENDING) out = GS_QNAN;       // (a NaN payload handed through from rhs / x: still a NaN, but not "pending")
+                    __hip_atomic_store(x_new + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    done = true;
+                    moved = true;
+                }
+            }
+            more = __ballot(!done) != 0ull;
+            if (more) {
+                spins = moved ? 0u : spins + 1u;
+                unsigned int st = 0;
+                if ((spins & 63u) == 63u) st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (spins > GS_SPIN_LIMIT) {
+                    atomicOr(status, GS_TIMEOUT);
+                    st = GS_TIMEOUT;
+                }
+                if (__ballot((st & GS_TIMEOUT) != 0u) != 0ull) return;
+                if (__ballot(moved) == 0ull) SPRS_POLL_PAUSE();        // nobody got anywhere: let the publishers run
+            }
+        }
+    }
+}
+
+// residual sum of the reference's convergence test: sum_i (v_i - rhs_i), v = A x.  Fixed two-level tree (chunks of 8192:
+// thread t adds elements t, t + 256, ... in order, then the lanes and the waves in a fixed shape): deterministic, rounded
+// differently from ndarray's eight running sums.
+__global__ __launch_bounds__(GS_BLOCK) void gs_resid_partial_kernel(const double *__restrict__ v, const double *__restrict__ rhs,
+                                                                    uint64_t n, double *__restrict__ partial) {
+    __shared__ double lds[GS_BLOCK / 64];
+    const uint64_t lo = (uint64_t)blockIdx.x * SUM_CHUNK;
+    const uint64_t hi = lo + SUM_CHUNK < n ? lo + SUM_CHUNK : n;
+    double s = 0.0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += GS_BLOCK) {
+        const double r = v[i] - rhs[i];
+        s = s + r;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+        for (int w = 1; w < GS_BLOCK / 64; ++w) t = t + lds[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(GS_BLOCK) void gs_resid_final_kernel(const double *__restrict__ partial, uint64_t nchunks,
+                                                                  double *__restrict__ out) {
+    __shared__ double lds[GS_BLOCK / 64];
+    double s = 0.0;
+    for (uint64_t i = threadIdx.x; i < nchunks; i += GS_BLOCK) s = s + partial[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63u) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+        for (int w = 1; w < GS_BLOCK / 64; ++w) t = t + lds[w];
+        out[0] = t;
+    }
+}
+
+// The level order, on the host, once per handle: level(i) = 1 + max level(c) over the stored c < i, rows sorted by
+// (level, row) with one counting sort.  The levels are themselves a recurrence over the rows; a serial pass over the
+// structure (0.3 s for the 1.7e7 rows of a 4096 x 4096 grid, the download included) is paid once and amortised over the
+// sweeps.
+template <typename IDX, typename PTR>
+int32_t gs_plan_build(sprs_hip_csmat *a) {
+    GsPlan &pl = a->gs;
+    const uint64_t n = a->rows;
+    std::vector<PTR> ip(n + 1);
+    std::vector<IDX> ix(a->nnz ? a->nnz : 1);
+    SPRS_TRY_HIP(hipMemcpy(ip.data(), a->indptr, (n + 1) * sizeof(PTR), hipMemcpyDeviceToHost));
+    if (a->nnz) SPRS_TRY_HIP(hipMemcpy(ix.data(), a->indices, a->nnz * sizeof(IDX), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> level(n);
+    uint64_t no_diag = UINT64_MAX;
+    uint32_t top = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t lv = 0;
+        bool diag = false;
+        for (uint64_t p = (uint64_t)ip[i]; p < (uint64_t)ip[i + 1]; ++p) {
+            const uint64_t c = (uint64_t)ix[p];
+            if (c < i) {
+                if (level[c] + 1 > lv) lv = level[c] + 1;
+            } else if (c == i) {
+                diag = true;
+            }
+        }
+        if (!diag && no_diag == UINT64_MAX) no_diag = i;
+        level[i] = lv;
+        if (lv > top) top = lv;
+    }
+    std::vector<uint64_t> start((uint64_t)top + 2, 0);
+    for (uint64_t i = 0; i < n; ++i) ++start[(uint64_t)level[i] + 1];
+    for (uint64_t l = 0; l <= top; ++l) start[l + 1] += start[l];
+    std::vector<uint32_t> order(n ? n : 1);
+    for (uint64_t i = 0; i < n; ++i) order[start[level[i]]++] = (uint32_t)i;
+    SPRS_TRY_HIP(hipMalloc((void **)&pl.order, (n ? n : 1) * sizeof(uint32_t)));
+    hipError_t e = hipMemcpy(pl.order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        pl.release();
+        return fail_hip(e, "upload of the Gauss-Seidel level order");
+    }
+    pl.nlevels = n ? (uint64_t)top + 1 : 0;
+    pl.no_diag_row = no_diag;
+    pl.built = true;
+    return SPRS_HIP_OK;
+}
+
+struct Work {
+    double *buf = nullptr;
+    unsigned int *words = nullptr;
+    ~Work() {
+        if (buf) (void)hipFree(buf);
+        if (words) (void)hipFree(words);
+    }
+};
+
+template <typename IDX, typename PTR>
+int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uint64_t max_iter, double eps,
+                sprs_hip_gauss_seidel_info *info, hipStream_t stream) {
+    const uint32_t *order = nullptr;
+    uint64_t nlevels = 0, no_diag_row = UINT64_MAX;
+    {
+        std::lock_guard<std::recursive_mutex> lock(a->mu);
+        if (!a->gs.built) SPRS_TRY((gs_plan_build<IDX, PTR>(a)));
+        order = a->gs.order;
+        nlevels = a->gs.nlevels;
+        no_diag_row = a->gs.no_diag_row;
+    }
+    if (max_iter > 0 && no_diag_row != UINT64_MAX)
+        SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Gauss-Seidel: row %llu has no stored diagonal entry (the reference's diag.unwrap() panics, heat.rs:127)",
+                  (unsigned long long)no_diag_row);
+
+    const uint64_t nchunks = (n + SUM_CHUNK - 1) / SUM_CHUNK;
+    Work w;
+    SPRS_TRY_HIP(hipMalloc((void **)&w.buf, (2 * n + nchunks + 8) * sizeof(double)));
+    SPRS_TRY_HIP(hipMalloc((void **)&w.words, 64));
+    double *other = w.buf, *v = other + n, *partial = v + n, *scal = partial + nchunks;
+    unsigned int *next_chunk = w.words, *status = w.words + 1;
+
+    auto residual_error = [&](const double *xc, double &err) -> int32_t {      // (&mat * &x - rhs).sum().sqrt()
+        SPRS_TRY(spmv_f64(a, xc, v, false, stream));
+        hipLaunchKernelGGL(gs_resid_partial_kernel, dim3((unsigned)nchunks), dim3(GS_BLOCK), 0, stream, v, rhs, n, partial);
+        hipLaunchKernelGGL(gs_resid_final_kernel, dim3(1), dim3(GS_BLOCK), 0, stream, partial, nchunks, scal);
+        SPRS_TRY_HIP(hipGetLastError());
+        double h = 0.0;
+        SPRS_TRY_HIP(hipMemcpyAsync(&h, scal, sizeof(double), hipMemcpyDeviceToHost, stream));
+        SPRS_TRY_HIP(hipStreamSynchronize(stream));
+        err = std::sqrt(h);
+        return SPRS_HIP_OK;
+    };
+
+    int ncu = 0, dev = 0;
+    SPRS_TRY_HIP(hipGetDevice(&dev));
+    SPRS_TRY_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const uint64_t per_cu = options().gauss_seidel_blocks > 0 ? (uint64_t)options().gauss_seidel_blocks : 2;
+    const uint64_t need = (n + GS_BLOCK - 1) / GS_BLOCK;
+    uint64_t grid = (uint64_t)(ncu > 0 ? ncu : 1) * per_cu;
+    if (grid > need) grid = need;
+
+    double error = 0.0;
+    int32_t converged = 0;
+    uint64_t iterations = max_iter;
+    double *cur = x, *nxt = other;
+    if (max_iter == 0) SPRS_TRY(residual_error(cur, error));                   // heat.rs:111: what Err(error) holds then
+    for (uint64_t it = 0; it < max_iter; ++it) {
+        SPRS_TRY_HIP(hipMemsetAsync(nxt, 0xFF, n * sizeof(double), stream));   // every row of the next iterate "pending"
+        SPRS_TRY_HIP(hipMemsetAsync(w.words, 0, 64, stream));
+        hipLaunchKernelGGL((gs_sweep_kernel<IDX, PTR>), dim3((unsigned)grid), dim3(GS_BLOCK), 0, stream, (const PTR *)a->indptr,
+                           (const IDX *)a->indices, (const double *)a->data, order, (const double *)cur,
+                           (unsigned long long *)nxt, rhs, n, next_chunk, status);
+        SPRS_TRY_HIP(hipGetLastError());
+        unsigned int st = 0;
+        SPRS_TRY_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, stream));
+        double *t = cur;
+        cur = nxt;
+        nxt = t;
+        SPRS_TRY(residual_error(cur, error));                                  // (drains the stream: st is valid after it)
+        if (st & GS_TIMEOUT)
+            SPRS_FAIL(SPRS_HIP_HIP_ERROR, "Gauss-Seidel sweep: a row waited for a value that was never published (level order broken)");
+        if (st & GS_NO_DIAG) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Gauss-Seidel: a row has no stored diagonal entry");
+        if (error < eps) {                                                     // heat.rs:134-136
+            converged = 1;
+            iterations = it;
+            break;
+        }
+    }
+    if (cur != x) SPRS_TRY_HIP(hipMemcpyAsync(x, cur, n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    SPRS_TRY_HIP(hipStreamSynchronize(stream));
+    if (info) {
+        info->iterations = iterations;
+        info->error = error;
+        info->converged = converged;
+        info->levels = nlevels;
+    }
+    return SPRS_HIP_OK;
+}
+
+}  // namespace
+
+int32_t gauss_seidel_f64(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uint64_t max_iter, double eps,
+                         sprs_hip_gauss_seidel_info *info, hipStream_t stream) {
+    if (n >= (1ull << 32)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "Gauss-Seidel: 2^32 rows or more are not supported");
+    if (n == 0) {                      // an empty sum: error = sqrt(0) = 0
+        if (info) *info = sprs_hip_gauss_seidel_info{max_iter && !(0.0 < eps) ? max_iter : 0, 0.0, (max_iter && 0.0 < eps) ? 1 : 0, 0};
+        return SPRS_HIP_OK;
+    }
+    if (a->idx_bytes == 8 && a->iptr_bytes == 8) return gs_impl<uint64_t, uint64_t>(a, x, rhs, n, max_iter, eps, info, stream);
+    if (a->idx_bytes == 4 && a->iptr_bytes == 8) return gs_impl<uint32_t, uint64_t>(a, x, rhs, n, max_iter, eps, info, stream);
+    if (a->idx_bytes == 8 && a->iptr_bytes == 4) return gs_impl<uint64_t, uint32_t>(a, x, rhs, n, max_iter, eps, info, stream);
+    return gs_impl<uint32_t, uint32_t>(a, x, rhs, n, max_iter, eps, info, stream);
+}
+
+}  // namespace sprs_hip

@@ -1,6 +1,7 @@
-"""Host mirror of sprs::linalg::bicgstab (sprs/src/sparse/linalg/bicgstab.rs) over the device path:
-the solver loop runs behind `sprs_hip_bicgstab_f64` with every vector resident in HBM (two SpMVs,
-four fused element-wise kernels and three dot launches per iteration; include/sprs_hip.h)."""
+"""Host mirror of the reference's two callers that loop on the SpMV, over the device path:
+sprs::linalg::bicgstab (sprs/src/sparse/linalg/bicgstab.rs) behind `sprs_hip_bicgstab_f64` (every vector resident
+in HBM: two SpMVs, four fused element-wise kernels and three dot launches per iteration) and the Gauss-Seidel
+solver of the heat example (sprs/examples/heat.rs:103-139) behind `sprs_hip_gauss_seidel_f64`."""
 import ctypes as C
 
 from . import _ffi
@@ -66,3 +67,34 @@ class BiCGSTAB:
 
     def b(self):
         return self._b
+
+
+class _GsInfo(C.Structure):
+    _fields_ = [("iterations", C.c_uint64), ("error", C.c_double), ("converged", C.c_int32), ("levels", C.c_uint64)]
+
+
+class GaussSeidelResult:
+    """What `gauss_seidel` of the heat example returns (heat.rs:103-139): `Ok((iterations, error))` when
+    `converged`, `Err(error)` otherwise (then `iterations == max_iter`).  `levels` is the length of the
+    longest chain of rows that have to be swept one after the other (device-side information)."""
+
+    def __init__(self, info):
+        self.converged = bool(info.converged)
+        self.iterations = int(info.iterations)
+        self.error = float(info.error)
+        self.levels = int(info.levels)
+
+    def __repr__(self):
+        return ("Ok((%d, %r))" % (self.iterations, self.error)) if self.converged else "Err(%r)" % self.error
+
+
+def gauss_seidel(mat, x, rhs, max_iter, eps, stream=None):
+    """gauss_seidel(mat, x, rhs, max_iter, eps) (heat.rs:103-139): mat a square CSR DeviceCsMat, x (start vector,
+    overwritten with the result like the reference's `mut x`) and rhs DeviceVecs.  Dimension mismatch and a row
+    without a diagonal entry raise, like the reference's asserts / `diag.unwrap()`."""
+    if x.n != rhs.n:
+        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
+    info = _GsInfo()
+    check(lib.sprs_hip_gauss_seidel_f64(mat._h, C.c_void_p(x.ptr), C.c_void_p(rhs.ptr), x.n, int(max_iter), float(eps),
+                                        C.byref(info), C.c_void_p(int(stream) if stream else 0)))
+    return GaussSeidelResult(info)

@@ -176,6 +176,9 @@ inline void __threadfence_block() {}
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
+// agent-scope 8-byte hand-offs (gauss_seidel.hip): fibers switch cooperatively, a plain access is atomic
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
 inline long long __double_as_longlong(double v) { long long b; memcpy(&b, &v, 8); return b; }
 inline double __longlong_as_double(long long b) { double v; memcpy(&v, &b, 8); return v; }
 inline int __double2loint(double v) { long long b; memcpy(&b, &v, 8); return (int)(unsigned)(b & 0xFFFFFFFFll); }

@@ -39,3 +39,13 @@ def test_spmv_band_kernels_in_the_emulator(emu_lib):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_spmv_band_gpu.py"), "-x", "-q", "-m", "gpu",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("order", ["default", "reverse", "rotate"])
+def test_gauss_seidel_sweep_in_the_emulator(emu_lib, order):
+    """the sync-free sweep kernel (rows in level order, values handed from wave to wave through the next iterate) on the
+    small systems of tests/test_gauss_seidel_gpu.py, with the waves of a workgroup scheduled in three orders"""
+    env = dict(os.environ, SPRS_HIP_LIBRARY=emu_lib, HIPEMU_WAVE_ORDER=order)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gauss_seidel_gpu.py"), "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -269,6 +269,94 @@ def test_bicgstab_iteration_limit_is_not_an_error():
     assert info2["converged"] == 1 and np.linalg.norm(a @ x2 - b) < 1e-11 and info2["hard_restart_count"] >= 1
 
 
+def _py_gauss_seidel(n, ip, ix, dt, x, rhs, max_iter, eps):
+    """heat.rs:103-139 line by line in Python (ndarray's sum = numeric_util::unrolled_fold, eight running sums)"""
+    x = np.array(x, dtype=np.float64)
+
+    def error():
+        r = np.zeros(n)
+        for i in range(n):
+            s = 0.0
+            for p in range(int(ip[i]), int(ip[i + 1])):
+                s = s + dt[p] * x[int(ix[p])]
+            r[i] = s - rhs[i]
+        ps, k = [0.0] * 8, 0
+        while n - k >= 8:
+            for j in range(8):
+                ps[j] = ps[j] + r[k + j]
+            k += 8
+        acc = 0.0
+        for j in range(4):
+            acc = acc + (ps[j] + ps[j + 4])
+        for j in range(k, n):
+            acc = acc + r[j]
+        return float(np.sqrt(acc)) if acc >= 0 else float("nan")
+
+    e = error()
+    for it in range(max_iter):
+        for row in range(n):
+            sigma, diag = 0.0, None
+            for p in range(int(ip[row]), int(ip[row + 1])):
+                c = int(ix[p])
+                if c != row:
+                    sigma += dt[p] * x[c]
+                else:
+                    diag = dt[p]
+            x[row] = (rhs[row] - sigma) / diag
+        e = error()
+        if e < eps:
+            return x, (it, e, 1)
+    return x, (max_iter, e, 0)
+
+
+def test_gauss_seidel_heat_example():
+    """sprs/examples/heat.rs:141-174 (the example's main: 10 x 10 grid, rhs = row + col on the border, 300 sweeps, eps 1e-8).
+    The example asserts nothing and no Rust toolchain is here, so the C restatement is pinned three ways: it converges
+    (the example prints "Solved system in N iterations"), its solution is the solution of the linear system, and an
+    independent Python restatement written from the same source gives the same bits, sweep count and error."""
+    from oracle import oracle
+    shape, ip, ix, dt = oracle.grid_laplacian(10, 10)
+    i, j = np.meshgrid(np.arange(10), np.arange(10), indexing="ij")
+    border = (i == 0) | (i == 9) | (j == 0) | (j == 9)
+    rhs = np.where(border, (i + j).astype(np.float64), 0.0).reshape(-1)
+    x, info = oracle.gauss_seidel(shape, ip, ix, dt, np.zeros(100), rhs, 300, 1e-8)
+    assert info["converged"] == 1 and info["iterations"] < 300 and info["error"] < 1e-8
+    dense = np.zeros(shape)
+    for r in range(100):
+        for p in range(int(ip[r]), int(ip[r + 1])):
+            dense[r, int(ix[p])] = dt[p]
+    assert np.abs(x - np.linalg.solve(dense, rhs)).max() < 1e-12
+    assert np.allclose(x.reshape(10, 10), i + j, rtol=0, atol=1e-12)       # harmonic boundary data: the solution is row + col
+    x_py, (it, e, ok) = _py_gauss_seidel(100, ip, ix, dt, np.zeros(100), rhs, 300, 1e-8)
+    assert np.array_equal(x, x_py) and (info["iterations"], info["converged"]) == (it, ok) and info["error"] == e
+    # u32 instantiations: same bits
+    for idx, ptr in ((np.uint32, np.uint32), (np.uint32, np.uint64)):
+        x32, info32 = oracle.gauss_seidel(shape, ip.astype(ptr), ix.astype(idx), dt, np.zeros(100), rhs, 300, 1e-8)
+        assert np.array_equal(x, x32) and info == info32
+
+
+def test_gauss_seidel_iterates_and_edge_cases():
+    """non-symmetric system against the Python restatement sweep by sweep (Err(error) after k sweeps, NaN error of a
+    negative residual sum included); max_iter = 0 returns the start error; a row without diagonal panics (heat.rs:127)"""
+    import scipy.sparse as sp
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    n = 37
+    a = sp.random(n, n, density=0.15, random_state=2, format="csr")
+    a = (a + sp.diags(np.abs(a).sum(axis=1).A1 + 1.0)).tocsr()
+    a.sort_indices()
+    u = lambda v: v.astype(np.uint64)
+    rhs, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    for k in (0, 1, 2, 5):
+        x, info = oracle.gauss_seidel((n, n), u(a.indptr), u(a.indices), a.data, x0, rhs, k, -1.0)
+        x_py, (it, e, ok) = _py_gauss_seidel(n, a.indptr, a.indices, a.data, x0, rhs, k, -1.0)
+        assert np.array_equal(x, x_py) and info["iterations"] == it == k and info["converged"] == ok == 0
+        assert (np.isnan(e) and np.isnan(info["error"])) or e == info["error"]
+    with pytest.raises(oracle.OracleError):
+        oracle.gauss_seidel((3, 3), np.array([0, 1, 2, 3], dtype=np.uint64), np.array([0, 0, 2], dtype=np.uint64), np.ones(3),
+                            np.zeros(3), np.zeros(3), 1, 1e-8)
+
+
 def test_triplets_to_cs_golden(golden):
     """sprs/src/sparse/triplet.rs:343-646 (triplet_incremental, _unordered, _additions, _from_vecs, _mutate_entry,
     _to_csr, _complex, _empty_lines): the oracle's restatement of TriMatIter::into_cs (triplet_iter.rs:127-224) must give
