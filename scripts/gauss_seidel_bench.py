@@ -3,7 +3,8 @@
 G x G grid: time per sweep on the device (sweep kernel + the residual SpMV + the convergence scalar, as the reference's loop
 has them), the one-time plan (level order on the host, SpMV plan), the CPU oracle's time per sweep beside it, and parity:
 the iterate after K sweeps bit for bit against the oracle (at the full size: the oracle sweeps 1.7e7 rows in ~0.4 s).
-usage: gauss_seidel_bench.py [G] [K] [blocks_per_cu ...]     (defaults 4096 3 and the library's default)"""
+usage: gauss_seidel_bench.py [G] [K] [blocks[:naps] ...]     (defaults 4096 3 and the library's defaults; blocks = workgroups
+of the sweep kernel, naps = longest pause of a waiting wave)"""
 import json
 import os
 import sys
@@ -21,13 +22,28 @@ from oracle import oracle                                     # noqa: E402  (the
 def main():
     g = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    blocks = [int(v) for v in sys.argv[3:]] or [0]
-    shape, ip, ix, dt = oracle.grid_laplacian(g, g)
-    n = g * g
-    i, j = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
-    border = (i == 0) | (i == g - 1) | (j == 0) | (j == g - 1)
-    rhs = np.where(border, (i + j).astype(np.float64), 0.0).reshape(-1)
-    del i, j, border
+    blocks = [tuple(int(t) for t in (v + ":0").split(":")[:2]) for v in sys.argv[3:]] or [(0, 0)]
+    if g > 0:
+        shape, ip, ix, dt = oracle.grid_laplacian(g, g)
+        n = g * g
+        i, j = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+        border = (i == 0) | (i == g - 1) | (j == 0) | (j == g - 1)
+        rhs = np.where(border, (i + j).astype(np.float64), 0.0).reshape(-1)
+        del i, j, border
+    else:
+        # G < 0: a random non-symmetric, strictly diagonally dominant system of -G rows, 8 off-diagonal entries per row
+        # (few, wide levels: the sweep is bound by throughput there, not by the chain of levels)
+        import scipy.sparse as sp
+        n = -g
+        rng = np.random.default_rng(1)
+        r = np.repeat(np.arange(n), 8)
+        c = rng.integers(0, n, size=8 * n)
+        m = sp.coo_matrix((rng.standard_normal(8 * n), (r, c)), shape=(n, n)).tocsr()
+        m = (m + sp.diags(np.abs(m).sum(axis=1).A1 + 1.0)).tocsr()
+        m.sort_indices()
+        shape, ip, ix, dt = (n, n), m.indptr.astype(np.uint64), m.indices.astype(np.uint64), m.data
+        rhs = rng.standard_normal(n)
+        del m, r, c
     x0 = np.zeros(n)
     a = DeviceCsMat.from_host(shape, ip, ix, dt)
     d_rhs = DeviceVec.from_host(rhs)
@@ -39,8 +55,9 @@ def main():
     x_ref, info = oracle.gauss_seidel(shape, ip, ix, dt, x0, rhs, k, -1.0)
     cpu = (time.perf_counter() - t0) / max(k, 1)
     alg = ix.size * (8 + ix.itemsize) + (n + 1) * ip.itemsize + 4 * n * 8      # matrix once, x old + new, rhs, order (4 B) ~ per sweep
-    for b in blocks:
+    for b, naps in blocks:
         sprs_amd.set_option("gauss_seidel_blocks", b)
+        sprs_amd.set_option("gauss_seidel_naps", naps)
         x = DeviceVec.from_host(x0)
         gauss_seidel(a, x, d_rhs, 1, -1.0)                     # warm
         times = {}
@@ -53,7 +70,7 @@ def main():
                 got = x.to_host()
         per = (times[4 * k] - times[k]) / (3 * k)
         same = bool(np.array_equal(got, x_ref))
-        print(json.dumps({"grid": g, "rows": n, "nnz": int(ix.size), "levels": res.levels, "blocks_per_cu": b or "default",
+        print(json.dumps({"grid": g, "rows": n, "nnz": int(ix.size), "levels": res.levels, "workgroups": b or "default", "naps": naps or "default",
                           "ms_per_sweep_with_residual": round(per * 1e3, 3), "us_per_level": round(per * 1e6 / res.levels, 3),
                           "first_call_s_plans_included": round(first, 3), "oracle_ms_per_sweep_with_residual": round(cpu * 1e3, 1),
                           "speedup_vs_one_core": round(cpu / per, 1), "streamed_GBs": round(alg / per / 1e9, 1),

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_sweep_kernel(const PTR *__restric
                                                             const uint32_t *__restrict__ order,
                                                             const double *__restrict__ x_old, unsigned long long *x_new,
                                                             const double *__restrict__ rhs, uint64_t n,
-                                                            unsigned int *next_chunk, unsigned int *status) {
+                                                            unsigned int *next_chunk, unsigned int *status, uint32_t max_naps) {
     const uint32_t lane = threadIdx.x & 63u;
     auto draw = [&]() -> uint64_t {
         unsigned int q = 0;
@@ -172,7 +172,11 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_sweep_kernel(const PTR *__restric
                     st = GS_TIMEOUT;
                 }
                 if (__ballot((st & GS_TIMEOUT) != 0u) != 0ull) return;
-                if (__ballot(moved) == 0ull) SPRS_POLL_PAUSE();        // nobody got anywhere: let the publishers run
+                if (__ballot(moved) == 0ull) {                         // nobody got anywhere: let the publishers run, and back off
+                    uint32_t naps = spins < 8u ? 1u : spins < 32u ? 2u : spins < 128u ? 4u : 8u;
+                    if (naps > max_naps) naps = max_naps;
+                    for (uint32_t q = 0; q < naps; ++q) SPRS_POLL_PAUSE();
+                }
             }
         }
     }
@@ -312,10 +316,13 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
     int ncu = 0, dev = 0;
     SPRS_TRY_HIP(hipGetDevice(&dev));
     SPRS_TRY_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const uint64_t per_cu = options().gauss_seidel_blocks > 0 ? (uint64_t)options().gauss_seidel_blocks : 2;
+    // few workgroups on purpose: a level of the heat system is 64 waves wide, and every wave beyond the ones at the front
+    // only adds polls to the memory queues the hand-offs go through (profiles/r07a: 256 / 512 / 1024 / 2048 workgroups:
+    // 20 / 27 / 40 / 58 ms per sweep)
     const uint64_t need = (n + GS_BLOCK - 1) / GS_BLOCK;
-    uint64_t grid = (uint64_t)(ncu > 0 ? ncu : 1) * per_cu;
+    uint64_t grid = options().gauss_seidel_blocks > 0 ? (uint64_t)options().gauss_seidel_blocks : (uint64_t)(ncu > 0 ? ncu : 1);
     if (grid > need) grid = need;
+    const uint32_t max_naps = options().gauss_seidel_naps > 0 ? (uint32_t)options().gauss_seidel_naps : 1u;
 
     double error = 0.0;
     int32_t converged = 0;
@@ -327,7 +334,7 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
         SPRS_TRY_HIP(hipMemsetAsync(w.words, 0, 64, stream));
         hipLaunchKernelGGL((gs_sweep_kernel<IDX, PTR>), dim3((unsigned)grid), dim3(GS_BLOCK), 0, stream, (const PTR *)a->indptr,
                            (const IDX *)a->indices, (const double *)a->data, order, (const double *)cur,
-                           (unsigned long long *)nxt, rhs, n, next_chunk, status);
+                           (unsigned long long *)nxt, rhs, n, next_chunk, status, max_naps);
         SPRS_TRY_HIP(hipGetLastError());
         unsigned int st = 0;
         SPRS_TRY_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, stream));
