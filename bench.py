@@ -126,7 +126,7 @@ def spgemm5(dev, idx_bytes, steps, warmup, check_rows, cpu_blocks, cpu_block_row
         # evenly spaced row blocks; the whole product is extrapolated by the ratio of multiply-adds (products)
         pr_h = per_row_products.cpu().numpy()
         starts = [int(i * (n - cpu_block_rows) / max(1, cpu_blocks - 1)) for i in range(cpu_blocks)]
-        p_sample, t1, tauto, used_auto = 0.0, 0.0, 0.0, 0
+        p_sample, t1, tauto, tphys, used_auto, phys_threads = 0.0, 0.0, 0.0, 0.0, 0, 1
         for r0 in starts:
             r1 = r0 + cpu_block_rows
             s0, e0 = int(ip_h[r0]), int(ip_h[r1])
@@ -136,8 +136,17 @@ def spgemm5(dev, idx_bytes, steps, warmup, check_rows, cpu_blocks, cpu_block_row
             t1 += time.perf_counter() - t
             t = time.perf_counter()
             res = oracle.mul_csr_csr(*blk, threads=0, return_threads=True)
-            tauto += time.perf_counter() - t
+            dt_auto = time.perf_counter() - t
+            tauto += dt_auto
             used_auto = max(used_auto, res[-1])
+            pt = oracle.automatic_physical_threads(e0 - s0, ix_h.size)
+            phys_threads = max(phys_threads, pt)
+            if pt != res[-1]:                               # ThreadingStrategy::AutomaticPhysical resolves to another thread count here
+                t = time.perf_counter()
+                oracle.mul_csr_csr(*blk, threads=pt)
+                tphys += time.perf_counter() - t
+            else:
+                tphys += dt_auto                            # the same thread count: the same run
             p_sample += float(pr_h[r1] - pr_h[r0])
         scale = products / p_sample
         out["cpu_baseline"] = {
@@ -147,7 +156,9 @@ def spgemm5(dev, idx_bytes, steps, warmup, check_rows, cpu_blocks, cpu_block_row
                       "(nnzA + nnzB) / 8128), smmp.rs:210-227); extrapolated to the whole product by the ratio of multiply-adds; "
                       "rustc is not available here" % (cpu_blocks, cpu_block_rows, 100.0 / scale),
             "sample_seconds": round(tauto, 3), "single_thread_value": round(t1 * scale, 2), "single_thread_sample_seconds": round(t1, 3),
-            "host_cores": oracle.num_procs(),
+            "host_cores": oracle.num_procs(), "host_physical_cores": oracle.num_physical_cores(),
+            # ThreadingStrategy::AutomaticPhysical (smmp.rs:26-31): the same rule on the physical cores
+            "automatic_physical_value": round(tphys * scale, 2), "automatic_physical_cores": int(phys_threads),
         }
     return out
 

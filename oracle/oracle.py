@@ -68,6 +68,33 @@ def num_procs():
     return int(lib().oracle_num_procs())
 
 
+def num_physical_cores():
+    """what num_cpus::get_physical() counts on Linux: distinct (physical id, core id) pairs of /proc/cpuinfo
+    (falls back to the logical count, as the crate does, when the file does not say)"""
+    try:
+        cores, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+        return len(cores) or num_procs()
+    except OSError:
+        return num_procs()
+
+
+def automatic_physical_threads(a_nnz, b_nnz):
+    """ThreadingStrategy::AutomaticPhysical (smmp.rs:26-31, 210-227): the Automatic rule min(cpus, (nnzA + nnzB) / 8128)
+    with the number of PHYSICAL cores; returned as the Fixed(n) it resolves to"""
+    return max(1, min(num_physical_cores(), (int(a_nnz) + int(b_nnz)) // 8128))
+
+
 def _suffix(indices, indptr):
     ib, pb = indices.dtype.itemsize, indptr.dtype.itemsize
     suf = {(8, 8): "u64u64", (4, 4): "u32u32", (4, 8): "u32u64"}.get((ib, pb))
