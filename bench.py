@@ -39,12 +39,24 @@ def algorithmic_bytes(rows, cols, nnz, idx_bytes, iptr_bytes, accumulate=False):
     return nnz * (8 + idx_bytes) + (rows + 1) * iptr_bytes + cols * 8 + rows * 8 * (2 if accumulate else 1)
 
 
-def csrc_sha16():
-    """hash of the kernel sources: ties a committed PMC measurement to the code it was taken on"""
+# what a workload's launches can reach: its kernels, the headers they include, the shared scan / sort, the option table
+CSRC_OF = {
+    "spmv": ("common.hpp", "scan.hpp", "scan.hip", "spmv_shared.hpp", "spmv.hip", "spmv_band.hip", "spmv_band_kernels.hpp"),
+    "spgemm": ("common.hpp", "scan.hpp", "scan.hip", "sort.hip", "spgemm.hip"),
+}
+
+
+def csrc_sha16(part=None):
+    """hash of kernel sources: ties a committed PMC measurement to the code it was taken on.  part = "spmv" / "spgemm":
+    the translation units and headers that workload runs through (a change to another kernel family leaves the
+    measurement valid); None: every *.hip / *.hpp of sprs_amd/csrc."""
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "sprs_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "sprs_amd", "csrc", "*.hpp"))):
+    d = os.path.join(ROOT, "sprs_amd", "csrc")
+    files = [os.path.join(d, f) for f in CSRC_OF[part]] if part else glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp"))
+    for f in sorted(files):
+        h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
@@ -96,7 +108,7 @@ def spgemm5(dev, idx_bytes, steps, warmup, check_rows, cpu_blocks, cpu_block_row
                      "kernel_ms_avg": round(float(np.mean(ms)), 3), "kernel_ms_min": round(float(np.min(ms)), 3), "traffic": None},
     }
     try:        # PMC traffic of the same product on exactly these kernel sources (scripts/spgemm_traffic.py), else null
-        sha = csrc_sha16()
+        sha = csrc_sha16("spgemm")
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             for e in json.load(f)["entries"]:
                 if e["workload"] == "spgemm5" and e["index_bytes"] == idx_bytes and e.get("csrc_sha16") == sha:
@@ -422,7 +434,7 @@ def main():
     defaults = all(v is None for v in (args.kernel, args.xcs, args.split, args.idx32, args.sort, args.tile, args.ldspad, args.relabel, args.band)) and not args.permute_cols
     try:
         if world == 1 and defaults and not args.cold_cache:
-            sha = csrc_sha16()
+            sha = csrc_sha16("spmv")
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 for e in json.load(f)["entries"]:
                     # only a measurement taken on exactly these kernel sources counts (stale numbers read as null)

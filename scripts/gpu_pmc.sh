@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import bench; print('csrc_sha16:', bench.csrc_sha16())" > $OUT/pmc_summary.txt
+python3 -c "import sys; sys.path.insert(0, '$GRAFT_REPO_ROOT'); import bench; print('csrc_sha16:', bench.csrc_sha16('spmv'))" > $OUT/pmc_summary.txt
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \

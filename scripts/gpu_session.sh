@@ -69,7 +69,7 @@ for step in "$@"; do
     spgemm_stats)  # per-kernel times of ONE config-5 product
             ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spgemm_one.py 2 > $OUT/spgemm_one.json 2>/dev/null; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|^#|sprs_hip" | cut -c1-200 | tee $OUT/spgemm_kernel_stats.txt ;;
     spgemm_traffic1) # FETCH_SIZE and WRITE_SIZE, one counter per pass, ONE product, only the library's kernels instrumented
-            python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print('csrc_sha16:', bench.csrc_sha16())" > $OUT/spgemm_traffic.txt
+            python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print('csrc_sha16:', bench.csrc_sha16('spgemm'))" > $OUT/spgemm_traffic.txt
             for ctr in FETCH_SIZE WRITE_SIZE; do
               rm -rf /tmp/pt
               ( cd /tmp && timeout -s KILL 200 rocprofv3 --pmc $ctr --kernel-trace --kernel-include-regex "sprs_hip" -d /tmp/pt -o pmc -- python $ROOT/scripts/spgemm_one.py 1 > $OUT/spgemm_traffic_$ctr.json 2>/dev/null )
@@ -78,7 +78,7 @@ for step in "$@"; do
             done
             python3 $ROOT/scripts/spgemm_traffic.py $OUT/spgemm_traffic.txt 1 | grep -E "read_bytes|write_bytes|traffic_bytes" ;;
     spgemm_traffic) rm -rf /tmp/pt
-            python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print('csrc_sha16:', bench.csrc_sha16())" > $OUT/spgemm_traffic.txt
+            python3 -c "import sys; sys.path.insert(0, '$ROOT'); import bench; print('csrc_sha16:', bench.csrc_sha16('spgemm'))" > $OUT/spgemm_traffic.txt
             ( cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace -d /tmp/pt -o pmc -- python $ROOT/tests/spgemm_bench.py 1000000 8 8 1 > /dev/null 2>&1 )
             f=$(find /tmp/pt -name "*.db" | head -1)
             if [ -n "$f" ]; then python3 $ROOT/scripts/rocprof_summary.py "$f" sprs_hip | sed -n '/PMC counters/,$p' | cut -c1-250 >> $OUT/spgemm_traffic.txt; fi

@@ -71,7 +71,7 @@ def main():
            "ok": bool(rows_ok and idx_ok and worst <= 1e-10 and entries == int(c.nnz())),
            "oracle": "oracle/sprs_oracle_impl.h mul_csr_csr (smmp.rs:196-416), ThreadingStrategy::Automatic, %d host threads" % oracle.num_procs(),
            "oracle_seconds_all_blocks": round(cpu_s, 2), "gpu_seconds_first_product": round(gpu_s, 4),
-           "sum64_oracle_indices": sum_ix, "sum64_oracle_value_bits": sum_dt, "csrc_sha16": bench.csrc_sha16()}
+           "sum64_oracle_indices": sum_ix, "sum64_oracle_value_bits": sum_dt, "csrc_sha16": bench.csrc_sha16("spgemm")}
     with open(out_path, "w") as f:
         f.write(json.dumps(rec, indent=1) + "\n")
     print(json.dumps(rec))

@@ -281,6 +281,9 @@ struct Work {
 template <typename IDX, typename PTR>
 int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uint64_t max_iter, double eps,
                 sprs_hip_gauss_seidel_info *info, hipStream_t stream) {
+    if (options().gauss_seidel_chain > 1)
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "gauss_seidel_chain = %lld: chains of consecutive rows per lane are not built yet (0 / 1: one row per lane in level order)",
+                  (long long)options().gauss_seidel_chain);
     const uint32_t *order = nullptr;
     uint64_t nlevels = 0, no_diag_row = UINT64_MAX;
     {
