@@ -272,7 +272,9 @@ int32_t gs_plan_build(sprs_hip_csmat *a) {
 struct Work {
     double *buf = nullptr;
     unsigned int *words = nullptr;
+    hipStream_t stream = nullptr;
     ~Work() {
+        (void)hipStreamSynchronize(stream);     // an early return must not leave copies into this frame's variables in flight
         if (buf) (void)hipFree(buf);
         if (words) (void)hipFree(words);
     }
@@ -284,21 +286,21 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
     if (options().gauss_seidel_chain > 1)
         SPRS_FAIL(SPRS_HIP_INVALID_ARG, "gauss_seidel_chain = %lld: chains of consecutive rows per lane are not built yet (0 / 1: one row per lane in level order)",
                   (long long)options().gauss_seidel_chain);
-    const uint32_t *order = nullptr;
-    uint64_t nlevels = 0, no_diag_row = UINT64_MAX;
-    {
-        std::lock_guard<std::recursive_mutex> lock(a->mu);
-        if (!a->gs.built) SPRS_TRY((gs_plan_build<IDX, PTR>(a)));
-        order = a->gs.order;
-        nlevels = a->gs.nlevels;
-        no_diag_row = a->gs.no_diag_row;
-    }
+    // held for the whole solve: the level order (and the SpMV plan of the residual) must outlive every launch that reads them;
+    // sprs_hip_csmat_refresh / _free on another thread wait (recursive: the SpMV of the residual locks again)
+    std::lock_guard<std::recursive_mutex> lock(a->mu);
+    if (!a->gs.built) SPRS_TRY((gs_plan_build<IDX, PTR>(a)));
+    const uint32_t *order = a->gs.order;
+    const uint64_t nlevels = a->gs.nlevels, no_diag_row = a->gs.no_diag_row;
     if (max_iter > 0 && no_diag_row != UINT64_MAX)
         SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Gauss-Seidel: row %llu has no stored diagonal entry (the reference's diag.unwrap() panics, heat.rs:127)",
                   (unsigned long long)no_diag_row);
 
     const uint64_t nchunks = (n + SUM_CHUNK - 1) / SUM_CHUNK;
+    unsigned int st = 0;                       // (declared before `w`: its destructor drains the stream that may still write them)
+    double h_sum = 0.0;
     Work w;
+    w.stream = stream;
     SPRS_TRY_HIP(hipMalloc((void **)&w.buf, (2 * n + nchunks + 8) * sizeof(double)));
     SPRS_TRY_HIP(hipMalloc((void **)&w.words, 64));
     double *other = w.buf, *v = other + n, *partial = v + n, *scal = partial + nchunks;
@@ -309,10 +311,9 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
         hipLaunchKernelGGL(gs_resid_partial_kernel, dim3((unsigned)nchunks), dim3(GS_BLOCK), 0, stream, v, rhs, n, partial);
         hipLaunchKernelGGL(gs_resid_final_kernel, dim3(1), dim3(GS_BLOCK), 0, stream, partial, nchunks, scal);
         SPRS_TRY_HIP(hipGetLastError());
-        double h = 0.0;
-        SPRS_TRY_HIP(hipMemcpyAsync(&h, scal, sizeof(double), hipMemcpyDeviceToHost, stream));
+        SPRS_TRY_HIP(hipMemcpyAsync(&h_sum, scal, sizeof(double), hipMemcpyDeviceToHost, stream));
         SPRS_TRY_HIP(hipStreamSynchronize(stream));
-        err = std::sqrt(h);
+        err = std::sqrt(h_sum);
         return SPRS_HIP_OK;
     };
 
@@ -339,7 +340,6 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
                            (const IDX *)a->indices, (const double *)a->data, order, (const double *)cur,
                            (unsigned long long *)nxt, rhs, n, next_chunk, status, max_naps);
         SPRS_TRY_HIP(hipGetLastError());
-        unsigned int st = 0;
         SPRS_TRY_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, stream));
         double *t = cur;
         cur = nxt;
