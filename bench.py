@@ -172,6 +172,51 @@ def spgemm5(dev, idx_bytes, steps, warmup, check_rows, cpu_blocks, cpu_block_row
             # ThreadingStrategy::AutomaticPhysical (smmp.rs:26-31): the same rule on the physical cores
             "automatic_physical_value": round(tphys * scale, 2), "automatic_physical_cores": int(phys_threads),
         }
+    # ---- the supported opt-out of the reference's ORDER of additions (option spgemm_ordered = 0): same products, added by the
+    # waves of a large-row workgroup as they arrive.  Timed beside the default, never instead of it; compared entry by entry
+    # with the ordered product (which is bit-identical to the oracle's) on the device.
+    import ctypes as C
+    from sprs_amd import _ffi
+    sprs_amd.set_option("spgemm_ordered", 0)
+    try:
+        c2 = None
+        for _ in range(max(1, min(warmup, 2))):
+            c2 = None
+            c2 = smmp.mul_csr_csr(a, a)
+        torch.cuda.synchronize()
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for s_ in range(steps):
+            c2 = None
+            ev2[s_][0].record(stream)
+            c2 = smmp.mul_csr_csr(a, a)
+            ev2[s_][1].record(stream)
+        torch.cuda.synchronize()
+    finally:
+        sprs_amd.set_option("spgemm_ordered", 1)
+    ms2 = [p.elapsed_time(q) for p, q in ev2]
+    ptrs = []
+    for m in (c, c2):
+        p_ip, p_ix, p_dt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _ffi.check(_ffi.lib.sprs_hip_csmat_device_ptrs(m._h, C.byref(p_ip), C.byref(p_ix), C.byref(p_dt)))
+        ptrs.append((p_ix.value, p_dt.value))
+    blk = 1 << 26
+    b0 = torch.empty(blk, dtype=torch.float64, device=dev)
+    b1 = torch.empty(blk, dtype=torch.float64, device=dev)
+    same_structure, worst = int(c2.nnz()) == nnz_c, 0.0
+    for lo in range(0, nnz_c if same_structure else 0, blk):
+        m = min(blk, nnz_c - lo)
+        for buf, (pix, pdt) in ((b0, ptrs[0]), (b1, ptrs[1])):
+            _ffi.check(_ffi.lib.sprs_hip_memcpy_d2d(C.c_void_p(buf.data_ptr()), C.c_void_p(pix + lo * idx_bytes), m * idx_bytes, None))
+        torch.cuda.synchronize()
+        same_structure = same_structure and bool(torch.equal(b0.view(torch.uint8)[:m * idx_bytes], b1.view(torch.uint8)[:m * idx_bytes]))
+        for buf, (pix, pdt) in ((b0, ptrs[0]), (b1, ptrs[1])):
+            _ffi.check(_ffi.lib.sprs_hip_memcpy_d2d(C.c_void_p(buf.data_ptr()), C.c_void_p(pdt + lo * 8), m * 8, None))
+        torch.cuda.synchronize()
+        worst = max(worst, float(((b0[:m] - b1[:m]).abs() / b0[:m].abs().clamp_min(1e-300)).max().item()))
+    out["unordered_adds"] = {"option": "spgemm_ordered = 0", "seconds_per_product": round(float(np.mean(ms2)) * 1e-3, 5),
+                             "kernel_ms_min": round(float(np.min(ms2)), 3), "indices_bit_identical_to_ordered": bool(same_structure),
+                             "max_rel_diff_vs_ordered": worst, "tolerance": 1e-10, "ok": bool(same_structure and worst <= 1e-10)}
+    del c2, b0, b1
     return out
 
 

@@ -340,6 +340,9 @@ int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const 
  *                          128), spmv_band_tile (labels per slice: 16384 or 8192), spmv_band_split (row length from which a row
  *                          is cut into pieces, default 24), spmv_band_rounds, spmv_band_hot_run, spmv_band_cold_tiles,
  *                          spmv_band_overlap, spmv_band_split_permute, spmv_band_phases, spmv_band_hot_cut;
+ * name = "spgemm_ordered":  1 (default): SpGEMM adds the products of an entry in the reference's order (values bit-identical
+ *                          to sprs', deterministic); 0: unordered atomic adds in the large-row kernel (same products, rounding-
+ *                          level differences, not reproducible run to run, ~12 % faster on BASELINE config 5);
  * name = "gauss_seidel_blocks": workgroups of the Gauss-Seidel sweep kernel (0 = default: one per CU), "gauss_seidel_naps";
  * name = "spgemm_*", "spmm_long_row", "pool", "pool_max_bytes": INTEGRATION.md, "Options".
  * The whole table (name, default, range) is SPRS_HIP_OPTIONS in sprs_amd/csrc/common.hpp.  Developer switches — timing

@@ -80,6 +80,7 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_midwin_sym, 16, 14, 16, 0) /* log2 of the window of the wave-per-row COUNTING kernel */                              \
     X(spgemm_midwin, 14, 13, 14, 0)     /* log2 of the column window of the wave-per-row kernel */                                \
     X(spgemm_mid, 65536, 0, 1ll << 31, 0) /* rows of <= 64 k's and at most this many products run one wave per row (0: none) */   \
+    X(spgemm_ordered, 1, 0, 1, 0)       /* 1: products are added in the reference's order (values bit-identical to sprs'); 0: the waves of a large-row workgroup add as they arrive (LDS atomics: same products, rounding-level differences, not reproducible run to run; ~20 % faster kernel) */ \
     X(spgemm_debug, 0, 0, 3, 1)         /* TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission */ \
     X(spgemm_occupancy, 3, 2, 3, 0)     /* workgroups per CU the large-row numeric kernel is compiled for: 3 (80 VGPRs) or 2 (128) */ \
     X(spgemm_retain, 1, 0, 1, 0)        /* windows of few entries keep them in registers from the bit pass to the adds (A/B) */    \

@@ -630,7 +630,7 @@ __device__ __forceinline__ void lds_store_f64(double *p, double v) { *(lds_vf64 
 #endif
 
 __device__ __forceinline__ void token_wait(uint32_t *token, uint32_t turn) {
-    if (turn == 0xFFFFFFFFu) return;       // timing experiments only (option spgemm_debug & 1, developer builds): no ordering
+    if (turn == 0xFFFFFFFFu) return;       // option spgemm_ordered = 0: no ordering of the waves' adds
     while (lds_load_u32(token) != turn) SPRS_POLL_PAUSE();
     asm volatile("" ::: "memory");
     wave_sync_lds();      // (no instruction; in the CPU emulator, where the lanes of a wave run one after the other, it keeps lane 0
@@ -1085,7 +1085,8 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const bool values = NUMERIC && c_data != nullptr;
     const bool lds_atomic = (flags & 1u) != 0;
     const bool retain_ok = values && (flags & 2u) != 0;
-    const bool no_order = DEVTOOLS && (flags & 4u) != 0, no_emit = DEVTOOLS && (flags & 8u) != 0;     // timing experiments (option spgemm_debug): WRONG results
+    const bool no_order = (flags & 4u) != 0;                        // option spgemm_ordered = 0 (supported: same products, unordered atomic adds)
+    const bool no_emit = DEVTOOLS && (flags & 8u) != 0;             // timing experiment (option spgemm_debug & 2): WRONG results
     const uint32_t ntok = 1u << ((flags >> 4) & 3u);                          // 1, 2 or 4 token chains (option spgemm_tokens)
     // a row whose k's fit one staged group: thread j keeps k_j, the bounds of B's row k_j and a_ik for the whole task
     const bool mine_k = one_group && tid < (uint32_t)(ae - as) && w_begin < w_end;
@@ -1580,7 +1581,12 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     }
     if (n_large) {
         const dim3 g((unsigned)n_large), blk(LG_BLOCK);
-        const uint32_t flags = (options().spgemm_lds_atomic ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u) | ((uint32_t)options().spgemm_debug << 2) |
+        // bit 2: the adds of a workgroup's waves are NOT put in the reference's order (option spgemm_ordered = 0: every C(i,j) still
+        // is the sum of the same products, added by LDS atomics in whatever order the waves arrive — rounding-level differences,
+        // not reproducible run to run; structure unaffected).  Needs the atomic form of the add.
+        const bool unordered = options().spgemm_ordered == 0;
+        const uint32_t flags = ((options().spgemm_lds_atomic || unordered) ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u) |
+                               (unordered ? 4u : 0u) | ((uint32_t)options().spgemm_debug << 2) |
                                ((options().spgemm_tokens >= 4 ? 2u : options().spgemm_tokens >= 2 ? 1u : 0u) << 4);
 #define SPRS_LG_NUM(WL, OCC)                                                                                         \
     hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, true, OCC>), g, blk, 0, stream, A, B, pl->b_cols,            \

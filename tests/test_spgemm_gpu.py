@@ -580,3 +580,42 @@ def test_task_order_does_not_change_the_result(hip):
         hip.set_option("spgemm_task_order", 0)
     for x, y in zip(r1[1:], r2[1:]):
         assert np.array_equal(x, y)
+
+
+def test_unordered_adds_option(hip):
+    """option spgemm_ordered = 0 (supported opt-out of the reference's order of additions in the large-row kernel): the
+    structure stays bit-identical; every value is the sum of the same products, so it agrees with the ordered result to the
+    rounding of a reordered sum — |diff| <= n_products * eps * sum |products| per entry — and, on an R-MAT product of
+    positive values (no cancellation), to 1e-10 relative, the north star's tolerance.  The default is restored."""
+    from sprs_amd import gen
+    from sprs_amd.device import DeviceCsMat
+    cases = [(_order_stress_cases()[i]) for i in (0, 1, 2, 3)]
+    eps = np.finfo(np.float64).eps
+    for a, b in cases:
+        A = DeviceCsMat.from_host(*a)
+        B = DeviceCsMat.from_host(*b)
+        exact = (A * B).to_host()
+        hip.set_option("spgemm_ordered", 0)
+        try:
+            relaxed = (A * B).to_host()
+        finally:
+            hip.set_option("spgemm_ordered", 1)
+        assert np.array_equal(exact[1], relaxed[1]) and np.array_equal(exact[2], relaxed[2])
+        # bound from |A| * |B| through the same kernels (ordered)
+        absA = DeviceCsMat.from_host(a[0], a[1], a[2], np.abs(a[3]))
+        absB = DeviceCsMat.from_host(b[0], b[1], b[2], np.abs(b[3]))
+        mag = (absA * absB).to_host()[3]
+        n_prod = int(np.diff(a[1].astype(np.int64)).max())
+        assert np.all(np.abs(exact[3] - relaxed[3]) <= 2.0 * n_prod * eps * mag)
+    n = 30000
+    indptr, indices, data = gen.rmat_csr(n, 12, seed=5)
+    m = DeviceCsMat.from_host((n, n), indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy())
+    exact = (m * m).to_host()
+    hip.set_option("spgemm_ordered", 0)
+    try:
+        relaxed = (m * m).to_host()
+    finally:
+        hip.set_option("spgemm_ordered", 1)
+    assert np.array_equal(exact[1], relaxed[1]) and np.array_equal(exact[2], relaxed[2])
+    assert np.max(np.abs(exact[3] - relaxed[3]) / np.maximum(np.abs(exact[3]), 1e-300)) <= 1e-10
+    assert hip.get_option("spgemm_ordered") == 1
