@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the HIP path against the CPU oracle: seeded random matrices (empty rows, single entries, hub rows,
+unreferenced column ranges, rectangular shapes, 4- and 8-byte index types) through the SpMV plans (plain, XCD-sliced, banded
+with random plan geometry), SpGEMM (every row class by random thresholds), SpMM and the Gauss-Seidel sweep, for a time budget.
+Every case prints nothing when it agrees; a disagreement prints the seed and the parameters that reproduce it and counts
+as a failure (exit status 1).  The oracle is the checker here, nothing else.
+usage: fuzz_parity.py [seconds] [first_seed]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import sprs_amd                                               # noqa: E402
+from sprs_amd.device import DeviceCsMat, DeviceVec           # noqa: E402
+from oracle import oracle                                     # noqa: E402
+
+DEFAULTS = {}
+
+
+def setopt(**kw):
+    for k, v in kw.items():
+        if k not in DEFAULTS:
+            DEFAULTS[k] = sprs_amd.get_option(k)
+        sprs_amd.set_option(k, v)
+
+
+def reset():
+    for k, v in DEFAULTS.items():
+        sprs_amd.set_option(k, v)
+
+
+def random_csr(rng, rows, cols, idx, ptr, positive=False):
+    kinds = rng.integers(0, 7, size=rows)
+    lens = np.select([kinds == 0, kinds == 1, kinds == 2, kinds == 3], [0, 1, rng.integers(2, 12, size=rows), rng.integers(12, 40, size=rows)],
+                     rng.integers(1, 6, size=rows))
+    for h in rng.choice(rows, size=min(rows, int(rng.integers(0, 4))), replace=False):
+        lens[h] = rng.integers(1, cols + 1) if cols < 4000 else rng.integers(cols // 8, cols // 2)
+    lens = np.minimum(lens, cols)
+    ip = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=ip[1:])
+    ix = np.empty(ip[-1], dtype=np.int64)
+    skew = rng.random() < 0.5                                 # popular columns (power-law-ish) or uniform
+    for r in range(rows):
+        n = int(lens[r])
+        if not n:
+            continue
+        if n * 3 > cols:
+            c = rng.permutation(cols)[:n]
+        else:
+            c = np.zeros(0, dtype=np.int64)
+            while c.size < n:
+                draw = (cols * rng.random(2 * n + 8) ** (3.0 if skew else 1.0)).astype(np.int64)
+                c = np.unique(np.concatenate([c, np.minimum(draw, cols - 1)]))
+            c = rng.permutation(c)[:n]
+        ix[ip[r]:ip[r + 1]] = np.sort(c)
+    dt = (rng.random(ip[-1]) + 0.5) if positive else rng.standard_normal(ip[-1]) * 10.0 ** rng.integers(-3, 4, size=ip[-1])
+    return (rows, cols), ip.astype(ptr), ix.astype(idx), dt
+
+
+def types(rng):
+    return [(np.uint64, np.uint64), (np.uint32, np.uint64), (np.uint32, np.uint32)][int(rng.integers(0, 3))]
+
+
+def case_spmv(rng):
+    idx, ptr = types(rng)
+    rows, cols = int(rng.integers(1, 3000)), int(rng.integers(1, 40000))
+    shape, ip, ix, dt = random_csr(rng, rows, cols, idx, ptr)
+    plan = int(rng.integers(0, 4))
+    opts = {}
+    if plan == 1:
+        opts = dict(spmv_band=2, spmv_xcs=1, spmv_xcs_split=int(rng.choice([2, 8, 32])))
+    elif plan == 2:
+        tile = int(rng.choice([8192, 16384]))
+        opts = dict(spmv_band=1, spmv_band_tile=tile, spmv_band_hot=int(rng.integers(1, max(2, cols // tile + 2))),
+                    spmv_band_split=int(rng.choice([2, 8, 24, 40])), spmv_band_rounds=int(rng.integers(1, 5)),
+                    spmv_band_hot_run=int(rng.integers(1, 5)), spmv_band_cold_tiles=int(rng.integers(1, 5)),
+                    spmv_band_phases=int(rng.integers(1, 3)))
+    elif plan == 3:
+        opts = dict(spmv_band=2, spmv_xcs=2, spmv_kernel=int(rng.choice([1, 2])), spmv_tile=int(rng.choice([0, 2048, 4096])))
+    setopt(**opts)
+    a = DeviceCsMat.from_host(shape, ip, ix, dt)
+    x = rng.standard_normal(cols)
+    y0 = rng.standard_normal(rows)
+    from sprs_amd import prod
+    ref = oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, x, y0.copy())
+    yd = DeviceVec.from_host(y0)
+    prod.mul_acc_mat_vec_csr(a, DeviceVec.from_host(x), yd)
+    got = yd.to_host()
+    import scipy.sparse as sp
+    mag = np.abs(sp.csr_matrix((np.abs(dt), ix.astype(np.int64), ip.astype(np.int64)), shape=shape)) @ np.abs(x) + np.abs(y0)
+    bad = np.abs(got - ref) > 1e-10 * np.maximum(np.abs(ref), 1e-300) + 64 * np.finfo(float).eps * mag
+    plain = prod.csmat_mul_vec(a, DeviceVec.from_host(x)).to_host()
+    ref2 = oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, x, np.zeros(rows))
+    bad2 = np.abs(plain - ref2) > 1e-10 * np.maximum(np.abs(ref2), 1e-300) + 64 * np.finfo(float).eps * mag
+    return not (bad.any() or bad2.any()), dict(kind="spmv", rows=rows, cols=cols, plan=plan, opts=opts, idx=str(np.dtype(idx)), ptr=str(np.dtype(ptr)))
+
+
+def case_spgemm(rng):
+    idx, ptr = types(rng)
+    m, k, n = int(rng.integers(1, 400)), int(rng.integers(1, 900)), int(rng.integers(1, 300000))
+    A = random_csr(rng, m, k, idx, ptr)
+    B = random_csr(rng, k, n, idx, ptr)
+    opts = dict(spgemm_mid=int(rng.choice([0, 600, 65536])), spgemm_heavy=int(rng.choice([1024, 4096, 131072])),
+                spgemm_winlog=int(rng.choice([16, 17, 18, 19])), spgemm_bucket=int(rng.integers(0, 2)),
+                spgemm_retain=int(rng.integers(0, 2)), spgemm_tokens=int(rng.choice([1, 2, 4])))
+    setopt(**opts)
+    try:
+        rs, rip, rix, rdt = oracle.mul_csr_csr(A[0], A[1], A[2], A[3], B[0], B[1], B[2], B[3])
+    except oracle.OracleError:
+        return True, dict(kind="spgemm", skipped="index overflow in the oracle")
+    c = (DeviceCsMat.from_host(*A) * DeviceCsMat.from_host(*B)).to_host()
+    ok = c[0] == tuple(rs) and np.array_equal(c[1], rip) and np.array_equal(c[2], rix) and np.array_equal(c[3].view(np.uint64), rdt.view(np.uint64))
+    return ok, dict(kind="spgemm", m=m, k=k, n=n, opts=opts, idx=str(np.dtype(idx)), ptr=str(np.dtype(ptr)))
+
+
+def case_spmm(rng):
+    idx, ptr = types(rng)
+    rows, cols, k = int(rng.integers(1, 1500)), int(rng.integers(1, 5000)), int(rng.choice([1, 2, 3, 7, 8, 9, 16, 17, 33, 64, 70]))
+    shape, ip, ix, dt = random_csr(rng, rows, cols, idx, ptr)
+    rhs = rng.standard_normal((cols, k))
+    a = DeviceCsMat.from_host(shape, ip, ix, dt)
+    import ctypes as C
+    from sprs_amd import _ffi
+    d_rhs, d_out = DeviceVec.from_host(rhs.reshape(-1)), DeviceVec.zeros(rows * k)
+    _ffi.check(_ffi.lib.sprs_hip_spmm_rowmaj_f64(a._h, C.c_void_p(d_rhs.ptr), cols, k, k, C.c_void_p(d_out.ptr), rows, k, 0, None))
+    got = d_out.to_host().reshape(rows, k)
+    import scipy.sparse as sp
+    absm = sp.csr_matrix((np.abs(dt), ix.astype(np.int64), ip.astype(np.int64)), shape=shape)
+    ok = True
+    for j in range(k):
+        ref = oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, np.ascontiguousarray(rhs[:, j]), np.zeros(rows))
+        mag = absm @ np.abs(rhs[:, j])
+        ok = ok and not np.any(np.abs(got[:, j] - ref) > 1e-10 * np.abs(ref) + 64 * np.finfo(float).eps * mag)
+    return ok, dict(kind="spmm", rows=rows, cols=cols, k=k, idx=str(np.dtype(idx)), ptr=str(np.dtype(ptr)))
+
+
+def case_gauss_seidel(rng):
+    from sprs_amd.linalg import gauss_seidel
+    import scipy.sparse as sp
+    idx, ptr = types(rng)
+    n = int(rng.integers(1, 3000))
+    shape, ip, ix, dt = random_csr(rng, n, n, np.uint64, np.uint64)
+    m = sp.csr_matrix((dt, ix.astype(np.int64), ip.astype(np.int64)), shape=shape)
+    m = (m + sp.diags(np.abs(m).sum(axis=1).A1 + 1.0)).tocsr()
+    m.sort_indices()
+    ip, ix, dt = m.indptr.astype(ptr), m.indices.astype(idx), m.data
+    rhs, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    sweeps = int(rng.integers(1, 4))
+    opts = dict(gauss_seidel_xcd=int(rng.integers(0, 3)), gauss_seidel_blocks=int(rng.choice([0, 1, 3, 64])))
+    setopt(**opts)
+    ref, info = oracle.gauss_seidel(shape, ip, ix, dt, x0, rhs, sweeps, -1.0)
+    x = DeviceVec.from_host(x0)
+    gauss_seidel(DeviceCsMat.from_host(shape, ip, ix, dt), x, DeviceVec.from_host(rhs), sweeps, -1.0)
+    return bool(np.array_equal(x.to_host().view(np.uint64), ref.view(np.uint64))), dict(kind="gauss_seidel", n=n, sweeps=sweeps, opts=opts)
+
+
+CASES = (case_spmv, case_spmv, case_spgemm, case_spgemm, case_spmm, case_gauss_seidel)
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0, counts, failures = time.time(), {}, []
+    while time.time() - t0 < seconds:
+        rng = np.random.default_rng(seed)
+        fn = CASES[seed % len(CASES)]
+        try:
+            ok, what = fn(rng)
+        except Exception as e:                                # a status the oracle does not mirror is a finding too
+            ok, what = False, dict(kind=fn.__name__, error=repr(e)[:300])
+        finally:
+            reset()
+        counts[what.get("kind", "?")] = counts.get(what.get("kind", "?"), 0) + 1
+        if not ok:
+            failures.append(dict(seed=seed, **what))
+            print(json.dumps(failures[-1]), flush=True)
+        seed += 1
+    print(json.dumps({"cases": counts, "failures": len(failures), "seconds": round(time.time() - t0, 1), "next_seed": seed}))
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -3,7 +3,7 @@
 G x G grid: time per sweep on the device (sweep kernel + the residual SpMV + the convergence scalar, as the reference's loop
 has them), the one-time plan (level order on the host, SpMV plan), the CPU oracle's time per sweep beside it, and parity:
 the iterate after K sweeps bit for bit against the oracle (at the full size: the oracle sweeps 1.7e7 rows in ~0.4 s).
-usage: gauss_seidel_bench.py [G] [K] [blocks[:naps] ...]     (defaults 4096 3 and the library's defaults; blocks = workgroups
+usage: gauss_seidel_bench.py [G] [K] [blocks[:naps[:xcd]] ...]     (defaults 4096 3 and the library's defaults; blocks = workgroups
 of the sweep kernel, naps = longest pause of a waiting wave)"""
 import json
 import os
@@ -22,7 +22,7 @@ from oracle import oracle                                     # noqa: E402  (the
 def main():
     g = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    blocks = [tuple(int(t) for t in (v + ":0").split(":")[:2]) for v in sys.argv[3:]] or [(0, 0)]
+    blocks = [tuple(int(t) for t in (v + ":0:0").split(":")[:3]) for v in sys.argv[3:]] or [(0, 0, 0)]
     if g > 0:
         shape, ip, ix, dt = oracle.grid_laplacian(g, g)
         n = g * g
@@ -55,9 +55,10 @@ def main():
     x_ref, info = oracle.gauss_seidel(shape, ip, ix, dt, x0, rhs, k, -1.0)
     cpu = (time.perf_counter() - t0) / max(k, 1)
     alg = ix.size * (8 + ix.itemsize) + (n + 1) * ip.itemsize + 4 * n * 8      # matrix once, x old + new, rhs, order (4 B) ~ per sweep
-    for b, naps in blocks:
+    for b, naps, xcd in blocks:
         sprs_amd.set_option("gauss_seidel_blocks", b)
         sprs_amd.set_option("gauss_seidel_naps", naps)
+        sprs_amd.set_option("gauss_seidel_xcd", xcd)
         x = DeviceVec.from_host(x0)
         gauss_seidel(a, x, d_rhs, 1, -1.0)                     # warm
         times = {}
@@ -70,7 +71,7 @@ def main():
                 got = x.to_host()
         per = (times[4 * k] - times[k]) / (3 * k)
         same = bool(np.array_equal(got, x_ref))
-        print(json.dumps({"grid": g, "rows": n, "nnz": int(ix.size), "levels": res.levels, "workgroups": b or "default", "naps": naps or "default",
+        print(json.dumps({"grid": g, "rows": n, "nnz": int(ix.size), "levels": res.levels, "workgroups": b or "default", "naps": naps or "default", "xcd_mode": xcd,
                           "ms_per_sweep_with_residual": round(per * 1e3, 3), "us_per_level": round(per * 1e6 / res.levels, 3),
                           "first_call_s_plans_included": round(first, 3), "oracle_ms_per_sweep_with_residual": round(cpu * 1e3, 1),
                           "speedup_vs_one_core": round(cpu / per, 1), "streamed_GBs": round(alg / per / 1e9, 1),

@@ -90,6 +90,7 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_heavy, 131072, 1024, INT64_MAX, 0) /* a row of more products is cut into one task per (narrower) column window */    \
     X(gauss_seidel_blocks, 0, 0, 65536, 0) /* workgroups (4 waves) of the Gauss-Seidel sweep kernel (0 = default: one per CU) */          \
     X(gauss_seidel_chain, 0, 0, 1ll << 30, 0) /* rows one lane sweeps one after the other: 0 auto, 1 one row per lane in level order, L > 1 chains of L consecutive rows */ \
+    X(gauss_seidel_xcd, 0, 0, 2, 0)     /* sweep kernel: 1 only the workgroups that find themselves on XCD 0 take part (hand-offs through ONE L2), 0 / 2 every XCD (measured: one XCD is not faster) */ \
     X(gauss_seidel_naps, 0, 0, 64, 0)   /* longest pause of a wave whose rows all wait, in s_sleep(1) units, growing with the wait (0 = default 1) */ \
     X(pool, 1, 0, 1, 0)                 /* keep released result blocks (>= 1 MiB) for the next result instead of hipFree */        \
     X(pool_max_bytes, 128ll << 30, 0, INT64_MAX, 0) /* cap on the bytes the pool may hold */

@@ -59,7 +59,20 @@ __device__ __forceinline__ unsigned long long gs_peek(const unsigned long long *
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename IDX, typename PTR>
+// the XCD (accelerator die: its own L2) this wave runs on, from the hardware register
+__device__ __forceinline__ uint32_t gs_xcc_id() {
+#ifdef SPRS_HIP_EMU
+    return 0u;
+#else
+    return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // hwreg(HW_REG_XCC_ID, 0, 4)
+#endif
+}
+
+// ONE_XCD: only workgroups that find themselves on XCD 0 take part.  All of them then share one L2, so a result can be
+// published with a plain store (it stays in that L2, dirty) and the 8-byte L1-bypassing loads of the pollers are served
+// from there instead of from the fabric: a shorter hop for matrices whose sweep is a long chain of narrow levels.  Which
+// XCD a wave is on is read from the hardware (never assumed from blockIdx), so only speed depends on the dispatcher.
+template <typename IDX, typename PTR, bool ONE_XCD>
 __global__ __launch_bounds__(GS_BLOCK) void gs_sweep_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
                                                             const double *__restrict__ data,
                                                             const uint32_t *__restrict__ order,
@@ -67,6 +80,7 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_sweep_kernel(const PTR *__restric
                                                             const double *__restrict__ rhs, uint64_t n,
                                                             unsigned int *next_chunk, unsigned int *status, uint32_t max_naps) {
     const uint32_t lane = threadIdx.x & 63u;
+    if (ONE_XCD && gs_xcc_id() != 0u) return;
     auto draw = [&]() -> uint64_t {
         unsigned int q = 0;
         if (lane == 0) q = atomicAdd(next_chunk, 1u);
@@ -88,12 +102,12 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_sweep_kernel(const PTR *__restric
         bool has_diag = false;
         uint32_t col[GS_B];
         double val[GS_B], xv[GS_B];
-        uint32_t nb = 0, used = 0, ready = 0, spins = 0;
-        bool more = true;
+        uint32_t nb = 0, pend = 0, spins = 0;
+        bool loaded = false, more = true;
         while (more) {
             bool moved = false;
             if (!done) {
-                if (used == nb && p < end) {                   // the next (up to) eight entries of my row
+                if (!loaded) {                                 // the next (up to) eight entries of my row
                     nb = end - p < (uint64_t)GS_B ? (uint32_t)(end - p) : (uint32_t)GS_B;
 #pragma unroll
                     for (int u = 0; u < GS_B; ++u)
@@ -102,64 +116,64 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_sweep_kernel(const PTR *__restric
                             val[u] = data[p + u];
                         }
                     p += nb;
-                    used = 0;
-                    ready = 0;
                     // The column ids are needed NOW (they address the x loads below).  Without a use at this point the compiler
                     // waits for them in front of every single x load with a count that must hold on every path (vmcnt(1)): the
-                    // eight x loads then go out one after the other instead of together.
+                    // x loads then go out one after the other instead of together.
                     uint32_t touch = 0;
 #pragma unroll
                     for (int u = 0; u < GS_B; ++u)
                         if ((uint32_t)u < nb) touch |= col[u];
                     GS_TOUCH(touch);
+                    // columns behind the row: the previous iterate, requested once; columns before it: to be polled
+                    pend = 0;
+#pragma unroll
+                    for (int u = 0; u < GS_B; ++u)
+                        if ((uint32_t)u < nb) {
+                            if (col[u] > row) xv[u] = x_old[col[u]];
+                            else if (col[u] < row) pend |= 1u << u;
+                        }
+                    loaded = true;
+                    moved = true;
                 }
-                // request what has not arrived yet, all at once
+                // the poll: this sweep's values that have not arrived yet, all requested together — kept short, it is what a
+                // waiting wave executes over and over and what stands between a published value and its use
                 unsigned long long bits[GS_B];
 #pragma unroll
-                for (int u = 0; u < GS_B; ++u) {
-                    bits[u] = GS_PENDING;
-                    if ((uint32_t)u >= used && (uint32_t)u < nb && !((ready >> u) & 1u)) {
-                        const uint32_t c = col[u];
-                        if (c < row) bits[u] = gs_peek(x_new + c);                                    // this sweep's value, once published
-                        else if (c > row) bits[u] = (unsigned long long)__double_as_longlong(x_old[c]);   // the previous iterate
-                    }
-                }
+                for (int u = 0; u < GS_B; ++u)
+                    if ((pend >> u) & 1u) bits[u] = gs_peek(x_new + col[u]);
 #pragma unroll
                 for (int u = 0; u < GS_B; ++u)
-                    if ((uint32_t)u >= used && (uint32_t)u < nb && !((ready >> u) & 1u)) {
-                        const uint32_t c = col[u];
-                        if (c == row) {
-                            ready |= 1u << u;
-                        } else if (c > row || bits[u] != GS_PENDING) {
-                            xv[u] = __longlong_as_double((long long)bits[u]);
-                            ready |= 1u << u;
-                        }
-                    }
-                // add in entry order as far as the operands are there (heat.rs:117-123)
-#pragma unroll
-                for (int u = 0; u < GS_B; ++u)
-                    if ((uint32_t)u == used && (uint32_t)u < nb && ((ready >> u) & 1u)) {
-                        if (col[u] == row) {
-                            diag = val[u];
-                            has_diag = true;
-                        } else {
-                            const double prod = val[u] * xv[u];
-                            sigma = sigma + prod;
-                        }
-                        ++used;
+                    if (((pend >> u) & 1u) && bits[u] != GS_PENDING) {
+                        xv[u] = __longlong_as_double((long long)bits[u]);
+                        pend &= ~(1u << u);
                         moved = true;
                     }
-                if (used == nb && p == end) {
-                    double xr = (b - sigma) / diag;             // heat.rs:128-130
-                    unsigned long long out = (unsigned long long)__double_as_longlong(xr);
-                    if (!has_diag) {                            // diag.unwrap() of None: the host turns this into an error
-                        atomicOr(status, GS_NO_DIAG);
-                        out = GS_QNAN;
-                    }
-                    if (out == GS_PENDING) out = GS_QNAN;       // (a NaN payload handed through from rhs / x: still a NaN, but not "pending")
-                    __hip_atomic_store(x_new + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    done = true;
+                if (pend == 0u) {                              // every operand of the batch is here: add in entry order (heat.rs:117-123)
+#pragma unroll
+                    for (int u = 0; u < GS_B; ++u)
+                        if ((uint32_t)u < nb) {
+                            if (col[u] == row) {
+                                diag = val[u];
+                                has_diag = true;
+                            } else {
+                                const double prod = val[u] * xv[u];
+                                sigma = sigma + prod;
+                            }
+                        }
+                    loaded = false;
                     moved = true;
+                    if (p == end) {
+                        double xr = (b - sigma) / diag;         // heat.rs:128-130
+                        unsigned long long out = (unsigned long long)__double_as_longlong(xr);
+                        if (!has_diag) {                        // diag.unwrap() of None: the host turns this into an error
+                            atomicOr(status, GS_NO_DIAG);
+                            out = GS_QNAN;
+                        }
+                        if (out == GS_PENDING) out = GS_QNAN;   // (a NaN payload handed through from rhs / x: still a NaN, but not "pending")
+                        if constexpr (ONE_XCD) __hip_atomic_store(x_new + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: into the shared L2
+                        else __hip_atomic_store(x_new + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                         // write-through (sc1): every XCD sees it
+                        done = true;
+                    }
                 }
             }
             more = __ballot(!done) != 0ull;
@@ -326,6 +340,10 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
     const uint64_t need = (n + GS_BLOCK - 1) / GS_BLOCK;
     uint64_t grid = options().gauss_seidel_blocks > 0 ? (uint64_t)options().gauss_seidel_blocks : (uint64_t)(ncu > 0 ? ncu : 1);
     if (grid > need) grid = need;
+    // one XCD (option): hand-offs through one L2 for long chains of narrow levels
+    // (measured: no gain — 20.2 against 19.3 ms on the 4096^2 heat system, profiles/r08d, r08e — so auto means every XCD)
+    const bool one_xcd = options().gauss_seidel_xcd == 1;
+    if (one_xcd && options().gauss_seidel_blocks == 0) grid = (uint64_t)(ncu > 8 ? ncu / 8 : 1) < need ? (uint64_t)(ncu > 8 ? ncu / 8 : 1) : need;
     const uint32_t max_naps = options().gauss_seidel_naps > 0 ? (uint32_t)options().gauss_seidel_naps : 1u;
 
     double error = 0.0;
@@ -336,9 +354,14 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
     for (uint64_t it = 0; it < max_iter; ++it) {
         SPRS_TRY_HIP(hipMemsetAsync(nxt, 0xFF, n * sizeof(double), stream));   // every row of the next iterate "pending"
         SPRS_TRY_HIP(hipMemsetAsync(w.words, 0, 64, stream));
-        hipLaunchKernelGGL((gs_sweep_kernel<IDX, PTR>), dim3((unsigned)grid), dim3(GS_BLOCK), 0, stream, (const PTR *)a->indptr,
-                           (const IDX *)a->indices, (const double *)a->data, order, (const double *)cur,
-                           (unsigned long long *)nxt, rhs, n, next_chunk, status, max_naps);
+        if (one_xcd)       // 8 x the workgroups: an eighth of them lands on XCD 0 and stays
+            hipLaunchKernelGGL((gs_sweep_kernel<IDX, PTR, true>), dim3((unsigned)(grid * 8)), dim3(GS_BLOCK), 0, stream, (const PTR *)a->indptr,
+                               (const IDX *)a->indices, (const double *)a->data, order, (const double *)cur,
+                               (unsigned long long *)nxt, rhs, n, next_chunk, status, max_naps);
+        else
+            hipLaunchKernelGGL((gs_sweep_kernel<IDX, PTR, false>), dim3((unsigned)grid), dim3(GS_BLOCK), 0, stream, (const PTR *)a->indptr,
+                               (const IDX *)a->indices, (const double *)a->data, order, (const double *)cur,
+                               (unsigned long long *)nxt, rhs, n, next_chunk, status, max_naps);
         SPRS_TRY_HIP(hipGetLastError());
         SPRS_TRY_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, stream));
         double *t = cur;

@@ -176,6 +176,9 @@ inline void __threadfence_block() {}
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
+#ifndef __HIP_MEMORY_SCOPE_WORKGROUP
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#endif
 // agent-scope 8-byte hand-offs (gauss_seidel.hip): fibers switch cooperatively, a plain access is atomic
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
