@@ -23,7 +23,25 @@ def main():
     g = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     blocks = [tuple(int(t) for t in (v + ":0:0").split(":")[:3]) for v in sys.argv[3:]] or [(0, 0, 0)]
-    if g > 0:
+    if os.environ.get("GS_BANDED"):
+        # experiment: the same number of rows, entries per row and levels as the heat system, but the rows of a level are
+        # CONTIGUOUS (row i reads rows i - W and i - W + 1): hand-offs of neighbouring lanes share cache lines
+        w = int(os.environ["GS_BANDED"])
+        n = g * g
+        i = np.arange(n, dtype=np.int64)
+        cols = np.stack([i - w, i - w + 1, i, i + 1, i + w], axis=1)
+        vals = np.broadcast_to(np.array([1.0, 1.0, -4.5, 1.0, 1.0]), cols.shape)
+        keep = (cols >= 0) & (cols < n)
+        keep[:, 1] &= cols[:, 1] < i                           # (i - W + 1 < i unless W = 1)
+        lens = keep.sum(axis=1)
+        ip = np.zeros(n + 1, dtype=np.uint64)
+        ip[1:] = np.cumsum(lens)
+        ix = cols[keep].astype(np.uint64)
+        dt = np.ascontiguousarray(vals[keep])
+        shape = (n, n)
+        rhs = np.random.default_rng(1).standard_normal(n)
+        del cols, vals, keep, i
+    elif g > 0:
         shape, ip, ix, dt = oracle.grid_laplacian(g, g)
         n = g * g
         i, j = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
