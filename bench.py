@@ -395,6 +395,32 @@ def main():
         libdist.spmv(DeviceVec.borrow(xv), yv_all, stream=stream)
         return sh.y
 
+    routes_check = None
+    if world > 1:
+        # every rank must take the same route: the library route only if it came up on ALL ranks, and only if one step through it
+        # gives what one step through torch.distributed gives (the two exchanges move the same blocks; the multiply is the same
+        # kernel) — otherwise all ranks time the torch route together and the line says so
+        import torch.distributed as dist
+        flag = torch.tensor([1.0 if libdist is not None else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 0.5:
+            libdist = None
+        if libdist is not None:
+            worst = torch.tensor([float("inf")], dtype=torch.float64, device=dev)
+            try:
+                y_t = torch_step(x).clone()
+                y_l = lib_step(x)
+                torch.cuda.synchronize()
+                worst = ((y_l - y_t).abs() / y_t.abs().clamp_min(1e-300)).max().reshape(1)
+                worst = torch.where(torch.isfinite(worst), worst, torch.full_like(worst, float("inf")))
+                del y_t
+            except Exception as e:
+                if rank == 0:
+                    print("bench.py: library exchange failed in the cross-check (%s)" % repr(e)[:200], file=sys.stderr)
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            routes_check = {"lib_vs_torch_max_rel_diff": float(worst.item()), "tolerance": 1e-10, "ok": bool(float(worst.item()) <= 1e-10)}
+            if not routes_check["ok"]:
+                libdist = None
     use_lib = libdist is not None and args.exchange == "lib"
     if use_lib:
         step = lib_step
@@ -533,6 +559,8 @@ def main():
     }
 
     if exchange_times is not None:
+        if routes_check is not None:
+            exchange_times["routes_agree"] = routes_check
         out["exchange"] = exchange_times
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on the host cores -------------

@@ -231,6 +231,21 @@ private:
     DeviceVec x_;
     sprs_hip_bicgstab_info info_{};
 };
+// gauss_seidel(mat, x, rhs, max_iter, eps) of the reference's heat example (sprs/examples/heat.rs:103-139): x is the start
+// vector and receives the result (the reference's `mut x`); Ok((iterations, error)) <-> converged, Err(error) otherwise.
+struct GaussSeidelResult {
+    bool converged;
+    uint64_t iterations;
+    double error;
+    uint64_t levels;      // longest chain of rows that must be swept one after the other (device-side information)
+};
+inline GaussSeidelResult gauss_seidel(const DeviceCsMat &mat, DeviceVec &x, const DeviceVec &rhs, uint64_t max_iter, double eps) {
+    if (x.dim() != rhs.dim()) throw Error(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    sprs_hip_gauss_seidel_info info{};
+    check(sprs_hip_gauss_seidel_f64(const_cast<sprs_hip_csmat *>(mat.handle()), x.ptr(), rhs.ptr(), x.dim(), max_iter, eps, &info,
+                                    nullptr));
+    return GaussSeidelResult{info.converged != 0, info.iterations, info.error, info.levels};
+}
 }  // namespace linalg
 
 // Result blocks released by ~DeviceCsMat stay in the library's pool for the next result (sprs_hip.h);

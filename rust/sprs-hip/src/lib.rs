@@ -217,6 +217,19 @@ pub mod linalg {
         pub fn rho(&self) -> f64 { self.info.rho }
         pub fn x(&self) -> &DeviceVec { &self.x }
     }
+
+    /// Twin of `gauss_seidel(mat, x, rhs, max_iter, eps)` of the reference's heat example (examples/heat.rs:103-139):
+    /// `x` is the start vector and receives the result; `Ok((iterations, error))` / `Err(error)` like the reference.
+    pub fn gauss_seidel(mat: &DeviceCsMat, x: &mut DeviceVec, rhs: &DeviceVec, max_iter: usize, eps: f64)
+        -> Result<(usize, f64), f64> {
+        assert_eq!(x.len, rhs.len, "Dimension mismatch");
+        let mut info = sys::sprs_hip_gauss_seidel_info::default();
+        unsafe {
+            check(sys::sprs_hip_gauss_seidel_f64(mat.h, x.ptr, rhs.ptr, x.len as u64, max_iter as u64, eps, &mut info,
+                                                 std::ptr::null_mut()));
+        }
+        if info.converged != 0 { Ok((info.iterations as usize, info.error)) } else { Err(info.error) }
+    }
 }
 
 /// Result blocks released by `Drop for DeviceCsMat` stay pooled inside the library; this returns them to

@@ -82,6 +82,22 @@ int main() {
             REQUIRE(std::fabs(1.0 - 1.0 / bi) < 1e-60);
         }
     }
+    {   // gauss_seidel of heat.rs:103-139 on a 3 x 3 system: two sweeps by hand (x updated in place, row by row)
+        DeviceCsMat a(SPRS_HIP_CSR, 3, 3, std::vector<uint64_t>{0, 2, 5, 7}, std::vector<uint64_t>{0, 1, 0, 1, 2, 1, 2},
+                      std::vector<double>{4., -1., -1., 4., -1., -1., 4.});
+        const double b[3] = {1., 2., 3.};
+        double xr[3] = {0., 0., 0.};
+        for (int it = 0; it < 2; ++it) {
+            xr[0] = (b[0] - (-1. * xr[1])) / 4.;
+            xr[1] = (b[1] - ((-1. * xr[0]) + (-1. * xr[2]))) / 4.;
+            xr[2] = (b[2] - (-1. * xr[1])) / 4.;
+        }
+        DeviceVec x(std::vector<double>(3, 0.0)), rhs(std::vector<double>{1., 2., 3.});
+        auto res = linalg::gauss_seidel(a, x, rhs, 2, -1.0);
+        auto xg = x.to_host();
+        REQUIRE(!res.converged && res.iterations == 2 && res.levels == 3);
+        REQUIRE(xg[0] == xr[0] && xg[1] == xr[1] && xg[2] == xr[2]);
+    }
     {   // TriMat::to_csr: rows sorted, duplicates summed in triplet order, explicit zero kept (triplet_iter.rs:127-224)
         TriMat t(4, 4);
         const uint64_t r[6] = {2, 0, 2, 0, 2, 1}, c[6] = {1, 3, 1, 0, 1, 2};
