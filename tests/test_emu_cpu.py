@@ -49,3 +49,14 @@ def test_gauss_seidel_sweep_in_the_emulator(emu_lib, order):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gauss_seidel_gpu.py"), "-x", "-q", "-m", "gpu",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_differential_fuzzer_in_the_emulator(emu_lib):
+    """scripts/fuzz_parity.py (nine kinds of seeded random cases against the oracle; on the GPU: profiles/r08g, r09c) for
+    twenty seconds through the emulated kernels: the script itself stays runnable and the kernels' logic agrees on whatever
+    shapes the seeds of this run produce"""
+    env = dict(os.environ, SPRS_HIP_LIBRARY=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "20", "777"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert '"failures": 0' in r.stdout
