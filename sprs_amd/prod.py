@@ -29,11 +29,7 @@ def mul_acc_mat_vec_csc(mat, in_vec, res_vec, stream=None):
         raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")       # prod.rs:92
     if mat.cols() != in_vec.n or mat.rows() != res_vec.n:
         raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:88-91
-    csr = getattr(mat, "_as_csr", None)
-    if csr is None:
-        csr = mat.to_other_storage()
-        mat._as_csr = csr
-    mul_acc_mat_vec_csr(csr, in_vec, res_vec, stream)
+    mul_acc_mat_vec_csr(_csr_of(mat), in_vec, res_vec, stream)
 
 
 def csr_mulacc_dense_colmaj(lhs, rhs_cols, out_cols, stream=None):
@@ -71,10 +67,45 @@ def csr_mulacc_dense_rowmaj(lhs, rhs, out, stream=None):
                                        C.c_void_p(out.vec.ptr), out.rows, out.cols, 1, _stream_ptr(stream)))
 
 
+def _csr_of(mat):
+    """the CSR form of a CSC handle (to_other_storage on the device, csmat.rs:1405-1426), made once per Python object"""
+    csr = getattr(mat, "_as_csr", None)
+    if csr is None:
+        csr = mat.to_other_storage()
+        mat._as_csr = csr
+    return csr
+
+
+def csc_mulacc_dense_rowmaj(lhs, rhs, out, stream=None):
+    """prod::csc_mulacc_dense_rowmaj (prod.rs:219-241): out += lhs * rhs for a CSC lhs, rhs / out dense row-major.  The
+    reference walks the columns of lhs in order and adds `lval * rhs[col, :]` into out[row, :], so every out[i, j]
+    receives its products by ascending column — the order the CSR kernel uses on the converted matrix."""
+    if not lhs.is_csc():
+        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")       # prod.rs:231
+    if lhs.cols() != rhs.rows or lhs.rows() != out.rows or rhs.cols != out.cols:
+        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:228-230
+    csr_mulacc_dense_rowmaj(_csr_of(lhs), rhs, out, stream)
+
+
+def csc_mulacc_dense_colmaj(lhs, rhs_cols, out_cols, stream=None):
+    """prod::csc_mulacc_dense_colmaj (prod.rs:246-270) with rhs / out as lists of column vectors: out[:, j] += lhs * rhs[:, j]
+    (per column the reference's scatter loop = mul_acc_mat_vec_csc)."""
+    if not lhs.is_csc():
+        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")       # prod.rs:258
+    if len(rhs_cols) != len(out_cols):
+        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:257
+    for r, o in zip(rhs_cols, out_cols):
+        mul_acc_mat_vec_csc(lhs, r, o, stream)
+
+
 def csmat_mul_dense(mat, rhs, stream=None):
-    """`&CsMat * &Array2` (csmat.rs:1989-2048) for a CSR lhs: fresh zero result; >= 8 columns use the
+    """`&CsMat * &Array2` (csmat.rs:1989-2048): fresh zero result; a CSC lhs is converted once on the device; >= 8 columns use the
     row-major kernel, fewer go column by column like csr_mulacc_dense_colmaj (prod.rs:274-298) —
     here through one strided pass of the same kernel, the result stays row-major."""
+    if mat.is_csc():                     # (CSC, _) arms of the dispatch, csmat.rs:2026-2045: the same product on the CSR form
+        if mat.cols() != rhs.rows:
+            raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
+        mat = _csr_of(mat)
     out = DeviceMat(mat.rows(), rhs.cols, DeviceVec(mat.rows() * rhs.cols))
     check(lib.sprs_hip_spmm_rowmaj_f64(mat._h, C.c_void_p(rhs.vec.ptr), rhs.rows, rhs.cols, rhs.cols,
                                        C.c_void_p(out.vec.ptr), out.rows, out.cols, 0, _stream_ptr(stream)))

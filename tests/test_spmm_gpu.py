@@ -51,6 +51,48 @@ def test_golden_mul_csr_dense_rowmaj(hip, golden, idx, ptr):
         assert np.all(np.abs(res.to_host() - 2 * exp) <= 2 * golden[ek]["epsilon"] + 1e-12)
 
 
+def test_golden_mul_csc_dense(hip, golden):
+    """prod.rs:545-597: mul_csc_dense_rowmaj, mul_csc_dense_colmaj, mul_csr_dense_colmaj — mat1 (CSC / CSR) * mat_dense1 in both
+    layouts, the explicit kernels and `&a * &b`; and the (CSC, cols < 8) / (CSC, cols >= 8) arms of the dispatch on wider data"""
+    from sprs_amd import prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec, CSC
+    exp = np.array(golden["mat1_times_mat_dense1"]["rows"])
+    dense = np.array(golden["mat_dense1"])
+    g = golden["mat1_csc"]
+    u = lambda v: np.array(v, dtype=np.uint64)
+    a_csc = DeviceCsMat.from_host(tuple(g["shape"]), u(g["indptr"]), u(g["indices"]), np.array(g["data"]), storage=CSC)
+    a_csr = DeviceCsMat.from_host(*as_csr(golden["mat1"], np.uint64, np.uint64))
+    b = prod.DeviceMat.from_host(dense)
+    res = prod.DeviceMat(5, 5)
+    prod.csc_mulacc_dense_rowmaj(a_csc, b, res)                           # mul_csc_dense_rowmaj
+    assert np.array_equal(res.to_host(), exp)
+    assert np.array_equal((a_csc * b).to_host(), exp)
+    for a, kernel in ((a_csc, prod.csc_mulacc_dense_colmaj), (a_csr, prod.csr_mulacc_dense_colmaj)):   # the two colmaj tests
+        cols_in = [DeviceVec.from_host(np.ascontiguousarray(dense[:, j])) for j in range(5)]
+        cols_out = [DeviceVec.zeros(5) for _ in range(5)]
+        kernel(a, cols_in, cols_out)
+        assert np.array_equal(np.stack([c.to_host() for c in cols_out], axis=1), exp)
+    with pytest.raises(hip.SprsHipError) as e:                            # assert!(lhs.is_csc(), "Storage mismatch")
+        prod.csc_mulacc_dense_rowmaj(a_csr, b, res)
+    assert e.value.status == hip._ffi.STORAGE_MISMATCH
+    with pytest.raises(hip.SprsHipError) as e:
+        prod.csc_mulacc_dense_rowmaj(a_csc, prod.DeviceMat(4, 5), res)
+    assert e.value.status == hip._ffi.DIM_MISMATCH
+    # wider: a random CSC matrix times 3 and 11 columns against the oracle on its CSR form
+    import scipy.sparse as sp
+    rng = np.random.default_rng(8)
+    m = sp.random(300, 200, density=0.05, random_state=4, format="csc")
+    m.sort_indices()
+    d = DeviceCsMat.from_host((300, 200), u(m.indptr), u(m.indices), m.data, storage=CSC)
+    mr = m.tocsr()
+    mr.sort_indices()
+    for k in (3, 11):
+        rhs = rng.standard_normal((200, k))
+        got = (d * prod.DeviceMat.from_host(rhs)).to_host()
+        ref = oracle_spmm((300, 200), u(mr.indptr), u(mr.indices), mr.data, rhs)
+        assert rel_err(got, ref) <= 1e-10
+
+
 @pytest.fixture(params=[0, 2048], ids=["chunks", "entry-order"])
 def long_row(request, hip):
     """the two summation modes of spmm.hip: every row by 512-entry chunks (default), or rows of <= L entries in the
