@@ -107,7 +107,8 @@ def case_spgemm(rng):
     B = random_csr(rng, k, n, idx, ptr)
     opts = dict(spgemm_mid=int(rng.choice([0, 600, 65536])), spgemm_heavy=int(rng.choice([1024, 4096, 131072])),
                 spgemm_winlog=int(rng.choice([16, 17, 18, 19])), spgemm_bucket=int(rng.integers(0, 2)),
-                spgemm_retain=int(rng.integers(0, 2)), spgemm_tokens=int(rng.choice([1, 2, 4])))
+                spgemm_retain=int(rng.integers(0, 2)), spgemm_tokens=int(rng.choice([1, 2, 4])),
+                spgemm_lane_order=int(rng.choice([0, 2])), spgemm_midwin=int(rng.choice([13, 14, 15, 16])))
     setopt(**opts)
     try:
         rs, rip, rix, rdt = oracle.mul_csr_csr(A[0], A[1], A[2], A[3], B[0], B[1], B[2], B[3])
@@ -299,10 +300,12 @@ CASES = (case_spmv, case_spgemm, case_spmm, case_gauss_seidel, case_dispatch, ca
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    only = os.environ.get("FUZZ_KINDS")                       # e.g. FUZZ_KINDS=spgemm,kept_plan
+    cases = [c for c in CASES if not only or c.__name__[5:] in only.split(",")]
     t0, counts, failures = time.time(), {}, []
     while time.time() - t0 < seconds:
         rng = np.random.default_rng(seed)
-        fn = CASES[seed % len(CASES)]
+        fn = cases[seed % len(cases)]
         try:
             ok, what = fn(rng)
         except Exception as e:                                # a status the oracle does not mirror is a finding too

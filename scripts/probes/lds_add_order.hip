@@ -1,0 +1,96 @@
+// Hardware probe (developer tool, not part of the library): in which order does the LDS apply the lanes of ONE
+// ds_add_f64 wave instruction that hit the same address?  Floating-point adds do not commute across three operands, so the
+// order is observable: every trial lets the 64 lanes of a wave add values of wildly different magnitude into a few LDS
+// doubles with a single atomic instruction and compares the bits with a host loop that adds them in ascending lane order
+// (and, for the record, in descending order).  usage: lds_add_order.out [trials]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+template <int WITH_RETURN>
+__global__ __launch_bounds__(64) void probe_kernel(const double *__restrict__ v, const uint32_t *__restrict__ slot,
+                                                  const unsigned long long *__restrict__ active, double *__restrict__ out,
+                                                  int nslots) {
+    __shared__ double acc[64];
+    const uint32_t lane = threadIdx.x;
+    const size_t t = blockIdx.x;
+    acc[lane] = 0.0;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const bool on = (active[t] >> lane) & 1ull;
+    const double x = v[t * 64 + lane];
+    const uint32_t s = slot[t * 64 + lane];
+    double r = 0.0;
+    if (on) {
+        if constexpr (WITH_RETURN) r = atomicAdd(&acc[s], x);
+        else atomicAdd(&acc[s], x);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (WITH_RETURN && r == 12345.678) out[0] = r;     // keep the returning form alive
+    if ((int)lane < nslots) out[t * 64 + lane] = acc[lane];
+}
+
+static uint64_t sm64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int main(int argc, char **argv) {
+    const size_t trials = argc > 1 ? strtoull(argv[1], nullptr, 10) : 200000;
+    for (int with_return = 0; with_return < 2; ++with_return)
+    for (int nslots : {1, 2, 3, 8, 33, 64}) {
+        std::vector<double> v(trials * 64), ref_up(trials * 64), ref_dn(trials * 64), got(trials * 64);
+        std::vector<uint32_t> slot(trials * 64);
+        std::vector<unsigned long long> act(trials);
+        uint64_t seed = 1234 + nslots * 77 + with_return;
+        for (size_t t = 0; t < trials; ++t) {
+            act[t] = (t % 3 == 0) ? ~0ull : sm64(seed) | sm64(seed);
+            for (int l = 0; l < 64; ++l) {
+                const uint64_t h = sm64(seed);
+                const double m = 0.5 + (double)(h >> 11) * (1.0 / 9007199254740992.0);
+                const int e = (int)(sm64(seed) % 41) - 20;
+                v[t * 64 + l] = ((h & 1) ? -m : m) * __builtin_ldexp(1.0, e);
+                slot[t * 64 + l] = (uint32_t)(sm64(seed) % (uint64_t)nslots);
+            }
+            for (int s = 0; s < 64; ++s) ref_up[t * 64 + s] = ref_dn[t * 64 + s] = 0.0;
+            for (int l = 0; l < 64; ++l)
+                if ((act[t] >> l) & 1) ref_up[t * 64 + slot[t * 64 + l]] += v[t * 64 + l];
+            for (int l = 63; l >= 0; --l)
+                if ((act[t] >> l) & 1) ref_dn[t * 64 + slot[t * 64 + l]] += v[t * 64 + l];
+        }
+        double *dv, *dout;
+        uint32_t *dslot;
+        unsigned long long *dact;
+        hipMalloc(&dv, v.size() * 8);
+        hipMalloc(&dout, v.size() * 8);
+        hipMalloc(&dslot, slot.size() * 4);
+        hipMalloc(&dact, act.size() * 8);
+        hipMemcpy(dv, v.data(), v.size() * 8, hipMemcpyHostToDevice);
+        hipMemcpy(dslot, slot.data(), slot.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dact, act.data(), act.size() * 8, hipMemcpyHostToDevice);
+        hipMemset(dout, 0, v.size() * 8);
+        if (with_return) hipLaunchKernelGGL(probe_kernel<1>, dim3((unsigned)trials), dim3(64), 0, nullptr, dv, dslot, dact, dout, nslots);
+        else hipLaunchKernelGGL(probe_kernel<0>, dim3((unsigned)trials), dim3(64), 0, nullptr, dv, dslot, dact, dout, nslots);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
+        hipMemcpy(got.data(), dout, v.size() * 8, hipMemcpyDeviceToHost);
+        size_t bad_up = 0, bad_dn = 0, sens = 0, n = 0;
+        for (size_t t = 0; t < trials; ++t)
+            for (int s = 0; s < nslots; ++s) {
+                const size_t i = t * 64 + s;
+                ++n;
+                if (memcmp(&ref_up[i], &ref_dn[i], 8)) ++sens;
+                if (memcmp(&got[i], &ref_up[i], 8)) ++bad_up;
+                if (memcmp(&got[i], &ref_dn[i], 8)) ++bad_dn;
+            }
+        printf("{\"probe\": \"lds_add_f64_lane_order\", \"returning\": %d, \"slots\": %d, \"sums\": %zu, \"order_sensitive\": %zu, "
+               "\"differ_from_ascending\": %zu, \"differ_from_descending\": %zu}\n", with_return, nslots, n, sens, bad_up, bad_dn);
+        hipFree(dv); hipFree(dout); hipFree(dslot); hipFree(dact);
+    }
+    return 0;
+}

@@ -76,9 +76,10 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_bucket, 1, 0, 1, 0)        /* column-bucket table of B instead of binary searches (A/B) */                           \
     X(spgemm_prof, 0, 0, 1, 1)          /* print the time of the numeric tasks by class and the longest ones */                   \
     X(spgemm_tokens, 1, 1, 4, 0)        /* token chains of the workgroup kernel's ordered adds: 1, 2 or 4 */                      \
+    X(spgemm_lane_order, 0, 0, 2, 0)    /* products of one wave instruction into the LDS accumulators: 0 auto = ONE ds_add_f64 when the device passes the lane-order probe (same-address lanes applied in ascending lane order), else one instruction per k-run; 2 always per k-run (A/B); same bits either way */ \
     X(spgemm_overlap, 0, 0, 1, 0)       /* wave kernels on a second stream beside the large-row kernel */                         \
     X(spgemm_midwin_sym, 16, 14, 16, 0) /* log2 of the window of the wave-per-row COUNTING kernel */                              \
-    X(spgemm_midwin, 14, 13, 14, 0)     /* log2 of the column window of the wave-per-row kernel */                                \
+    X(spgemm_midwin, 14, 13, 16, 0)     /* log2 of the column window of the wave-per-row kernel (measured on config 5: 2^14 and 2^15 equal, 2^16 slower — 10 waves per CU, profiles/r10d) */                                \
     X(spgemm_mid, 65536, 0, 1ll << 31, 0) /* rows of <= 64 k's and at most this many products run one wave per row (0: none) */   \
     X(spgemm_ordered, 1, 0, 1, 0)       /* 1: products are added in the reference's order (values bit-identical to sprs'); 0: the waves of a large-row workgroup add as they arrive (LDS atomics: same products, rounding-level differences, not reproducible run to run; ~20 % faster kernel) */ \
     X(spgemm_debug, 0, 0, 3, 1)         /* TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission */ \

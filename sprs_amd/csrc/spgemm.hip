@@ -35,6 +35,7 @@
 #include "scan.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 namespace sprs_hip {
@@ -91,6 +92,17 @@ struct CsrView {
     // binary searches, ~20 dependent loads per (row, window) — into two independent loads.
     const uint32_t *bucket;
     uint64_t nb;
+    // plan-owned copies of the right operand's entries for the window kernels (they are bound by the bytes they pull through
+    // the fabric, not by instructions: profiles/r10b): the columns as 32-bit numbers (b_cols < 2^32) for the counting walks —
+    // half the bytes of a usize index — and one 16-byte record {column, value} per entry for the value walks — one load
+    // and ONE cache line per short run instead of two.  Null in views that do not come from a plan.
+    const uint32_t *col32;
+    const struct BRec *pack;
+};
+
+struct alignas(16) BRec {
+    uint32_t col, pad;
+    double val;
 };
 
 constexpr int BUCKET_LOG2 = 11;   // 2048 columns = one superblock of the LDS bitmap: pass and window bounds are free
@@ -138,6 +150,25 @@ __global__ __launch_bounds__(256) void build_bucket_kernel(const PTR *__restrict
         }
         const int64_t lastb = e > s ? (int64_t)((uint64_t)indices[e - 1] >> BUCKET_LOG2) : -1;
         for (uint64_t bb = (uint64_t)(lastb + 1) + lane; bb < nb; bb += 64) t[bb] = (uint32_t)(e - s);
+    }
+}
+
+template <typename IDX>
+__global__ __launch_bounds__(256) void pack_cols_kernel(const IDX *__restrict__ indices, uint64_t nnz, uint32_t *__restrict__ col32) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) col32[p] = (uint32_t)indices[p];
+}
+
+template <typename IDX>
+__global__ __launch_bounds__(256) void pack_entries_kernel(const IDX *__restrict__ indices, const double *__restrict__ data, uint64_t nnz,
+                                                           BRec *__restrict__ pack) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
+        BRec r;
+        r.col = (uint32_t)indices[p];
+        r.pad = 0;
+        r.val = data[p];
+        pack[p] = r;
     }
 }
 
@@ -559,8 +590,8 @@ struct Batch {
     bool val[LG_U];
 };
 
-template <int K_CAP, bool VALUES, typename IDX>
-__device__ __forceinline__ void batch_load(Batch &bt, const IDX *__restrict__ b_indices, const double *__restrict__ b_data,
+template <int K_CAP, bool VALUES>
+__device__ __forceinline__ void batch_load(Batch &bt, const uint32_t *__restrict__ b_col32, const BRec *__restrict__ b_pack,
                                            uint64_t wlo, uint32_t gtot, uint32_t U, uint32_t b, const uint64_t *kS,
                                            const uint32_t *kP, const double *kA) {
     const uint32_t t0 = b * (64 * U) + (threadIdx.x & (WAVE - 1));
@@ -584,9 +615,17 @@ __device__ __forceinline__ void batch_load(Batch &bt, const IDX *__restrict__ b_
     double bv[LG_U];
 #pragma unroll
     for (int u = 0; u < LG_U; ++u) {           // all loads of the batch are independent
-        bt.cc[u] = bt.val[u] ? (uint32_t)((uint64_t)b_indices[pos[u]] - wlo) : 0u;
+        bt.cc[u] = 0u;
         bv[u] = 0.0;
-        if constexpr (VALUES) bv[u] = bt.val[u] ? b_data[pos[u]] : 0.0;
+        if constexpr (VALUES) {                // one 16-byte record per entry
+            if (bt.val[u]) {
+                const BRec rec = b_pack[pos[u]];
+                bt.cc[u] = rec.col - (uint32_t)wlo;
+                bv[u] = rec.val;
+            }
+        } else {
+            if (bt.val[u]) bt.cc[u] = b_col32[pos[u]] - (uint32_t)wlo;
+        }
     }
 #pragma unroll
     for (int u = 0; u < LG_U; ++u) bt.pr[u] = av[u] * bv[u];
@@ -598,15 +637,15 @@ __device__ __forceinline__ void batch_bits(const Batch &bt, uint32_t *bm32) {
         if (bt.val[u]) atomicOr(&bm32[bt.cc[u] >> 5], 1u << (bt.cc[u] & 31));   // little endian: bit c & 63 of word c >> 6
 }
 
-template <int K_CAP, typename IDX>
-__device__ __forceinline__ void walk_bits(const IDX *__restrict__ b_indices, uint64_t wlo, uint32_t gtot, const uint64_t *kS,
+template <int K_CAP>
+__device__ __forceinline__ void walk_bits(const uint32_t *__restrict__ b_col32, uint64_t wlo, uint32_t gtot, const uint64_t *kS,
                                           const uint32_t *kP, uint32_t *bm32) {
     const uint32_t wave = threadIdx.x / WAVE;
     const uint32_t U = batch_u(gtot);
     const uint32_t nbatch = (gtot + 64 * U - 1) / (64 * U);
     for (uint32_t b = wave; b < nbatch; b += LG_WAVES) {
         Batch bt;
-        batch_load<K_CAP, false>(bt, b_indices, (const double *)nullptr, wlo, gtot, U, b, kS, kP, (const double *)nullptr);
+        batch_load<K_CAP, false>(bt, b_col32, (const BRec *)nullptr, wlo, gtot, U, b, kS, kP, (const double *)nullptr);
         batch_bits(bt, bm32);
     }
 }
@@ -678,7 +717,7 @@ constexpr int MID_BLOCK = 128;
 constexpr int MID_WAVES = MID_BLOCK / WAVE;
 constexpr int MID_ACC = 512;                      // accumulators of one pass
 constexpr int MID_K = 64;                         // k's per row: one per lane
-constexpr int MID_KEEP = 4;                       // wave instructions of a window that stay in registers
+constexpr int MID_KEEP = 8;                       // wave instructions of a chunk: what a segment of <= 512 entries keeps in registers from the bit pass to the adds
 
 // inclusive scan over the 64 lanes without the LDS: four row_shr steps inside the rows of 16 lanes, then row_bcast 15 and 31
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
@@ -701,8 +740,54 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
 #endif
 }
 
+// inclusive MAX scan over the 64 lanes (same DPP ladder as the sum; identity 0, operands are small non-negative numbers)
+__device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
+#ifdef SPRS_HIP_EMU
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, WAVE);
+        if (lane >= (uint32_t)off && o > v) v = o;
+    }
+    return v;
+#else
+    int x = (int)v;
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));     // row_shr:1 (zeros shifted in)
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));     // row_shr:2
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));     // row_shr:4
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));     // row_shr:8
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));    // row_bcast:15 into rows 1 and 3
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));    // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+#endif
+}
+
+// The products of one wave instruction into their accumulators.  The lanes hold 64 CONSECUTIVE positions of the expansion
+// (k ascending with the lane), so lanes that meet in one accumulator must be applied in ascending lane order.
+// lane_order = true: ONE ds_add_f64 — the LDS applies the lanes of an atomic instruction that hit one address in ascending
+// lane order (measured on gfx950: scripts/probes/lds_add_order.hip, 2.2e7 sums of which 2.2e6 order-sensitive, every one equal
+// to the ascending-lane sum; the library repeats a short form of that probe once per device, lds_lane_order_ok(), and falls
+// back to one instruction per k-run when it does not hold).
+__device__ __forceinline__ void add_lanes(bool val, uint32_t own, uint32_t slot, double pr, double *acc, bool lane_order) {
+    if (lane_order) {
+#ifdef SPRS_HIP_EMU
+        wave_sync_lds();      // the CPU emulator runs a lane until its next collective: without this a lane would issue the adds of
+                              // several wave instructions before its neighbours issue their first (the hardware is instruction-major)
+#endif
+        if (val) atomicAdd(&acc[slot], pr);                      // ds_add_f64, no return value
+    } else {
+        add_runs(val, own, slot, pr, acc, true);
+    }
+}
+
+// what a position of the expansion needs from its k: where the k's sub-range starts (as the offset that turns a flat
+// position into an entry of B) and a_ik — one 16-byte LDS read
+struct alignas(16) KRec {
+    uint64_t base;
+    double a;
+};
+
 template <typename IDX, typename PTR, bool NUMERIC, int MID_WL>
-__global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t b_cols,
+__global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t b_cols,
                                                              const uint64_t *__restrict__ mid_list, uint64_t n_mid,
                                                              const uint64_t *__restrict__ task_row,
                                                              uint64_t *__restrict__ count,        // symbolic: out
@@ -710,7 +795,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                                                              IDX *__restrict__ c_indices, double *__restrict__ c_data,
                                                              unsigned long long *__restrict__ prof,
                                                              const uint64_t *__restrict__ ub_dbg,
-                                                             unsigned int *__restrict__ next_row) {
+                                                             unsigned int *__restrict__ next_row, uint32_t flags) {
     // The phase timers of option spgemm_prof (developer builds) live in LDS and are touched only when prof is set: kept in
     // registers (ten 64-bit values per lane) they cost the numeric kernel 92 bytes of scratch per lane.  The release library
     // compiles them out.
@@ -728,28 +813,28 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             ph[8] = now;
         }
     };
-    constexpr int MID_WORDS = 1 << (MID_WL - 6);      // bitmap words of a window; lane l takes words l, l + 64, ...
-    constexpr int WPL = MID_WORDS / WAVE;             // words per lane (2^13 columns: 2, 2^14: 4, 2^15: 8)
-    static_assert(MID_WL >= 13 && (MID_WL <= 14 || (!NUMERIC && MID_WL <= 16)), "window of the wave-per-row kernel");   // (numeric: LDS / registers for 20 waves per CU; the counting kernel has no accumulators and takes 2^16)
+    constexpr int MID_WORDS = 1 << (MID_WL - 6);      // bitmap words of a window; lane l owns the WPL CONSECUTIVE words from l * WPL
+    constexpr int WPL = MID_WORDS / WAVE;             // words per lane (2^13 columns: 2, 2^14: 4, 2^16: 16)
+    static_assert(MID_WL >= 13 && MID_WL <= 16, "window of the wave-per-row kernel");   // (the owner | column pairs are packed 16 + 16 bits)
     __shared__ unsigned long long bm_s[MID_WAVES][MID_WORDS];
-    __shared__ uint16_t sub_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_WORDS : 1];
+    __shared__ uint16_t sub_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_WORDS : 4];
     __shared__ double acc_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_ACC : 1];
-    __shared__ uint64_t kS_s[MID_WAVES][MID_K];
-    __shared__ uint32_t kP_s[MID_WAVES][MID_K + 1];
-    __shared__ double kA_s[NUMERIC ? MID_WAVES : 1][NUMERIC ? MID_K : 1];
+    __shared__ KRec krec_s[MID_WAVES][MID_K];
+    __shared__ uint32_t mark_s[MID_WAVES][MID_KEEP * WAVE / 4];      // one-byte marks: which k starts at a position of the current chunk
     const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     unsigned long long *bm = bm_s[wave];
     uint32_t *bm32 = (uint32_t *)bm;
     uint16_t *sub = sub_s[NUMERIC ? wave : 0];
     double *acc = acc_s[NUMERIC ? wave : 0];
-    uint64_t *kS = kS_s[wave];
-    uint32_t *kP = kP_s[wave];
-    double *kA = kA_s[NUMERIC ? wave : 0];
+    KRec *krec = krec_s[wave];
+    uint32_t *mark32 = mark_s[wave];
+    uint8_t *mark8 = (uint8_t *)mark32;
     const bool values = NUMERIC && c_data != nullptr;
+    const bool lane_order = (flags & 1u) != 0;
     uint64_t nwin = (b_cols + (1ull << MID_WL) - 1) >> MID_WL;
     if (nwin == 0) nwin = 1;
 #pragma unroll
-    for (int i = 0; i < WPL; ++i) bm[i * WAVE + lane] = 0;
+    for (int i = 0; i < WPL; ++i) bm[lane * WPL + i] = 0;
     wave_sync_lds();
     // The waves draw rows from a counter (the list is sorted by cost, costliest first): which wave takes which row changes
     // nothing in the result — every row is computed by one wave on its own, into its own piece of C.
@@ -806,13 +891,13 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)winc, WAVE - 1);
             mark(1);
             if (wtotal == 0) continue;                                // wave-uniform: nothing of the row in this window
-            // A window of more entries than the registers keep (the dense low columns of a power-law row) is taken bucket by
-            // bucket, 2048 columns at a time: its outputs then fit one pass of accumulators nearly always, instead of every
-            // pass walking the whole window again (first version: 74 of 152 s of wave time, profiles/r02y).
-            // 1, 2, 4 or 8 segments of whole buckets, about 500 entries each or fewer (a segment of more outputs than
-            // accumulators is walked once per pass: rare, and bounded by the bucket)
-            const uint32_t nseg = !NUMERIC || wtotal <= (uint32_t)MID_ACC ? 1u : wtotal <= 2u * MID_ACC ? 2u : wtotal <= 4u * MID_ACC ? 4u
-                                                                                                          : (1u << (MID_WL - BUCKET_LOG2));
+            // A window of more entries than one pass of accumulators takes (the dense low columns of a power-law row) is cut into
+            // 2, 4 or 8 segments of whole buckets (2048 columns), about 500 entries each or fewer: its outputs then fit one pass
+            // nearly always, instead of every pass walking the whole window again (first version: 74 of 152 s of wave time,
+            // profiles/r02y).  (A segment of more outputs than accumulators is walked once per pass: rare, bounded by the bucket.)
+            uint32_t nseg = 1;
+            if (NUMERIC)
+                while (nseg < (1u << (MID_WL - BUCKET_LOG2)) && wtotal > nseg * (uint32_t)MID_ACC) nseg <<= 1;
             const uint32_t SEG_COLS = (1u << MID_WL) / nseg;
             uint32_t seg_s = win_s, seg_nxt = win_e;
             if (nseg > 1 && has) seg_nxt = edge(win_s, win_e, win_lo + SEG_COLS);
@@ -827,97 +912,102 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
             const uint32_t inc = nseg == 1 ? winc : wave_incl_scan_u32(len);
             const uint32_t total = nseg == 1 ? wtotal : (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             if (total == 0) continue;                                 // wave-uniform
-            kP[lane] = inc - len;                                     // lanes without a k: = total (the search never passes them)
-            if (lane == WAVE - 1) kP[MID_K] = total;
-            kS[lane] = rs + ws;
-            if (values) kA[lane] = rav;
+            const uint32_t excl = inc - len;                          // flat position of my k's first entry
+            {
+                KRec rec;
+                rec.base = rs + ws - excl;                            // flat position p of my k lives at entry base + p of B
+                rec.a = rav;
+                krec[lane] = rec;
+            }
             wave_sync_lds();
             const uint32_t nb = (total + WAVE - 1) / WAVE;
             const bool keep = values && nb <= (uint32_t)MID_KEEP;     // wave-uniform
-            uint32_t kco[MID_KEEP];                                   // column offset (< 2^15) | owner << 16; 0xFFFFFFFF: no entry
+            uint32_t kco[MID_KEEP];                                   // column offset (< 2^16) | owner << 16; 0xFFFFFFFF: no entry
             double kpr[MID_KEEP];
-            // MID_KEEP wave instructions of the expansion at once (owner, column, product): the loads of all of them are in
-            // flight together — one memory round trip per MID_KEEP * 64 entries, not one per 64
-            auto load_batches = [&](uint32_t b0, bool with_value) {
+            uint32_t carry = 0;                                       // owner + 1 of the position before the chunk (wave-uniform)
+            // One CHUNK = MID_KEEP wave instructions = 256 consecutive positions of the expansion (k ascending, columns ascending
+            // inside a k: the reference's order).  Owners: every k that starts inside the chunk leaves its number at its first
+            // position (one byte), a max-scan over the positions spreads it over the run — one LDS read and six DPP steps per
+            // instruction instead of a search per position.  The loads of the whole chunk are in flight together.
+            auto load_chunk = [&](uint32_t c0, bool with_value) {
+#pragma unroll
+                for (int i = 0; i < MID_KEEP / 4; ++i) mark32[i * WAVE + lane] = 0;
+                wave_sync_lds();
+                if (len != 0 && excl - c0 < (uint32_t)(MID_KEEP * WAVE)) mark8[excl - c0] = (uint8_t)(lane + 1);
+                wave_sync_lds();
                 uint64_t pos[MID_KEEP];
                 uint32_t own[MID_KEEP];
-                bool valid[MID_KEEP];
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b) {
-                    valid[b] = false;
                     own[b] = 0;
-                    pos[b] = 0;
-                    if (b0 + (uint32_t)b < nb) {                      // wave-uniform: a batch that does not exist costs a branch
-                        const uint32_t tpos = (b0 + (uint32_t)b) * WAVE + lane;
-                        valid[b] = tpos < total;
-                        if (nk <= 16) {
-                            // few k's (most rows): count the k's that end at or before the position — scalar compares, no LDS
-                            for (uint32_t j = 0; j + 1 < nk; ++j)
-                                own[b] += tpos >= (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)j) ? 1u : 0u;
-                        } else if (valid[b]) {
-                            own[b] = flat_owner<MID_K>(kP, tpos);
-                        }
-                        if (valid[b]) pos[b] = kS[own[b]] + (uint64_t)(tpos - kP[own[b]]);
+                    pos[b] = ~0ull;                                   // no entry
+                    if (c0 + (uint32_t)(b * WAVE) < total) {          // wave-uniform: an instruction that does not exist costs a branch
+                        const uint32_t tpos = c0 + (uint32_t)(b * WAVE) + lane;
+                        uint32_t o = wave_incl_max_u32((uint32_t)mark8[b * WAVE + lane]);
+                        o = o > carry ? o : carry;
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)o, WAVE - 1);
+                        own[b] = o - 1u;                              // (position 0 always starts a k: o >= 1)
+                        if (tpos < total) pos[b] = krec[own[b]].base + tpos;
                     }
                 }
-                uint32_t cc[MID_KEEP];
                 double bv[MID_KEEP];
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b) {
-                    cc[b] = 0;
+                    kco[b] = 0xFFFFFFFFu;
                     bv[b] = 0.0;
-                    if (b0 + (uint32_t)b < nb) {                      // wave-uniform
-                        cc[b] = valid[b] ? (uint32_t)((uint64_t)B.indices[pos[b]] - wlo) : 0u;
-                        bv[b] = valid[b] && with_value ? B.data[pos[b]] : 0.0;
+                    if (c0 + (uint32_t)(b * WAVE) < total) {          // wave-uniform
+                        if (with_value) {                             // wave-uniform: one 16-byte record per entry
+                            if (pos[b] != ~0ull) {
+                                const BRec rec = B.pack[pos[b]];
+                                kco[b] = (rec.col - (uint32_t)wlo) | (own[b] << 16);
+                                bv[b] = rec.val;
+                            }
+                        } else if (pos[b] != ~0ull) {
+                            kco[b] = (B.col32[pos[b]] - (uint32_t)wlo) | (own[b] << 16);
+                        }
                     }
                 }
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b) {
-                    kco[b] = 0xFFFFFFFFu;
                     kpr[b] = 0.0;
-                    if (b0 + (uint32_t)b < nb) {                      // wave-uniform
-                        kco[b] = valid[b] ? cc[b] | (own[b] << 16) : 0xFFFFFFFFu;
-                        kpr[b] = valid[b] && with_value ? kA[own[b]] * bv[b] : 0.0;
-                    }
+                    if (with_value && c0 + (uint32_t)(b * WAVE) < total) kpr[b] = krec[own[b]].a * bv[b];   // wave-uniform
                 }
             };
-            auto set_bits = [&](uint32_t b0) {
+            auto set_bits = [&](uint32_t c0) {
 #pragma unroll
                 for (int b = 0; b < MID_KEEP; ++b)
-                    if (b0 + (uint32_t)b < nb)                        // wave-uniform
+                    if (c0 + (uint32_t)(b * WAVE) < total)            // wave-uniform
                         if (kco[b] != 0xFFFFFFFFu) atomicOr(&bm32[(kco[b] & 0xFFFFu) >> 5], 1u << (kco[b] & 31));
             };
             // ---- bit pass ----
             if (keep) {
-                load_batches(0, true);
+                load_chunk(0, true);
                 set_bits(0);
             } else {
-                for (uint32_t b0 = 0; b0 < nb; b0 += MID_KEEP) {
-                    load_batches(b0, false);
-                    set_bits(b0);
+                for (uint32_t c0 = 0; c0 < total; c0 += MID_KEEP * WAVE) {
+                    load_chunk(c0, false);
+                    set_bits(c0);
                 }
             }
             wave_sync_lds();
             mark(2);
-            uint32_t pc[WPL];
+            // ---- popcount prefix: outputs before each word; a lane's words are consecutive: ONE wave scan ----
+            uint32_t run = 0, pre[WPL];
 #pragma unroll
-            for (int i = 0; i < WPL; ++i) pc[i] = (uint32_t)__popcll(bm[i * WAVE + lane]);
+            for (int i = 0; i < WPL; ++i) {
+                pre[i] = run;
+                run += (uint32_t)__popcll(bm[lane * WPL + i]);
+            }
             if constexpr (!NUMERIC) {
-#pragma unroll
-                for (int i = 0; i < WPL; ++i) fresh += pc[i];
+                fresh += run;
             } else {
-                // ---- popcount prefix: outputs before each word (words i * 64 + lane: one wave scan per i) ----
-                uint32_t wtot = 0;
+                const uint32_t in = wave_incl_scan_u32(run);
+                const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)in, WAVE - 1);
 #pragma unroll
-                for (int i = 0; i < WPL; ++i) {
-                    const uint32_t in = wave_incl_scan_u32(pc[i]);
-                    sub[i * WAVE + lane] = (uint16_t)(wtot + in - pc[i]);
-                    wtot += (uint32_t)__builtin_amdgcn_readlane((int)in, WAVE - 1);
-                }
+                for (int i = 0; i < WPL; ++i) sub[lane * WPL + i] = (uint16_t)(in - run + pre[i]);
                 wave_sync_lds();
                 mark(3);
-                mark(4);
-                // ---- values: passes of MID_ACC outputs; every pass walks the window's entries and takes its own ----
+                // ---- values: passes of MID_ACC outputs; every pass walks the segment's entries and takes its own ----
                 // The indices come out sorted for free — the rank of a column IS its place in the row — and are written entry by
                 // entry in the first pass (several entries of one column write the same value to the same place).
                 for (uint32_t p0 = 0; (values || c_indices) && p0 < wtot; p0 += MID_ACC) {
@@ -929,23 +1019,24 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                         const uint32_t word = cc >> 6;
                         return (uint32_t)sub[word] + (uint32_t)__popcll(bm[word] & ((1ull << (cc & 63)) - 1ull)) - p0;
                     };
-                    auto add_batches = [&](uint32_t b0) {
+                    auto add_chunk = [&](uint32_t c0) {
 #pragma unroll
                         for (int b = 0; b < MID_KEEP; ++b) {
-                            if (b0 + (uint32_t)b < nb) {                  // wave-uniform
+                            if (c0 + (uint32_t)(b * WAVE) < total) {  // wave-uniform
                                 const bool kv = kco[b] != 0xFFFFFFFFu;
                                 const uint32_t slot = kv ? slot_of(kco[b] & 0xFFFFu) : 0xFFFFFFFFu;
                                 if (kv && c_indices && p0 == 0) c_indices[out + slot] = (IDX)(wlo + (kco[b] & 0xFFFFu));
-                                if (values) add_runs(kv && slot < n_out, kco[b] >> 16, slot, kpr[b], acc, true);
+                                if (values) add_lanes(kv && slot < n_out, kco[b] >> 16, slot, kpr[b], acc, lane_order);
                             }
                         }
                     };
                     if (keep) {
-                        add_batches(0);
+                        add_chunk(0);
                     } else {
-                        for (uint32_t b0 = 0; b0 < nb; b0 += MID_KEEP) {
-                            load_batches(b0, values);
-                            add_batches(b0);
+                        carry = 0;
+                        for (uint32_t c0 = 0; c0 < total; c0 += MID_KEEP * WAVE) {
+                            load_chunk(c0, values);
+                            add_chunk(c0);
                         }
                     }
                     wave_sync_lds();
@@ -956,7 +1047,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
                 mark(5);
             }
 #pragma unroll
-            for (int i = 0; i < WPL; ++i) bm[i * WAVE + lane] = 0;
+            for (int i = 0; i < WPL; ++i) bm[lane * WPL + i] = 0;
             wave_sync_lds();
             }   // segments of the window
         }
@@ -987,7 +1078,7 @@ __global__ __launch_bounds__(MID_BLOCK, 5) void mid_rows_kernel(CsrView<IDX, PTR
 // still busy with set 1: the hand-overs (a completed ds_add, a token write, the next wave's poll) overlap NTOK deep.
 __device__ __forceinline__ void batch_add(const Batch &bt, uint32_t U, const unsigned long long *bm, const uint16_t *sub,
                                           const uint32_t *super, uint32_t base_rank, double *acc, uint32_t *token, uint32_t turn,
-                                          bool lds_atomic, uint32_t ntok) {
+                                          uint32_t lds_atomic, uint32_t ntok) {
     uint32_t slot[LG_U];
 #pragma unroll
     for (int u = 0; u < LG_U; ++u) {
@@ -1003,24 +1094,28 @@ __device__ __forceinline__ void batch_add(const Batch &bt, uint32_t U, const uns
         token_wait(token + tk, turn);
 #pragma unroll
         for (int u = 0; u < LG_U; ++u)
-            if ((uint32_t)u < U) add_runs(bt.val[u] && (slot[u] & (ntok - 1)) == tk, bt.own[u], slot[u], bt.pr[u], acc, lds_atomic);
+            if ((uint32_t)u < U) {
+                const bool mine = bt.val[u] && (slot[u] & (ntok - 1)) == tk;
+                if (lds_atomic == 2u) add_lanes(mine, bt.own[u], slot[u], bt.pr[u], acc, true);     // one ds_add_f64: the LDS applies the lanes in order
+                else add_runs(mine, bt.own[u], slot[u], bt.pr[u], acc, lds_atomic != 0u);
+            }
         token_pass(token + tk, turn + 1);       // (a real turn never is 0xFFFFFFFF: the token would have to wrap exactly there; see tok_base)
     }
 }
 
 // value walk of one staged group restricted to a pass; returns the number of batches (the token advances by it)
-template <int K_CAP, typename IDX>
-__device__ __forceinline__ uint32_t walk_values(const IDX *__restrict__ b_indices, const double *__restrict__ b_data, uint64_t wlo,
+template <int K_CAP>
+__device__ __forceinline__ uint32_t walk_values(const BRec *__restrict__ b_pack, uint64_t wlo,
                                                 uint32_t gtot, const uint64_t *kS, const uint32_t *kP, const double *kA,
                                                 const unsigned long long *bm, const uint16_t *sub, const uint32_t *super,
                                                 uint32_t base_rank, double *acc, uint32_t *token, uint32_t tok_base,
-                                                bool lds_atomic, uint32_t ntok) {
+                                                uint32_t lds_atomic, uint32_t ntok) {
     const uint32_t wave = threadIdx.x / WAVE;
     const uint32_t U = batch_u(gtot);
     const uint32_t nbatch = (gtot + 64 * U - 1) / (64 * U);
     for (uint32_t b = wave; b < nbatch; b += LG_WAVES) {
         Batch bt;
-        batch_load<K_CAP, true>(bt, b_indices, b_data, wlo, gtot, U, b, kS, kP, kA);
+        batch_load<K_CAP, true>(bt, (const uint32_t *)nullptr, b_pack, wlo, gtot, U, b, kS, kP, kA);
         batch_add(bt, U, bm, sub, super, base_rank, acc, token, tok_base == 0xFFFFFFFFu ? tok_base : tok_base + b, lds_atomic, ntok);
     }
     return nbatch;
@@ -1083,7 +1178,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
     const bool one_group = ae - as <= (uint64_t)K_CAP;
     const bool values = NUMERIC && c_data != nullptr;
-    const bool lds_atomic = (flags & 1u) != 0;
+    const uint32_t lds_atomic = (flags & 64u) ? 2u : (flags & 1u);       // how a wave instruction's products are added: 2 one ds_add_f64 (lane order), 1 one per k-run, 0 read-add-write per k-run (A/B)
     const bool retain_ok = values && (flags & 2u) != 0;
     const bool no_order = (flags & 4u) != 0;                        // option spgemm_ordered = 0 (supported: same products, unordered atomic adds)
     const bool no_emit = DEVTOOLS && (flags & 8u) != 0;             // timing experiment (option spgemm_debug & 2): WRONG results
@@ -1138,13 +1233,13 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
 #pragma unroll
                     for (int u = 0; u < LG_U; ++u) kept.val[u] = false;
                     if (wave * 64 * U < gtot) {
-                        batch_load<K_CAP, true>(kept, B.indices, B.data, wlo, gtot, U, wave, kS, kP, kA);
+                        batch_load<K_CAP, true>(kept, (const uint32_t *)nullptr, B.pack, wlo, gtot, U, wave, kS, kP, kA);
                         batch_bits(kept, (uint32_t *)bm);
                     }
                     continue;
                 }
             }
-            walk_bits<K_CAP>(B.indices, wlo, gtot, kS, kP, (uint32_t *)bm);
+            walk_bits<K_CAP>(B.col32, wlo, gtot, kS, kP, (uint32_t *)bm);
         }
         lds_barrier();
         mark(1);
@@ -1247,7 +1342,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                             gtot = stage_k_group<K_CAP>(A, B, kc, n, single ? wlo : plo, single ? whi : phi, single && nwin == 1,
                                                         kS, kP, kA, wt);
                         }
-                        const uint32_t nb_ = walk_values<K_CAP>(B.indices, B.data, wlo, gtot, kS, kP, kA, bm, sub, super, base_rank, acc,
+                        const uint32_t nb_ = walk_values<K_CAP>(B.pack, wlo, gtot, kS, kP, kA, bm, sub, super, base_rank, acc,
                                                                 token, no_order ? 0xFFFFFFFFu : tok_base, lds_atomic, ntok);
                         tok_base += nb_;
                     }
@@ -1338,7 +1433,7 @@ struct sprs_hip_spgemm_plan {
     uint64_t ntask_total = 0, n_small = 0, n_mid = 0, n_large = 0, n_tiny = 0, c_nnz = 0, nb = 0;
     int64_t winlog = 17, midwin = 14;
     uint32_t xcd_chunk = 0;        // how the launch deals the task list to the XCDs (task_of_block)
-    sprs_hip::DevBuf bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, mid_list, large_list, count, off, counters;
+    sprs_hip::DevBuf bcol32, bpack, bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, mid_list, large_list, count, off, counters;
 };
 
 namespace sprs_hip {
@@ -1347,7 +1442,7 @@ namespace {
 
 template <typename IDX, typename PTR>
 CsrView<IDX, PTR> view_of(const sprs_hip_csmat *m) {
-    return CsrView<IDX, PTR>{(const PTR *)m->indptr, (const IDX *)m->indices, m->data, nullptr, 0};
+    return CsrView<IDX, PTR>{(const PTR *)m->indptr, (const IDX *)m->indices, m->data, nullptr, 0, nullptr, nullptr};
 }
 
 // Option spgemm_overlap = 1: the wave kernels (hash rows, wave-per-row rows) run on a second stream beside the workgroup
@@ -1373,6 +1468,67 @@ AuxStream *aux_stream() {
     }
     return &a;
 }
+
+// ---- the lane-order probe -----------------------------------------------------------------------------------
+// add_lanes() relies on a property of the LDS that the ISA manual does not state: the lanes of ONE ds_add_f64 that hit the
+// same address are applied in ascending lane order.  Floating-point sums make the order observable, so the library checks it
+// once per device before trusting it: 256 waves add 64 values of very different magnitude into 1, 2, 3 or 8 accumulators with
+// a single instruction and the host compares the bits with the ascending-lane sums (scripts/probes/lds_add_order.hip is the
+// long form: 2.2e7 sums on an MI355X, none different).  A device that fails gets one instruction per k-run (add_runs).
+__global__ __launch_bounds__(WAVE) void lane_order_probe_kernel(const double *__restrict__ v, const uint32_t *__restrict__ slot,
+                                                                double *__restrict__ out) {
+    __shared__ double acc[8];
+    const uint32_t lane = threadIdx.x;
+    if (lane < 8) acc[lane] = 0.0;
+    wave_sync_lds();
+    atomicAdd(&acc[slot[blockIdx.x * WAVE + lane]], v[blockIdx.x * WAVE + lane]);
+    wave_sync_lds();
+    if (lane < 8) out[blockIdx.x * 8 + lane] = acc[lane];
+}
+
+bool lds_lane_order_ok() {
+    static std::mutex mu;
+    static std::unordered_map<int, bool> per_device;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    auto it = per_device.find(dev);
+    if (it != per_device.end()) return it->second;
+    constexpr int TRIALS = 256;
+    std::vector<double> v(TRIALS * WAVE), ref(TRIALS * 8, 0.0), got(TRIALS * 8, -1.0);
+    std::vector<uint32_t> slot(TRIALS * WAVE);
+    uint64_t s = 0x243F6A8885A308D3ull;
+    auto next = [&]() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    static const int NSLOT[4] = {1, 2, 3, 8};
+    for (int t = 0; t < TRIALS; ++t)
+        for (int l = 0; l < WAVE; ++l) {
+            const uint64_t h = next();
+            const double m = 0.5 + (double)(h >> 11) * (1.0 / 9007199254740992.0);
+            v[t * WAVE + l] = ((h & 1) ? -m : m) * (double)(1ull << (next() % 41)) / 1048576.0;    // magnitudes over 2^-20 .. 2^20
+            slot[t * WAVE + l] = (uint32_t)(next() % (uint64_t)NSLOT[t & 3]);
+            ref[t * 8 + slot[t * WAVE + l]] += v[t * WAVE + l];                                   // ascending lane order
+        }
+    bool ok = false;
+    DevBuf dv, ds, dout;
+    if (dv.alloc(v.size() * 8) == hipSuccess && ds.alloc(slot.size() * 4) == hipSuccess && dout.alloc(got.size() * 8) == hipSuccess &&
+        hipMemcpy(dv.p, v.data(), v.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(ds.p, slot.data(), slot.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(lane_order_probe_kernel, dim3(TRIALS), dim3(WAVE), 0, nullptr, dv.as<double>(), ds.as<uint32_t>(), dout.as<double>());
+        if (hipGetLastError() == hipSuccess && hipMemcpy(got.data(), dout.p, got.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            ok = memcmp(got.data(), ref.data(), got.size() * 8) == 0;
+    }
+    (void)hipGetLastError();
+    per_device[dev] = ok;
+    return ok;
+}
+
+// what the wave kernels are told about the adds (bit 0: one ds_add_f64 per wave instruction)
+uint32_t add_flags() { return options().spgemm_lane_order != 2 && lds_lane_order_ok() ? 1u : 0u; }
 
 // ---- symbolic phase: counts, offsets, task lists ---------------------------------------------------------
 template <typename IDX, typename PTR>
@@ -1418,6 +1574,17 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     }
     B.bucket = pl->nb ? pl->bucket.as<uint32_t>() : nullptr;
     B.nb = pl->nb;
+    // the columns of B as 32-bit numbers for the counting walks (4-byte handles already have them)
+    if (sizeof(IDX) == 4) {
+        B.col32 = (const uint32_t *)b->indices;
+    } else {
+        SPRS_TRY_HIP(pl->bcol32.alloc((b->nnz ? b->nnz : 1) * sizeof(uint32_t)));
+        if (b->nnz) {
+            hipLaunchKernelGGL((pack_cols_kernel<IDX>), dim3(2048), dim3(256), 0, stream, B.indices, b->nnz, pl->bcol32.as<uint32_t>());
+            SPRS_TRY_HIP(hipGetLastError());
+        }
+        B.col32 = pl->bcol32.as<uint32_t>();
+    }
 
     DevBuf is_tiny, is_small, is_mid, n_large_r, pos_tiny, pos_small, pos_mid, pos_large, large_key, mid_key, cls;
     SPRS_TRY_HIP(pl->ub.alloc(rows * 8));
@@ -1534,7 +1701,7 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, false, WL>), mid_grid(n_mid), dim3(MID_BLOCK), 0, wstream, A, B, b_cols, \
                        pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
                        (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr, (unsigned long long *)nullptr, (const uint64_t *)nullptr, \
-                       pl->counters.as<unsigned int>())
+                       pl->counters.as<unsigned int>(), 0u)
         SPRS_TRY_HIP(pl->counters.alloc(64));
         SPRS_TRY_HIP(hipMemsetAsync(pl->counters.p, 0, 64, wstream));
         // the counting kernel has no accumulators: windows of 2^16 columns (four times fewer window prologues per row)
@@ -1565,6 +1732,16 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     CsrView<IDX, PTR> A = view_of<IDX, PTR>(a), B = view_of<IDX, PTR>(b);
     B.bucket = pl->nb ? pl->bucket.as<uint32_t>() : nullptr;
     B.nb = pl->nb;
+    B.col32 = sizeof(IDX) == 4 ? (const uint32_t *)b->indices : pl->bcol32.as<uint32_t>();
+    if (values && (pl->n_mid || pl->n_large)) {
+        // {column, value} records of B for the value walks; rebuilt per call: the values of b may have changed since the plan was made
+        SPRS_TRY_HIP(pl->bpack.alloc((b->nnz ? b->nnz : 1) * sizeof(BRec)));
+        if (b->nnz) {
+            hipLaunchKernelGGL((pack_entries_kernel<IDX>), dim3(2048), dim3(256), 0, stream, B.indices, B.data, b->nnz, pl->bpack.as<BRec>());
+            SPRS_TRY_HIP(hipGetLastError());
+        }
+        B.pack = pl->bpack.as<BRec>();
+    }
     const uint64_t n_tiny = pl->n_tiny, n_small = pl->n_small, n_mid = pl->n_mid, n_large = pl->n_large;
     double *c_values = values ? c->data : nullptr;
     IDX *c_indices = indices ? (IDX *)c->indices : nullptr;
@@ -1587,7 +1764,8 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
         const bool unordered = options().spgemm_ordered == 0;
         const uint32_t flags = ((options().spgemm_lds_atomic || unordered) ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u) |
                                (unordered ? 4u : 0u) | ((uint32_t)options().spgemm_debug << 2) |
-                               ((options().spgemm_tokens >= 4 ? 2u : options().spgemm_tokens >= 2 ? 1u : 0u) << 4);
+                               ((options().spgemm_tokens >= 4 ? 2u : options().spgemm_tokens >= 2 ? 1u : 0u) << 4) |
+                               ((options().spgemm_lds_atomic || unordered) && add_flags() ? 64u : 0u);
 #define SPRS_LG_NUM(WL, OCC)                                                                                         \
     hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, true, OCC>), g, blk, 0, stream, A, B, pl->b_cols,            \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
@@ -1675,10 +1853,13 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, true, WL>), dim3((unsigned)g), dim3(MID_BLOCK), 0, wstream, A, B, pl->b_cols, \
                        pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
                        pl->off.as<uint64_t>(), c_indices, c_values, mprof.as<unsigned long long>(), pl->ub.as<uint64_t>(),   \
-                       pl->counters.as<unsigned int>() + 4)
+                       pl->counters.as<unsigned int>() + 4, wave_flags)
         SPRS_TRY_HIP(hipMemsetAsync(pl->counters.as<unsigned int>() + 4, 0, 4, wstream));
+        const uint32_t wave_flags = add_flags();
         switch (pl->midwin) {
             case 13: SPRS_MID_NUM(13); break;
+            case 15: SPRS_MID_NUM(15); break;
+            case 16: SPRS_MID_NUM(16); break;
             default: SPRS_MID_NUM(14); break;
         }
 #undef SPRS_MID_NUM
