@@ -78,17 +78,19 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_tokens, 1, 1, 4, 0)        /* token chains of the workgroup kernel's ordered adds: 1, 2 or 4 */                      \
     X(spgemm_lane_order, 0, 0, 2, 0)    /* products of one wave instruction into the LDS accumulators: 0 auto = ONE ds_add_f64 when the device passes the lane-order probe (same-address lanes applied in ascending lane order), else one instruction per k-run; 2 always per k-run (A/B); same bits either way */ \
     X(spgemm_overlap, 0, 0, 1, 0)       /* wave kernels on a second stream beside the large-row kernel */                         \
-    X(spgemm_midwin_sym, 16, 14, 16, 0) /* log2 of the window of the wave-per-row COUNTING kernel */                              \
-    X(spgemm_midwin, 14, 13, 16, 0)     /* log2 of the column window of the wave-per-row kernel (measured on config 5: 2^14 and 2^15 equal, 2^16 slower — 10 waves per CU, profiles/r10d) */                                \
+    X(spgemm_midwin_sym, 14, 14, 16, 0) /* log2 of the window of the wave-per-row COUNTING kernel: 14 or 16 */                        \
+    X(spgemm_mid_keep, 8, 4, 8, 0)      /* wave instructions per chunk of the wave-per-row kernel (loads in flight together; kept in registers through a segment): 4 or 8 */ \
+    X(spgemm_mid_keep_sym, 8, 8, 16, 0) /* the same for its counting twin: 8 or 16 */ \
+    X(spgemm_midwin, 15, 14, 15, 0)     /* log2 of the column window of the wave-per-row kernel: 14 or 15 (measured equal on config 5; 2^16 — 10 waves per CU — slower: profiles/r10d) */ \
     X(spgemm_mid, 65536, 0, 1ll << 31, 0) /* rows of <= 64 k's and at most this many products run one wave per row (0: none) */   \
     X(spgemm_ordered, 1, 0, 1, 0)       /* 1: products are added in the reference's order (values bit-identical to sprs'); 0: the waves of a large-row workgroup add as they arrive (LDS atomics: same products, rounding-level differences, not reproducible run to run; ~20 % faster kernel) */ \
-    X(spgemm_debug, 0, 0, 3, 1)         /* TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission */ \
+    X(spgemm_debug, 0, 0, 15, 1)        /* TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission, 4 no value stores and 8 no adds (wave-per-row kernel) */ \
     X(spgemm_occupancy, 3, 2, 3, 0)     /* workgroups per CU the large-row numeric kernel is compiled for: 3 (80 VGPRs) or 2 (128) */ \
     X(spgemm_retain, 1, 0, 1, 0)        /* windows of few entries keep them in registers from the bit pass to the adds (A/B) */    \
     X(spgemm_lds_atomic, 1, 0, 1, 0)    /* value adds as ds_add_f64 (1) or read / add / write (0); same order either way (A/B) */  \
     X(spgemm_winlog, 17, 16, 19, 0)     /* log2 of the widest column window of a large-row task */                                \
     X(spgemm_minwin, 13, 11, 16, 0)     /* log2 of the narrowest column window of a heavy row */                                  \
-    X(spgemm_heavy, 131072, 1024, INT64_MAX, 0) /* a row of more products is cut into one task per (narrower) column window */    \
+    X(spgemm_heavy, 524288, 1024, INT64_MAX, 0) /* a row of more products is cut into one task per (narrower) column window */    \
     X(gauss_seidel_blocks, 0, 0, 65536, 0) /* workgroups (4 waves) of the Gauss-Seidel sweep kernel (0 = default: one per CU) */          \
     X(gauss_seidel_chain, 0, 0, 1ll << 30, 0) /* rows one lane sweeps one after the other: 0 auto, 1 one row per lane in level order, L > 1 chains of L consecutive rows */ \
     X(gauss_seidel_xcd, 0, 0, 2, 0)     /* sweep kernel: 1 only the workgroups that find themselves on XCD 0 take part (hand-offs through ONE L2), 0 / 2 every XCD (measured: one XCD is not faster) */ \

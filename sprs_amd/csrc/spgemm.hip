@@ -35,6 +35,7 @@
 #include "scan.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstring>
 #include <vector>
 
@@ -48,7 +49,8 @@ constexpr uint64_t SMALL_MAX = 512;       // products per row handled by the wav
 constexpr int SMALL_TAB = 1024;           // hash slots per wave (load factor <= 0.5)
 constexpr uint64_t TINY_MAX = 64;         // rows of at most this many products: same kernel with a 128-slot table,
 constexpr int TINY_TAB = 128;             //   so that 32 waves share a CU instead of 12 (these rows are latency bound)
-constexpr int SM_BLOCK = 256;             // 4 waves
+constexpr int SM_BLOCK = 128;             // 2 waves (28 KB of LDS per block at 1024 slots: 5 blocks per CU)
+constexpr int SM_NBIN = 128;              // column bins of the rank pass that replaces a sort of the hash table
 constexpr int SM_WAVES = SM_BLOCK / WAVE;
 constexpr int MAX_WIN_LOG2 = 19;          // widest column window of a large-row task (option spgemm_winlog <= this)
 constexpr int LG_BLOCK = 512;             // 8 waves
@@ -297,10 +299,14 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                                                               const uint64_t *__restrict__ ub,
                                                               uint64_t *__restrict__ count,        // symbolic: out
                                                               const uint64_t *__restrict__ off,    // numeric: in
-                                                              IDX *__restrict__ c_indices, double *__restrict__ c_data) {
+                                                              IDX *__restrict__ c_indices, double *__restrict__ c_data,
+                                                              uint32_t bin_shift, uint32_t flags) {
     __shared__ uint32_t keys_s[SM_WAVES][TAB];
     __shared__ double vals_s[NUMERIC ? SM_WAVES : 1][NUMERIC ? TAB : 1];
     __shared__ uint32_t tag_s[NUMERIC ? SM_WAVES : 1][WAVE];   // order tags of the entry-parallel path
+    __shared__ uint32_t bin_s[NUMERIC ? SM_WAVES : 1][NUMERIC ? SM_NBIN : 1];      // rank pass: keys per column bin, then the bins' ends
+    __shared__ uint32_t skey_s[NUMERIC ? SM_WAVES : 1][NUMERIC ? TAB / 2 : 1];     // rank pass: the keys grouped by bin
+    const bool lane_order = (flags & 1u) != 0;                 // one ds_add_f64 per wave instruction: see add_lanes()
     const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     uint32_t *keys = keys_s[wave];
     double *vals = vals_s[NUMERIC ? wave : 0];
@@ -349,10 +355,10 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                 const uint32_t inc_o = __shfl(inc, (int)own, WAVE), len_o = __shfl(len, (int)own, WAVE);
                 const uint64_t bs_o = __shfl(bs, (int)own, WAVE);
                 const double av_o = __shfl(av, (int)own, WAVE);
-                const uint64_t pos = bs_o + (uint64_t)(t - (inc_o - len_o));
-                const uint32_t c = valid ? (uint32_t)B.indices[pos] : 0u;
+                const uint64_t pos = valid ? bs_o + (uint64_t)(t - (inc_o - len_o)) : 0ull;   // (a lane without an entry loads entry 0 and drops it:
+                const uint32_t c = (uint32_t)B.indices[pos];                                   //  a load under a per-lane condition ends in its own wait)
                 double pr = 0.0;
-                if constexpr (NUMERIC) pr = valid ? av_o * B.data[pos] : 0.0;
+                if constexpr (NUMERIC) pr = av_o * B.data[pos];
                 uint32_t h = hash_slot(c, lg);
                 if (valid) {
                     for (;;) {
@@ -372,6 +378,11 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                     // adds, the others (same column, or merely the same tag) take another turn.
                     wave_sync_lds();
                     bool pend = valid;
+                    if (lane_order) {                         // the lanes hold consecutive positions: the LDS applies them in lane order
+                        if (valid) atomicAdd(&vals[h], pr);
+                        wave_sync_lds();
+                        pend = false;
+                    }
                     uint32_t *tg = &tag_s[wave][h & (WAVE - 1)];
                     while (__ballot(pend)) {
                         if (pend) atomicMin(tg, lane);
@@ -422,30 +433,48 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
             const uint64_t tot = wave_sum_u64(fresh);
             if (lane == 0) count[t] = tot;
         } else {
-            // bitonic sort of the table by key (EMPTY sorts last), values follow
-            for (uint32_t k2 = 2; k2 <= tsize; k2 <<= 1) {
-                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = lane; i < tsize; i += WAVE) {
-                        const uint32_t l = i ^ j;
-                        if (l > i) {
-                            const uint32_t ki = keys[i], kl = keys[l];
-                            const bool asc = (i & k2) == 0;
-                            if ((ki > kl) == asc) {
-                                keys[i] = kl;
-                                keys[l] = ki;
-                                const double vi = vals[i], vl = vals[l];
-                                vals[i] = vl;
-                                vals[l] = vi;
-                            }
-                        }
-                    }
-                    wave_sync_lds();
-                }
+            // The row comes out SORTED without sorting the table: the keys are counted per column bin (SM_NBIN bins of 2^bin_shift
+            // columns), grouped by bin, and a key's rank is its bin's start plus the keys of its bin that are smaller — a short scan
+            // of the bin.  (Rounds 1 to 3: a bitonic sort of the whole table, 45 stages of 8 dependent LDS round trips for a row of
+            // 200 outputs — most of this kernel's time.)
+            uint32_t *bin = bin_s[wave], *skey = skey_s[wave];
+#pragma unroll
+            for (int i = 0; i < SM_NBIN / WAVE; ++i) bin[i * WAVE + lane] = 0;
+            wave_sync_lds();
+            for (uint32_t i = lane; i < tsize; i += WAVE) {
+                const uint32_t c = keys[i];
+                if (c != EMPTY) atomicAdd(&bin[c >> bin_shift], 1u);
             }
+            wave_sync_lds();
+            {   // exclusive scan of the bin counts (two bins per lane) -> where each bin starts
+                static_assert(SM_NBIN == 2 * WAVE, "two bins per lane");
+                const uint32_t a0 = bin[2 * lane], a1 = bin[2 * lane + 1];
+                uint32_t inc = a0 + a1;
+#pragma unroll
+                for (int off2 = 1; off2 < WAVE; off2 <<= 1) {
+                    const uint32_t o2 = __shfl_up(inc, off2, WAVE);
+                    if (lane >= (uint32_t)off2) inc += o2;
+                }
+                bin[2 * lane] = inc - a0 - a1;
+                bin[2 * lane + 1] = inc - a1;
+            }
+            wave_sync_lds();
+            for (uint32_t i = lane; i < tsize; i += WAVE) {
+                const uint32_t c = keys[i];
+                if (c != EMPTY) skey[atomicAdd(&bin[c >> bin_shift], 1u)] = c;     // afterwards bin[b] = END of bin b
+            }
+            wave_sync_lds();
             const uint64_t o = off[t];
-            for (uint32_t i = lane; i < need; i += WAVE) {
-                if (c_indices) c_indices[o + i] = (IDX)keys[i];   // null: C already has its structure (numeric on a kept plan)
-                if (c_data) c_data[o + i] = vals[i];      // null: structure only (the twin of smmp::symbolic)
+            for (uint32_t i = lane; i < tsize; i += WAVE) {
+                const uint32_t c = keys[i];
+                if (c != EMPTY) {
+                    const uint32_t b = c >> bin_shift;
+                    const uint32_t e2 = bin[b];
+                    uint32_t rank = b ? bin[b - 1] : 0u;
+                    for (uint32_t j = rank; j < e2; ++j) rank += skey[j] < c ? 1u : 0u;
+                    if (c_indices) c_indices[o + rank] = (IDX)c;      // null: C already has its structure (numeric on a kept plan)
+                    if (c_data) c_data[o + rank] = vals[i];           // null: structure only (the twin of smmp::symbolic)
+                }
             }
             wave_sync_lds();
         }
@@ -602,7 +631,7 @@ __device__ __forceinline__ void batch_load(Batch &bt, const uint32_t *__restrict
     for (int u = 0; u < LG_U; ++u) {
         const uint32_t t = t0 + 64u * u;
         bt.val[u] = (uint32_t)u < U && t < gtot;
-        pos[u] = 0;
+        pos[u] = 0;                            // a lane without an entry loads entry 0 and drops it: see the loads below
         bt.own[u] = 0;
         av[u] = 0.0;
         if (bt.val[u]) {
@@ -612,23 +641,26 @@ __device__ __forceinline__ void batch_load(Batch &bt, const uint32_t *__restrict
             if constexpr (VALUES) av[u] = kA[wk.o];
         }
     }
+    // All loads of the batch are independent and UNCONDITIONAL (a load under a per-lane condition is compiled as a branch
+    // whose arm waits for that one load: four memory round trips per batch instead of one — the ISA of rounds 1 to 3).
+    uint32_t col[LG_U];
     double bv[LG_U];
 #pragma unroll
-    for (int u = 0; u < LG_U; ++u) {           // all loads of the batch are independent
-        bt.cc[u] = 0u;
+    for (int u = 0; u < LG_U; ++u) {
         bv[u] = 0.0;
         if constexpr (VALUES) {                // one 16-byte record per entry
-            if (bt.val[u]) {
-                const BRec rec = b_pack[pos[u]];
-                bt.cc[u] = rec.col - (uint32_t)wlo;
-                bv[u] = rec.val;
-            }
+            const BRec rec = b_pack[pos[u]];
+            col[u] = rec.col;
+            bv[u] = rec.val;
         } else {
-            if (bt.val[u]) bt.cc[u] = b_col32[pos[u]] - (uint32_t)wlo;
+            col[u] = b_col32[pos[u]];
         }
     }
 #pragma unroll
-    for (int u = 0; u < LG_U; ++u) bt.pr[u] = av[u] * bv[u];
+    for (int u = 0; u < LG_U; ++u) {
+        bt.cc[u] = bt.val[u] ? col[u] - (uint32_t)wlo : 0u;
+        bt.pr[u] = av[u] * bv[u];
+    }
 }
 
 __device__ __forceinline__ void batch_bits(const Batch &bt, uint32_t *bm32) {
@@ -717,7 +749,6 @@ constexpr int MID_BLOCK = 128;
 constexpr int MID_WAVES = MID_BLOCK / WAVE;
 constexpr int MID_ACC = 512;                      // accumulators of one pass
 constexpr int MID_K = 64;                         // k's per row: one per lane
-constexpr int MID_KEEP = 8;                       // wave instructions of a chunk: what a segment of <= 512 entries keeps in registers from the bit pass to the adds
 
 // inclusive scan over the 64 lanes without the LDS: four row_shr steps inside the rows of 16 lanes, then row_bcast 15 and 31
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
@@ -786,8 +817,8 @@ struct alignas(16) KRec {
     double a;
 };
 
-template <typename IDX, typename PTR, bool NUMERIC, int MID_WL>
-__global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t b_cols,
+template <typename IDX, typename PTR, bool NUMERIC, int MID_WL, int MID_KEEP>
+__global__ __launch_bounds__(MID_BLOCK, !NUMERIC ? 4 : MID_KEEP >= 8 ? 3 : 5) void mid_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t b_cols,
                                                              const uint64_t *__restrict__ mid_list, uint64_t n_mid,
                                                              const uint64_t *__restrict__ task_row,
                                                              uint64_t *__restrict__ count,        // symbolic: out
@@ -831,6 +862,7 @@ __global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR
     uint8_t *mark8 = (uint8_t *)mark32;
     const bool values = NUMERIC && c_data != nullptr;
     const bool lane_order = (flags & 1u) != 0;
+    const bool dbg_no_emit = DEVTOOLS && (flags & 8u), dbg_no_flush = DEVTOOLS && (flags & 16u), dbg_no_add = DEVTOOLS && (flags & 32u);   // timing experiments (option spgemm_debug & 2 / 4 / 8): WRONG results
     uint64_t nwin = (b_cols + (1ull << MID_WL) - 1) >> MID_WL;
     if (nwin == 0) nwin = 1;
 #pragma unroll
@@ -853,40 +885,70 @@ __global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR
         const uint64_t as = (uint64_t)A.indptr[r], ae = (uint64_t)A.indptr[r + 1];
         const uint32_t nk = (uint32_t)(ae - as);                     // <= 64 (row_work_kernel)
         const bool has = lane < nk;
-        // positions inside B's row k_j as 32-bit offsets from its start (a row has fewer than 2^32 entries: b_cols < 2^32)
-        uint64_t rk = 0, rs = 0;
-        uint32_t re = 0, cur = 0;
-        uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;       // where my row leaves windows w .. w + 3: loaded four windows ahead
+        // positions inside B's row k_j as 32-bit offsets from its start (a row has fewer than 2^32 entries: b_cols < 2^32).
+        // Every load here and in the window loop is unconditional (lanes without a k read the row's first k and are masked where
+        // lengths are formed): a load under `if (has)` ends in a wait for that load — the "prefetch" of a window edge four windows
+        // ahead used to be one more blocking round trip per window.  The edges come from the bucket table alone (this kernel only
+        // runs with one: plan_build classes every row as large otherwise): entries of row k before column col, col a multiple of
+        // 2048, = bucket[k][min(col / 2048, nb - 1)] — one load, no branch.
+        const uint64_t rk = (uint64_t)A.indices[as + (has ? lane : 0u)];
+        const uint64_t rs = (uint64_t)B.indptr[rk];
+        const uint32_t re = (uint32_t)((uint64_t)B.indptr[rk + 1] - rs);
         double rav = 0.0;
-        auto edge = [&](uint32_t lo, uint32_t hi, uint64_t col) -> uint32_t {      // first entry of my row in [lo, hi) with column >= col
-            return (uint32_t)(first_ge(B, rk, rs, rs + lo, rs + hi, col) - rs);
+        if (values) rav = A.data[as + (has ? lane : 0u)];
+        const uint32_t *__restrict__ bt = B.bucket + rk * B.nb;
+        auto edge = [&](uint64_t col) -> uint32_t {          // first entry of my row with column >= col (col a multiple of 2048)
+            const uint64_t b = col >> BUCKET_LOG2;
+            return bt[b < B.nb - 1 ? b : B.nb - 1];
         };
-        if (has) {
-            rk = (uint64_t)A.indices[as + lane];
-            rs = (uint64_t)B.indptr[rk];
-            re = (uint32_t)((uint64_t)B.indptr[rk + 1] - rs);
-            if (values) rav = A.data[as + lane];
-            cur = 0;
-            q0 = nwin <= 1 ? re : edge(0, re, 1ull << MID_WL);
-            q1 = nwin <= 2 ? re : edge(0, re, 2ull << MID_WL);
-            q2 = nwin <= 3 ? re : edge(0, re, 3ull << MID_WL);
-            q3 = nwin <= 4 ? re : edge(0, re, 4ull << MID_WL);
-        }
+        uint32_t cur = 0;
+        uint32_t q0 = edge(1ull << MID_WL), q1 = edge(2ull << MID_WL), q2 = edge(3ull << MID_WL), q3 = edge(4ull << MID_WL);   // where my row leaves windows w .. w + 3
         uint64_t out = 0;
         if constexpr (NUMERIC) out = off[t];
         uint32_t fresh = 0;
         mark(0);
         const long long t_row = (TIMERS && prof) ? (long long)wall_clock64() : 0;
-        for (uint64_t w = 0; w < nwin; ++w) {
+        // A row with ONE k is a_ik * B_k entry for entry (every sum is 0.0 + a b: the accumulators start at N::zero(), smmp.rs:174-181):
+        // streamed, no bitmap, no windows (config 5: 40 000 of the 268 000 rows of this kernel).  Every lane holds that k.
+        if (nk == 1) {
+            if constexpr (!NUMERIC) {
+                fresh = lane == 0 ? re : 0u;
+            } else {
+                for (uint32_t i0 = 0; i0 < re; i0 += 4 * WAVE) {
+                    uint32_t col[4];
+                    double bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t i = i0 + (uint32_t)(u * WAVE) + lane;
+                        const uint64_t at = rs + (i < re ? i : 0u);       // (unconditional loads: see load_chunk_n)
+                        bv[u] = 0.0;
+                        if (values) {                                     // wave-uniform
+                            const BRec rec = B.pack[at];
+                            col[u] = rec.col;
+                            bv[u] = rec.val;
+                        } else {
+                            col[u] = B.col32[at];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t i = i0 + (uint32_t)(u * WAVE) + lane;
+                        if (i < re) {
+                            if (c_indices) c_indices[out + i] = (IDX)col[u];
+                            if (values) c_data[out + i] = 0.0 + rav * bv[u];
+                        }
+                    }
+                }
+            }
+        }
+        for (uint64_t w = nk == 1 ? nwin : 0; w < nwin; ++w) {
             const uint64_t win_lo = w << MID_WL;
             const uint32_t win_s = cur, win_e = q0;
-            if (has) {
-                cur = win_e;
-                q0 = q1;
-                q1 = q2;
-                q2 = q3;
-                if (w + 4 < nwin) q3 = w + 5 >= nwin ? re : edge(q2, re, (w + 5) << MID_WL);
-            }
+            cur = win_e;
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            q3 = edge((w + 5) << MID_WL);                            // (past the last window: the whole row)
             const uint32_t winc = wave_incl_scan_u32(has ? win_e - win_s : 0u);
             const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)winc, WAVE - 1);
             mark(1);
@@ -899,15 +961,12 @@ __global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR
             if (NUMERIC)
                 while (nseg < (1u << (MID_WL - BUCKET_LOG2)) && wtotal > nseg * (uint32_t)MID_ACC) nseg <<= 1;
             const uint32_t SEG_COLS = (1u << MID_WL) / nseg;
-            uint32_t seg_s = win_s, seg_nxt = win_e;
-            if (nseg > 1 && has) seg_nxt = edge(win_s, win_e, win_lo + SEG_COLS);
+            uint32_t seg_s = win_s, seg_nxt = edge(win_lo + SEG_COLS);         // (one segment: = win_e)
             for (uint32_t seg = 0; seg < nseg; ++seg) {
             const uint64_t wlo = win_lo + (nseg > 1 ? (uint64_t)seg * SEG_COLS : 0ull);
             const uint32_t ws = seg_s, we = seg + 1 == nseg ? win_e : seg_nxt;
-            if (nseg > 1 && has) {
-                seg_s = we;
-                if (seg + 2 < nseg) seg_nxt = edge(we, win_e, wlo + 2 * (uint64_t)SEG_COLS);
-            }
+            seg_s = we;
+            seg_nxt = edge(wlo + 2 * (uint64_t)SEG_COLS);                  // (asked for one segment ahead; unused after the last)
             const uint32_t len = has ? we - ws : 0u;
             const uint32_t inc = nseg == 1 ? winc : wave_incl_scan_u32(len);
             const uint32_t total = nseg == 1 ? wtotal : (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
@@ -929,49 +988,60 @@ __global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR
             // inside a k: the reference's order).  Owners: every k that starts inside the chunk leaves its number at its first
             // position (one byte), a max-scan over the positions spreads it over the run — one LDS read and six DPP steps per
             // instruction instead of a search per position.  The loads of the whole chunk are in flight together.
-            auto load_chunk = [&](uint32_t c0, bool with_value) {
+            // (Every load below is UNCONDITIONAL: a lane without an entry reads entry 0 and drops it.  A load under a per-lane
+            // condition — `valid ? B[pos] : 0` — is compiled as a branch whose arm ends in a wait for that one load: the eight
+            // "independent" loads of a chunk then were eight memory round trips one after the other, in this kernel and in the
+            // workgroup kernel, from round 1 on; found in the ISA in round 4.  The instruction count NB is a compile-time number
+            // for the same reason: 1, 2, 4 or 8 wave instructions of straight-line code.)
+            auto load_chunk_n = [&](uint32_t c0, auto with_value_c, auto nb_c) {
+                constexpr bool WITH_VALUE = decltype(with_value_c)::value;
+                constexpr int NB = decltype(nb_c)::value;
 #pragma unroll
                 for (int i = 0; i < MID_KEEP / 4; ++i) mark32[i * WAVE + lane] = 0;
                 wave_sync_lds();
                 if (len != 0 && excl - c0 < (uint32_t)(MID_KEEP * WAVE)) mark8[excl - c0] = (uint8_t)(lane + 1);
                 wave_sync_lds();
-                uint64_t pos[MID_KEEP];
-                uint32_t own[MID_KEEP];
+                uint64_t pos[NB];
+                uint32_t own[NB];
+                bool ok[NB];
 #pragma unroll
-                for (int b = 0; b < MID_KEEP; ++b) {
-                    own[b] = 0;
-                    pos[b] = ~0ull;                                   // no entry
-                    if (c0 + (uint32_t)(b * WAVE) < total) {          // wave-uniform: an instruction that does not exist costs a branch
-                        const uint32_t tpos = c0 + (uint32_t)(b * WAVE) + lane;
-                        uint32_t o = wave_incl_max_u32((uint32_t)mark8[b * WAVE + lane]);
-                        o = o > carry ? o : carry;
-                        carry = (uint32_t)__builtin_amdgcn_readlane((int)o, WAVE - 1);
-                        own[b] = o - 1u;                              // (position 0 always starts a k: o >= 1)
-                        if (tpos < total) pos[b] = krec[own[b]].base + tpos;
-                    }
+                for (int b = 0; b < NB; ++b) {
+                    const uint32_t tpos = c0 + (uint32_t)(b * WAVE) + lane;
+                    uint32_t o = wave_incl_max_u32((uint32_t)mark8[b * WAVE + lane]);
+                    o = o > carry ? o : carry;
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)o, WAVE - 1);
+                    own[b] = o - 1u;                                  // (position 0 always starts a k: o >= 1)
+                    ok[b] = tpos < total;
+                    const uint64_t at = krec[own[b]].base + tpos;
+                    pos[b] = ok[b] ? at : 0ull;
                 }
-                double bv[MID_KEEP];
+                uint32_t col[NB];
+                double bv[NB];
 #pragma unroll
-                for (int b = 0; b < MID_KEEP; ++b) {
-                    kco[b] = 0xFFFFFFFFu;
+                for (int b = 0; b < NB; ++b) {
                     bv[b] = 0.0;
-                    if (c0 + (uint32_t)(b * WAVE) < total) {          // wave-uniform
-                        if (with_value) {                             // wave-uniform: one 16-byte record per entry
-                            if (pos[b] != ~0ull) {
-                                const BRec rec = B.pack[pos[b]];
-                                kco[b] = (rec.col - (uint32_t)wlo) | (own[b] << 16);
-                                bv[b] = rec.val;
-                            }
-                        } else if (pos[b] != ~0ull) {
-                            kco[b] = (B.col32[pos[b]] - (uint32_t)wlo) | (own[b] << 16);
-                        }
+                    if constexpr (WITH_VALUE) {                       // one 16-byte record per entry
+                        const BRec rec = B.pack[pos[b]];
+                        col[b] = rec.col;
+                        bv[b] = rec.val;
+                    } else {
+                        col[b] = B.col32[pos[b]];
                     }
                 }
 #pragma unroll
-                for (int b = 0; b < MID_KEEP; ++b) {
+                for (int b = 0; b < NB; ++b) {
+                    kco[b] = ok[b] ? (col[b] - (uint32_t)wlo) | (own[b] << 16) : 0xFFFFFFFFu;
                     kpr[b] = 0.0;
-                    if (with_value && c0 + (uint32_t)(b * WAVE) < total) kpr[b] = krec[own[b]].a * bv[b];   // wave-uniform
+                    if constexpr (WITH_VALUE) kpr[b] = krec[own[b]].a * bv[b];
                 }
+            };
+            auto load_chunk = [&](uint32_t c0, auto with_value_c) {
+                const uint32_t left = total - c0;
+                if (left <= (uint32_t)WAVE) load_chunk_n(c0, with_value_c, std::integral_constant<int, 1>{});
+                else if (left <= 2u * WAVE) load_chunk_n(c0, with_value_c, std::integral_constant<int, 2>{});
+                else if (left <= 4u * WAVE) load_chunk_n(c0, with_value_c, std::integral_constant<int, 4>{});
+                else if (MID_KEEP > 8 && left <= 8u * WAVE) load_chunk_n(c0, with_value_c, std::integral_constant<int, (MID_KEEP > 8 ? 8 : MID_KEEP)>{});
+                else load_chunk_n(c0, with_value_c, std::integral_constant<int, MID_KEEP>{});
             };
             auto set_bits = [&](uint32_t c0) {
 #pragma unroll
@@ -981,11 +1051,11 @@ __global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR
             };
             // ---- bit pass ----
             if (keep) {
-                load_chunk(0, true);
+                load_chunk(0, std::true_type{});
                 set_bits(0);
             } else {
                 for (uint32_t c0 = 0; c0 < total; c0 += MID_KEEP * WAVE) {
-                    load_chunk(c0, false);
+                    load_chunk(c0, std::false_type{});
                     set_bits(c0);
                 }
             }
@@ -1025,8 +1095,8 @@ __global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR
                             if (c0 + (uint32_t)(b * WAVE) < total) {  // wave-uniform
                                 const bool kv = kco[b] != 0xFFFFFFFFu;
                                 const uint32_t slot = kv ? slot_of(kco[b] & 0xFFFFu) : 0xFFFFFFFFu;
-                                if (kv && c_indices && p0 == 0) c_indices[out + slot] = (IDX)(wlo + (kco[b] & 0xFFFFu));
-                                if (values) add_lanes(kv && slot < n_out, kco[b] >> 16, slot, kpr[b], acc, lane_order);
+                                if (kv && c_indices && p0 == 0 && !dbg_no_emit) c_indices[out + slot] = (IDX)(wlo + (kco[b] & 0xFFFFu));
+                                if (values && !dbg_no_add) add_lanes(kv && slot < n_out, kco[b] >> 16, slot, kpr[b], acc, lane_order);
                             }
                         }
                     };
@@ -1035,12 +1105,13 @@ __global__ __launch_bounds__(MID_BLOCK, 4) void mid_rows_kernel(CsrView<IDX, PTR
                     } else {
                         carry = 0;
                         for (uint32_t c0 = 0; c0 < total; c0 += MID_KEEP * WAVE) {
-                            load_chunk(c0, values);
+                            if (values) load_chunk(c0, std::true_type{});
+                            else load_chunk(c0, std::false_type{});
                             add_chunk(c0);
                         }
                     }
                     wave_sync_lds();
-                    for (uint32_t i = lane; values && i < n_out; i += WAVE) c_data[out + p0 + i] = acc[i];
+                    for (uint32_t i = lane; values && !dbg_no_flush && i < n_out; i += WAVE) c_data[out + p0 + i] = acc[i];
                     wave_sync_lds();
                 }
                 out += wtot;
@@ -1606,7 +1677,7 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
                            (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint32_t)options().spgemm_minwin,
-                           (uint64_t)options().spgemm_mid,
+                           pl->nb ? (uint64_t)options().spgemm_mid : 0ull,      /* the wave-per-row kernel takes its window edges from the bucket table */
                            pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), cls.as<uint8_t>(), pl->wlog.as<uint8_t>());
         SPRS_TRY_HIP(hipGetLastError());
         hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, (const uint8_t *)cls.as<uint8_t>(), pl->ntasks.as<uint64_t>(), rows,
@@ -1681,13 +1752,13 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     if (n_tiny) {
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, wstream,
                            A, B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
-                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
+                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr, 0u, 0u);
         SPRS_TRY_HIP(hipGetLastError());
     }
     if (n_small) {
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, wstream,
                            A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
-                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);
+                           pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr, 0u, 0u);
         SPRS_TRY_HIP(hipGetLastError());
     }
     pl->midwin = options().spgemm_midwin;
@@ -1697,17 +1768,17 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         return dim3((unsigned)g);
     };
     if (n_mid) {
-#define SPRS_MID_SYM(WL)                                                                                             \
-    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, false, WL>), mid_grid(n_mid), dim3(MID_BLOCK), 0, wstream, A, B, b_cols, \
+#define SPRS_MID_SYM(WL, KP)                                                                                             \
+    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, false, WL, KP>), mid_grid(n_mid), dim3(MID_BLOCK), 0, wstream, A, B, b_cols, \
                        pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
                        (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr, (unsigned long long *)nullptr, (const uint64_t *)nullptr, \
                        pl->counters.as<unsigned int>(), 0u)
         SPRS_TRY_HIP(pl->counters.alloc(64));
         SPRS_TRY_HIP(hipMemsetAsync(pl->counters.p, 0, 64, wstream));
         // the counting kernel has no accumulators: windows of 2^16 columns (four times fewer window prologues per row)
-        if (options().spgemm_midwin_sym == 16) SPRS_MID_SYM(16);
-        else if (options().spgemm_midwin_sym == 15) SPRS_MID_SYM(15);
-        else SPRS_MID_SYM(14);
+        const bool k16 = options().spgemm_mid_keep_sym >= 16;
+        if (options().spgemm_midwin_sym >= 15) { if (k16) SPRS_MID_SYM(16, 16); else SPRS_MID_SYM(16, 8); }
+        else { if (k16) SPRS_MID_SYM(14, 16); else SPRS_MID_SYM(14, 8); }
 #undef SPRS_MID_SYM
         SPRS_TRY_HIP(hipGetLastError());
     }
@@ -1763,7 +1834,7 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
         // not reproducible run to run; structure unaffected).  Needs the atomic form of the add.
         const bool unordered = options().spgemm_ordered == 0;
         const uint32_t flags = ((options().spgemm_lds_atomic || unordered) ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u) |
-                               (unordered ? 4u : 0u) | ((uint32_t)options().spgemm_debug << 2) |
+                               (unordered ? 4u : 0u) | ((uint32_t)(options().spgemm_debug & 3) << 2) |
                                ((options().spgemm_tokens >= 4 ? 2u : options().spgemm_tokens >= 2 ? 1u : 0u) << 4) |
                                ((options().spgemm_lds_atomic || unordered) && add_flags() ? 64u : 0u);
 #define SPRS_LG_NUM(WL, OCC)                                                                                         \
@@ -1833,14 +1904,18 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
             }
         }
     }
+    // bins of the hash kernels' rank pass: the column space cut into SM_NBIN equal power-of-two ranges
+    uint32_t bin_shift = 0;
+    while (bin_shift < 32 && ((pl->b_cols - (pl->b_cols ? 1 : 0)) >> bin_shift) >= (uint64_t)SM_NBIN) ++bin_shift;
+    const uint32_t small_flags = add_flags();
     if (n_tiny)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, wstream, A,
                            B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
-                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
+                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values, bin_shift, small_flags);
     if (n_small)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, SMALL_TAB>), small_grid(n_small), dim3(SM_BLOCK), 0, wstream,
                            A, B, pl->small_list.as<uint64_t>(), n_small, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
-                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values);
+                           pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, c_values, bin_shift, small_flags);
     if (n_mid) {
         uint64_t g = (n_mid + MID_WAVES - 1) / MID_WAVES;
         if (g > 256 * 12) g = 256 * 12;
@@ -1849,19 +1924,16 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
             SPRS_TRY_HIP(mprof.alloc(256));
             SPRS_TRY_HIP(hipMemsetAsync(mprof.p, 0, 256, stream));
         }
-#define SPRS_MID_NUM(WL)                                                                                             \
-    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, true, WL>), dim3((unsigned)g), dim3(MID_BLOCK), 0, wstream, A, B, pl->b_cols, \
+#define SPRS_MID_NUM(WL, KP)                                                                                             \
+    hipLaunchKernelGGL((mid_rows_kernel<IDX, PTR, true, WL, KP>), dim3((unsigned)g), dim3(MID_BLOCK), 0, wstream, A, B, pl->b_cols, \
                        pl->mid_list.as<uint64_t>(), n_mid, pl->task_row.as<uint64_t>(), pl->count.as<uint64_t>(),    \
                        pl->off.as<uint64_t>(), c_indices, c_values, mprof.as<unsigned long long>(), pl->ub.as<uint64_t>(),   \
                        pl->counters.as<unsigned int>() + 4, wave_flags)
         SPRS_TRY_HIP(hipMemsetAsync(pl->counters.as<unsigned int>() + 4, 0, 4, wstream));
-        const uint32_t wave_flags = add_flags();
-        switch (pl->midwin) {
-            case 13: SPRS_MID_NUM(13); break;
-            case 15: SPRS_MID_NUM(15); break;
-            case 16: SPRS_MID_NUM(16); break;
-            default: SPRS_MID_NUM(14); break;
-        }
+        const uint32_t wave_flags = add_flags() | (DEVTOOLS ? (uint32_t)options().spgemm_debug << 2 : 0u);
+        const bool k8 = options().spgemm_mid_keep >= 8;
+        if (pl->midwin >= 15) { if (k8) SPRS_MID_NUM(15, 8); else SPRS_MID_NUM(15, 4); }
+        else { if (k8) SPRS_MID_NUM(14, 8); else SPRS_MID_NUM(14, 4); }
 #undef SPRS_MID_NUM
         if (DEVTOOLS && mprof.p) {
             unsigned long long h[32];
