@@ -86,7 +86,6 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_ordered, 1, 0, 1, 0)       /* 1: products are added in the reference's order (values bit-identical to sprs'); 0: the waves of a large-row workgroup add as they arrive (LDS atomics: same products, rounding-level differences, not reproducible run to run; ~20 % faster kernel) */ \
     X(spgemm_debug, 0, 0, 15, 1)        /* TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission, 4 no value stores and 8 no adds (wave-per-row kernel) */ \
     X(spgemm_occupancy, 3, 2, 3, 0)     /* workgroups per CU the large-row numeric kernel is compiled for: 3 (80 VGPRs) or 2 (128) */ \
-    X(spgemm_retain, 1, 0, 1, 0)        /* windows of few entries keep them in registers from the bit pass to the adds (A/B) */    \
     X(spgemm_lds_atomic, 1, 0, 1, 0)    /* value adds as ds_add_f64 (1) or read / add / write (0); same order either way (A/B) */  \
     X(spgemm_winlog, 17, 16, 19, 0)     /* log2 of the widest column window of a large-row task */                                \
     X(spgemm_minwin, 13, 11, 16, 0)     /* log2 of the narrowest column window of a heavy row */                                  \

@@ -1250,7 +1250,6 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const bool one_group = ae - as <= (uint64_t)K_CAP;
     const bool values = NUMERIC && c_data != nullptr;
     const uint32_t lds_atomic = (flags & 64u) ? 2u : (flags & 1u);       // how a wave instruction's products are added: 2 one ds_add_f64 (lane order), 1 one per k-run, 0 read-add-write per k-run (A/B)
-    const bool retain_ok = values && (flags & 2u) != 0;
     const bool no_order = (flags & 4u) != 0;                        // option spgemm_ordered = 0 (supported: same products, unordered atomic adds)
     const bool no_emit = DEVTOOLS && (flags & 8u) != 0;             // timing experiment (option spgemm_debug & 2): WRONG results
     const uint32_t ntok = 1u << ((flags >> 4) & 3u);                          // 1, 2 or 4 token chains (option spgemm_tokens)
@@ -1286,8 +1285,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
         }
         // ---- bit pass -------------------------------------------------------------------------------
         uint32_t k_total = 0;
-        bool any = false, retain = false;
-        Batch kept;
+        bool any = false;
         for (uint64_t kc = as; kc < ae; kc += K_CAP) {
             const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
             const uint32_t gtot =
@@ -1295,21 +1293,6 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                           : stage_k_group<K_CAP>(A, B, kc, n, wlo, whi, nwin == 1, kS, kP, values ? kA : (double *)nullptr, wt);
             k_total = gtot;
             any |= gtot != 0;
-            if constexpr (NUMERIC) {
-                // A window of few entries (one batch per wave at most) is loaded ONCE: column, value and owner stay in
-                // registers from the bit pass to the adds (its outputs fit one pass: <= 64 LG_U LG_WAVES <= ACC_CAP).
-                retain = retain_ok && one_group && gtot <= 64u * LG_U * LG_WAVES;     // block-uniform
-                if (retain) {
-                    const uint32_t U = batch_u(gtot), wave = tid / WAVE;
-#pragma unroll
-                    for (int u = 0; u < LG_U; ++u) kept.val[u] = false;
-                    if (wave * 64 * U < gtot) {
-                        batch_load<K_CAP, true>(kept, (const uint32_t *)nullptr, B.pack, wlo, gtot, U, wave, kS, kP, kA);
-                        batch_bits(kept, (uint32_t *)bm);
-                    }
-                    continue;
-                }
-            }
             walk_bits<K_CAP>(B.col32, wlo, gtot, kS, kP, (uint32_t *)bm);
         }
         lds_barrier();
@@ -1351,20 +1334,32 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             if (tid == 0) super[nsb] = wtot;
             lds_barrier();
             mark(2);
-            // indices come out sorted: walk the set bits of each word in order
+            // indices come out sorted: the set bits of each word in order.  They are STAGED in LDS (the accumulators are idle until
+            // the passes start: room for 2 ACC_CAP column offsets at a time) and written out one rank per thread — 512 contiguous
+            // bytes per wave instruction.  (Written straight from the bit loops, a store instruction hit 64 scattered 8-byte places;
+            // with the stores left out the kernel ran 17 % faster: profiles/r10i.)
             if (c_indices && !no_emit) {                            // (null: C already has its structure)
+                uint32_t *stage = (uint32_t *)acc;
+                constexpr uint32_t STAGE_CAP = 2u * ACC_CAP;
+                for (uint32_t base = 0; base < wtot; base += STAGE_CAP) {      // block-uniform
+                    const uint32_t lim = wtot - base < STAGE_CAP ? wtot - base : STAGE_CAP;
 #pragma unroll 1
-                for (int i = 0; i < WPT; ++i) {
-                    const int word = i * LG_BLOCK + (int)tid;
-                    if (word >= words) break;
-                    unsigned long long m = bm[word];
-                    uint32_t run = super[word / SUPER_WORDS] + sub[word];
-                    while (m) {
-                        const int bit = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        c_indices[out + run] = (IDX)(wlo + (uint64_t)word * 64 + (uint64_t)bit);
-                        ++run;
+                    for (int i = 0; i < WPT; ++i) {
+                        const int word = i * LG_BLOCK + (int)tid;
+                        if (word >= words) break;
+                        unsigned long long m = bm[word];
+                        uint32_t run = super[word / SUPER_WORDS] + sub[word] - base;     // (wraps below the chunk: the compare sorts it out)
+                        if (run + (uint32_t)__popcll(m) - 1u >= lim && run >= lim) continue;   // no rank of this word in the chunk
+                        while (m) {
+                            const int bit = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            if (run < lim) stage[run] = (uint32_t)word * 64u + (uint32_t)bit;
+                            ++run;
+                        }
                     }
+                    lds_barrier();
+                    for (uint32_t i = tid; i < lim; i += LG_BLOCK) c_indices[out + base + i] = (IDX)(wlo + (uint64_t)stage[i]);
+                    lds_barrier();
                 }
             }
             mark(3);
@@ -1394,13 +1389,6 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                     const bool single = pb == 0 && pe == (uint32_t)nsb;
                     const uint64_t plo = wlo + (uint64_t)pb * (SUPER_WORDS * 64);
                     const uint64_t phi = wlo + (uint64_t)pe * (SUPER_WORDS * 64);
-                    if (retain) {                                // (then single: see the bit pass)
-                        lds_barrier();                           // the accumulators are clear before anybody adds
-                        const uint32_t U = batch_u(k_total), wave = tid / WAVE;
-                        const uint32_t nbatch = (k_total + 64 * U - 1) / (64 * U);
-                        if (wave < nbatch) batch_add(kept, U, bm, sub, super, base_rank, acc, token, no_order ? 0xFFFFFFFFu : tok_base + wave, lds_atomic, ntok);
-                        tok_base += nbatch;
-                    } else
                     for (uint64_t kc = as; kc < ae; kc += K_CAP) {
                         const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
                         uint32_t gtot;
@@ -1833,8 +1821,7 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
         // is the sum of the same products, added by LDS atomics in whatever order the waves arrive — rounding-level differences,
         // not reproducible run to run; structure unaffected).  Needs the atomic form of the add.
         const bool unordered = options().spgemm_ordered == 0;
-        const uint32_t flags = ((options().spgemm_lds_atomic || unordered) ? 1u : 0u) | (options().spgemm_retain ? 2u : 0u) |
-                               (unordered ? 4u : 0u) | ((uint32_t)(options().spgemm_debug & 3) << 2) |
+        const uint32_t flags = ((options().spgemm_lds_atomic || unordered) ? 1u : 0u) |                                (unordered ? 4u : 0u) | ((uint32_t)(options().spgemm_debug & 3) << 2) |
                                ((options().spgemm_tokens >= 4 ? 2u : options().spgemm_tokens >= 2 ? 1u : 0u) << 4) |
                                ((options().spgemm_lds_atomic || unordered) && add_flags() ? 64u : 0u);
 #define SPRS_LG_NUM(WL, OCC)                                                                                         \

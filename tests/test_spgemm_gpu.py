@@ -233,15 +233,14 @@ def _order_stress_cases():
 
 def test_order_of_additions_stress(hip):
     for a, b in _order_stress_cases():
-        for retain in (1, 0):
-            for atomic in (1, 0):
-                hip.set_option("spgemm_retain", retain)
-                hip.set_option("spgemm_lds_atomic", atomic)
-                try:
-                    check_against_oracle(a, b, exact_values=True)
-                finally:
-                    hip.set_option("spgemm_retain", 1)
-                    hip.set_option("spgemm_lds_atomic", 1)
+        for lane_order, atomic in ((0, 1), (2, 1), (2, 0)):       # one ds_add_f64 per wave instruction / one per k-run / read-add-write per k-run
+            hip.set_option("spgemm_lane_order", lane_order)
+            hip.set_option("spgemm_lds_atomic", atomic)
+            try:
+                check_against_oracle(a, b, exact_values=True)
+            finally:
+                hip.set_option("spgemm_lane_order", 0)
+                hip.set_option("spgemm_lds_atomic", 1)
 
 
 @pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
