@@ -108,7 +108,7 @@ def case_spgemm(rng):
     opts = dict(spgemm_mid=int(rng.choice([0, 600, 65536])), spgemm_heavy=int(rng.choice([1024, 4096, 131072])),
                 spgemm_winlog=int(rng.choice([16, 17, 18, 19])), spgemm_bucket=int(rng.integers(0, 2)),
                 spgemm_tokens=int(rng.choice([1, 2, 4])),
-                spgemm_lane_order=int(rng.choice([0, 2])), spgemm_midwin=int(rng.choice([14, 15])), spgemm_mid_keep=int(rng.choice([4, 8])), spgemm_mid_keep_sym=int(rng.choice([8, 16])), spgemm_midwin_sym=int(rng.choice([14, 16])))
+                spgemm_lane_order=int(rng.choice([0, 2])), spgemm_keep_bits=int(rng.integers(0, 2)), spgemm_midwin=int(rng.choice([14, 15])), spgemm_mid_keep=int(rng.choice([4, 8])), spgemm_mid_keep_sym=int(rng.choice([8, 16])), spgemm_midwin_sym=int(rng.choice([14, 16])))
     setopt(**opts)
     try:
         rs, rip, rix, rdt = oracle.mul_csr_csr(A[0], A[1], A[2], A[3], B[0], B[1], B[2], B[3])

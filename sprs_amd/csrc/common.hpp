@@ -76,6 +76,7 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_bucket, 1, 0, 1, 0)        /* column-bucket table of B instead of binary searches (A/B) */                           \
     X(spgemm_prof, 0, 0, 1, 1)          /* print the time of the numeric tasks by class and the longest ones */                   \
     X(spgemm_tokens, 1, 1, 4, 0)        /* token chains of the workgroup kernel's ordered adds: 1, 2 or 4 */                      \
+    X(spgemm_keep_bits, 1, 0, 1, 0)     /* the counting pass keeps the bitmaps of the large rows for the numeric pass (one walk of their entries instead of two); 0: the numeric kernel walks for its bits (A/B) */ \
     X(spgemm_lane_order, 0, 0, 2, 0)    /* products of one wave instruction into the LDS accumulators: 0 auto = ONE ds_add_f64 when the device passes the lane-order probe (same-address lanes applied in ascending lane order), else one instruction per k-run; 2 always per k-run (A/B); same bits either way */ \
     X(spgemm_overlap, 0, 0, 1, 0)       /* wave kernels on a second stream beside the large-row kernel */                         \
     X(spgemm_midwin_sym, 14, 14, 16, 0) /* log2 of the window of the wave-per-row COUNTING kernel: 14 or 16 */                        \

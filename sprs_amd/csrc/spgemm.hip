@@ -1206,7 +1206,9 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
                                                               IDX *__restrict__ c_indices, double *__restrict__ c_data,
                                                               uint32_t xcd_chunk, uint32_t flags,
                                                               unsigned long long *__restrict__ prof,
-                                                              const uint64_t *__restrict__ ub_dbg) {
+                                                              const uint64_t *__restrict__ ub_dbg,
+                                                              const uint64_t *__restrict__ large_slot,
+                                                              unsigned long long *__restrict__ kept_bm, uint64_t kept_words) {
     using Cfg = LgCfg<WL>;
     // phase timers of option spgemm_prof (developer builds only: compiled out of the release library): in LDS (see mid_rows_kernel)
     constexpr bool TIMERS = DEVTOOLS;
@@ -1236,6 +1238,11 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
     const uint64_t t = large_list[task_of_block(blockIdx.x, gridDim.x, xcd_chunk)];
     const uint64_t r = task_row[t];
     const uint64_t jt = t - first_task[r], nt = ntasks[r];
+    // The structure of a large row is walked ONCE: the counting kernel leaves the bitmap of every window in global memory
+    // (kept_bm: one bit per column of B for every large row, at the slot of the row's first task; plan-owned, bounded), the
+    // numeric kernel reads it back — 8 coalesced bytes per 64 columns — instead of walking the row's entries of B a second
+    // time for their bits (rounds 1 to 3: 20 % of this kernel and 30 GB of fabric traffic on config 5).
+    unsigned long long *__restrict__ gbm = kept_bm ? kept_bm + large_slot[r] * kept_words : nullptr;
     // window width of this row: what row_work_kernel chose (2^winlog, narrower for heavy rows: their tasks ARE windows);
     // the counting kernel is launched in a wider layout (no accumulators) and walks a one-task row in its own, wider windows
     const uint32_t wl = (!NUMERIC && nt == 1) ? (uint32_t)WL : (uint32_t)wlog[r];
@@ -1286,6 +1293,17 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
         // ---- bit pass -------------------------------------------------------------------------------
         uint32_t k_total = 0;
         bool any = false;
+        if (NUMERIC && gbm) {
+            // the bitmap the counting pass kept; the k's of a one-group row are staged all the same (the single-pass walk
+            // below uses kS / kP / kA as they are left here), a row of several groups decides by the count of set bits
+            for (int i = tid; i < words; i += LG_BLOCK) bm[i] = gbm[(wlo >> 6) + (uint64_t)i];
+            if (one_group) {
+                k_total = stage_compact<K_CAP>(mine_k ? (uint32_t)(we - ws) : 0u, ws, rav, kS, kP, values ? kA : (double *)nullptr, wt);
+                any = k_total != 0;
+            } else {
+                any = true;
+            }
+        } else
         for (uint64_t kc = as; kc < ae; kc += K_CAP) {
             const uint32_t n = (ae - kc < (uint64_t)K_CAP) ? (uint32_t)(ae - kc) : (uint32_t)K_CAP;
             const uint32_t gtot =
@@ -1297,10 +1315,16 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
         }
         lds_barrier();
         mark(1);
-        if (!any) continue;                                  // block-uniform; the bitmap is still clear
+        if (!any) {                                          // block-uniform; the bitmap is still clear
+            if (!NUMERIC && gbm)
+                for (int i = tid; i < words; i += LG_BLOCK) gbm[(wlo >> 6) + (uint64_t)i] = 0ull;
+            continue;
+        }
         if constexpr (!NUMERIC) {
             for (int i = tid; i < words; i += LG_BLOCK) {
-                fresh += (uint32_t)__popcll(bm[i]);
+                const unsigned long long wbits = bm[i];
+                fresh += (uint32_t)__popcll(wbits);
+                if (gbm) gbm[(wlo >> 6) + (uint64_t)i] = wbits;
                 bm[i] = 0;
             }
             lds_barrier();
@@ -1334,6 +1358,7 @@ __global__ __launch_bounds__(LG_BLOCK, OCC) void large_rows_kernel(CsrView<IDX, 
             if (tid == 0) super[nsb] = wtot;
             lds_barrier();
             mark(2);
+            if (wtot == 0) continue;                               // block-uniform (a kept bitmap without a set bit: it is clear already)
             // indices come out sorted: the set bits of each word in order.  They are STAGED in LDS (the accumulators are idle until
             // the passes start: room for 2 ACC_CAP column offsets at a time) and written out one rank per thread — 512 contiguous
             // bytes per wave instruction.  (Written straight from the bit loops, a store instruction hit 64 scattered 8-byte places;
@@ -1492,7 +1517,8 @@ struct sprs_hip_spgemm_plan {
     uint64_t ntask_total = 0, n_small = 0, n_mid = 0, n_large = 0, n_tiny = 0, c_nnz = 0, nb = 0;
     int64_t winlog = 17, midwin = 14;
     uint32_t xcd_chunk = 0;        // how the launch deals the task list to the XCDs (task_of_block)
-    sprs_hip::DevBuf bcol32, bpack, bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, mid_list, large_list, count, off, counters;
+    uint64_t kept_words = 0;       // 64-bit words per row of the kept bitmaps (0: none kept)
+    sprs_hip::DevBuf bcol32, bpack, large_slot, kept_bm, bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, mid_list, large_list, count, off, counters;
 };
 
 namespace sprs_hip {
@@ -1645,7 +1671,8 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         B.col32 = pl->bcol32.as<uint32_t>();
     }
 
-    DevBuf is_tiny, is_small, is_mid, n_large_r, pos_tiny, pos_small, pos_mid, pos_large, large_key, mid_key, cls;
+    DevBuf is_tiny, is_small, is_mid, n_large_r, pos_tiny, pos_small, pos_mid, large_key, mid_key, cls;
+    DevBuf &pos_large = pl->large_slot;      // slot of a large row's bitmap = position of its first task in the (unsorted) large list
     SPRS_TRY_HIP(pl->ub.alloc(rows * 8));
     SPRS_TRY_HIP(pl->wlog.alloc(rows));
     SPRS_TRY_HIP(pl->ntasks.alloc(rows * 8));
@@ -1722,7 +1749,23 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, false, 1>), g, blk, 0, stream, A, B, b_cols,                    \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
                        pl->ntasks.as<uint64_t>(), (const uint8_t *)pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(), (const uint64_t *)nullptr, (IDX *)nullptr, \
-                       (double *)nullptr, pl->xcd_chunk, 0u, (unsigned long long *)nullptr, (const uint64_t *)nullptr)
+                       (double *)nullptr, pl->xcd_chunk, 0u, (unsigned long long *)nullptr, (const uint64_t *)nullptr,       \
+                       pl->large_slot.as<uint64_t>(), pl->kept_words ? pl->kept_bm.as<unsigned long long>() : (unsigned long long *)nullptr, pl->kept_words)
+        // bitmaps of the large rows, kept for the numeric phase (one bit per column per large task slot; config 5: 3.8 GB):
+        // bounded by 16 GiB and by a quarter of the free device memory, otherwise the numeric kernel walks for its bits
+        pl->kept_words = 0;
+        if (options().spgemm_keep_bits) {
+            const uint64_t words_row = ((b_cols + SUPER_WORDS * 64 - 1) / (SUPER_WORDS * 64)) * SUPER_WORDS;
+            const uint64_t bytes = n_large * words_row * 8;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= (16ull << 30) && bytes <= free_b / 4 &&
+                pl->kept_bm.alloc(bytes) == hipSuccess) {
+                pl->kept_words = words_row;
+            } else {
+                (void)hipGetLastError();
+                clear_error();
+            }
+        }
         switch (pl->winlog) {                    // (counting: one layout wider than the numeric kernel's)
             case 16: SPRS_LG_SYM(17); break;
             case 18: SPRS_LG_SYM(19); break;
@@ -1828,7 +1871,8 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     hipLaunchKernelGGL((large_rows_kernel<WL, IDX, PTR, true, OCC>), g, blk, 0, stream, A, B, pl->b_cols,            \
                        pl->large_list.as<uint64_t>(), pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(),    \
                        pl->ntasks.as<uint64_t>(), (const uint8_t *)pl->wlog.as<uint8_t>(), pl->count.as<uint64_t>(), pl->off.as<uint64_t>(), c_indices, \
-                       c_values, pl->xcd_chunk, flags, prof.as<unsigned long long>(), pl->ub.as<uint64_t>())
+                       c_values, pl->xcd_chunk, flags, prof.as<unsigned long long>(), pl->ub.as<uint64_t>(),                      \
+                       pl->large_slot.as<uint64_t>(), pl->kept_words ? pl->kept_bm.as<unsigned long long>() : (unsigned long long *)nullptr, pl->kept_words)
         DevBuf prof;
         if (DEVTOOLS && options().spgemm_prof) {
             SPRS_TRY_HIP(prof.alloc((n_large + 40) * 8));

@@ -26,7 +26,7 @@ def main():
     if len(sys.argv) > 6:
         import sprs_amd
         sprs_amd.set_option("spgemm_bucket", int(sys.argv[6]))
-    for name in ("winlog", "heavy", "bucket", "minwin", "lds_atomic", "occupancy", "task_order", "xcd_chunk", "debug", "mid", "midwin", "overlap", "tokens", "midwin_sym", "ordered", "lane_order", "mid_keep", "mid_keep_sym"):          # SPGEMM_WINLOG=17 SPGEMM_HEAVY=262144 ...
+    for name in ("winlog", "heavy", "bucket", "minwin", "lds_atomic", "occupancy", "task_order", "xcd_chunk", "debug", "mid", "midwin", "overlap", "tokens", "midwin_sym", "ordered", "lane_order", "mid_keep", "mid_keep_sym", "keep_bits"):          # SPGEMM_WINLOG=17 SPGEMM_HEAVY=262144 ...
         v = os.environ.get("SPGEMM_" + name.upper())
         if v:
             import sprs_amd
