@@ -432,6 +432,11 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter()
+    step(x)                                             # the first multiply builds the plan cached in the handle
+    torch.cuda.synchronize()
+    first_step_s = time.perf_counter() - t_plan
     for _ in range(args.warmup):
         step(x)
     torch.cuda.synchronize()
@@ -483,6 +488,11 @@ def main():
             return round(float(tt.item()) * 1e3 / k, 5)
         k2 = max(3, args.steps // 2)
         exchange_times = {"timed_route": "lib" if use_lib else "torch", "steps_each": k2}
+        if libdist is not None:
+            try:
+                exchange_times["rccl_comm_ranks"] = libdist.comm_count()     # what the communicator itself says (ncclCommCount)
+            except Exception as e:
+                exchange_times["rccl_comm_ranks"] = "failed: " + repr(e)[:120]
         for label, fn in (("multiply_only_ms", multiply_only), ("torch_route_ms", torch_step),
                           ("lib_route_ms", lib_step if libdist is not None else None)):
             try:
@@ -539,6 +549,8 @@ def main():
                           (world, "sprs_hip_dist_*, RCCL inside the library" if use_lib else "torch.distributed grouped send/recv on RCCL"))
                          if world > 1 else "single GPU",
             "generate_s": round(gen_s, 2),
+            # once per handle, never part of `value`: the first multiply (plan build + one SpMV) minus a steady-state step
+            "plan_build_s": round(max(0.0, first_step_s - ms_per_step * 1e-3), 4),
         },
         "roofline": {
             "bound": "hbm",
@@ -593,6 +605,59 @@ def main():
         }
         out["parity"] = {"max_rel_err_vs_oracle": float(rel.max()), "tolerance": 1e-10,
                          "ok": bool(rel.max() <= 1e-10)}
+        # NOT in the reference (sprs' SpMV is serial): the same loop split over the host's cores by rows with OpenMP, for scale
+        try:
+            ncpu = os.cpu_count() or 1
+            ts = []
+            for _ in range(2):
+                y_o = np.zeros(n)
+                t = time.perf_counter()
+                oracle.mul_acc_mat_vec_csr((n, n), ip_h, ix_h, dt_h, x_h, y_o, threads=ncpu)
+                ts.append(time.perf_counter() - t)
+            out["cpu_baseline"]["all_cores_openmp"] = {"value": round(2.0 * nnz_total / min(ts) / 1e9, 3), "unit": "GFLOP/s", "cores": ncpu,
+                                                        "seconds": round(min(ts), 4), "note": "not in reference: OpenMP row split of the same loop"}
+        except Exception as e:
+            out["cpu_baseline"]["all_cores_openmp"] = {"error": repr(e)[:160]}
+        # PCIe-inclusive note (never part of `value`): the host arrays uploaded once through the boundary's host entry
+        try:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            up = DeviceCsMat.from_host((n, n), ip_h, ix_h, dt_h)
+            _ffi.check(_ffi.lib.sprs_hip_synchronize(None))
+            out["config"]["h2d_upload_s"] = round(time.perf_counter() - t, 4)
+            del up
+        except Exception as e:
+            out["config"]["h2d_upload_s"] = "failed: " + repr(e)[:120]
+
+    # ---- the same matrix with u32 indices and indptr (a second line, 12 B per entry, never mixed with the headline) ----
+    if rank == 0 and world == 1 and wl == "rmat10m" and args.idx_bytes == 8 and not args.no_secondary:
+        try:
+            ip4, ix4, dt4 = gen.rmat_csr(n, 32, device=dev, idx_dtype=torch.int32, ptr_dtype=torch.int32)
+            a4 = DeviceCsMat.wrap_torch((n, n), ip4, ix4, dt4)
+            y4 = DeviceVec.borrow(torch.empty(n, dtype=torch.float64, device=dev))
+            xv = DeviceVec.borrow(x)
+            for _ in range(3):
+                prod.csmat_mul_vec(a4, xv, out=y4, stream=stream)
+            torch.cuda.synchronize()
+            k4 = max(5, args.steps // 2)
+            ev4 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k4)]
+            for p_, q_ in ev4:
+                p_.record(stream)
+                prod.csmat_mul_vec(a4, xv, out=y4, stream=stream)
+                q_.record(stream)
+            torch.cuda.synchronize()
+            ms4 = float(np.mean([p_.elapsed_time(q_) for p_, q_ in ev4]))
+            nnz4 = int(ix4.numel())
+            b4 = algorithmic_bytes(n, n, nnz4, 4, 4)
+            pk4, pb4 = a4.spmv_plan_info()
+            out["spmv_u32"] = {"workload": name + ", u32 indices and indptr", "nnz": nnz4, "steps": k4, "kernel_ms_avg": round(ms4, 5),
+                               "gflops": round(2.0 * nnz4 / (ms4 * 1e-3) / 1e9, 2), "algorithmic_bytes_per_launch": b4,
+                               "achieved_GBs": round(b4 / (ms4 * 1e-3) / 1e9, 2), "frac": round(b4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "plan_bytes": pb4}
+            del a4, ip4, ix4, dt4, y4
+            torch.cuda.empty_cache()
+        except Exception as e:   # the headline line must not depend on the secondary measurement
+            out["spmv_u32"] = {"error": repr(e)[:200]}
 
     # ---- BASELINE config 5 beside the headline (rank 0, N = 1, default workload): a short SpGEMM object -----------
     if rank == 0 and world == 1 and wl == "rmat10m" and not args.no_secondary and not args.no_cpu_baseline:

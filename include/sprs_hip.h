@@ -52,6 +52,9 @@ extern "C" {
 /* CompressedStorage, sprs/src/sparse.rs:30-40 */
 #define SPRS_HIP_CSR 0
 #define SPRS_HIP_CSC 1
+/* dense operands: C order (ndarray's standard layout) or Fortran order (`.f()`), with a leading dimension */
+#define SPRS_HIP_ROW_MAJOR 0
+#define SPRS_HIP_COL_MAJOR 1
 
 /* Thread-local text of the last failure on the calling thread ("" if none),
  * and the raw hipError_t behind a SPRS_HIP_HIP_ERROR (0 otherwise). */
@@ -176,6 +179,48 @@ int32_t sprs_hip_spmv_f64_host(uint64_t rows, uint64_t cols, const void *indptr,
 int32_t sprs_hip_spmm_rowmaj_f64(const sprs_hip_csmat *a, const double *rhs_dev, uint64_t rhs_rows,
                                  uint64_t k, uint64_t ld_rhs, double *out_dev, uint64_t out_rows,
                                  uint64_t ld_out, int32_t accumulate, void *stream);
+
+/* ---- products with dense operands: the operator dispatch below the ABI --------------------------- */
+
+/* Twin of prod::mul_acc_mat_vec_csc (prod.rs:74-99): y += A x for a CSC matrix.  SPRS_HIP_DIM_MISMATCH unless
+ * A.cols == x_len && A.rows == y_len, then SPRS_HIP_STORAGE_MISMATCH unless A is CSC (prod.rs:88-92).  The reference scatters
+ * column by column; here the matrix is converted ONCE to CSR on the device (to_other_storage, csmat.rs:1405-1426), the copy is
+ * cached in the handle (dropped by sprs_hip_csmat_refresh / _free) and the CSR kernels run on it: every y[i] still receives
+ * its products by ascending column. */
+int32_t sprs_hip_mul_acc_mat_vec_csc_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t x_len, double *y_dev,
+                                         uint64_t y_len, void *stream);
+
+/* Twin of `&CsMat * &Array1` and its Dot (csmat.rs:2119-2178): y = A x on a zeroed result for EITHER storage —
+ * CSR -> csr_mulacc_dense_colmaj, CSC -> csc_mulacc_dense_colmaj with one column (csmat.rs:2140-2156), the latter on the cached
+ * CSR form.  SPRS_HIP_DIM_MISMATCH as the kernels' asserts (prod.rs:257-259, 284-289). */
+int32_t sprs_hip_csmat_mul_vec_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t x_len, double *y_dev,
+                                   uint64_t y_len, void *stream);
+
+/* The four dense kernels of prod.rs in one entry: csr_mulacc_dense_rowmaj / _colmaj (prod.rs:189-214, 274-298) and
+ * csc_mulacc_dense_rowmaj / _colmaj (prod.rs:219-270):  out += lhs * rhs  (accumulate != 0) or  out = lhs * rhs  on a zeroed
+ * out (accumulate == 0), lhs in either storage (CSC through the cached CSR form), rhs (rhs_rows x k) and out (out_rows x k)
+ * each in the layout its tag names with leading dimension ld (row-major: >= k, column-major: >= rows).  The reference's four
+ * functions differ in the loop order only (every out[i, j] receives its products by ascending column index in all of them);
+ * the layouts tell this entry how to address the operands.  Column-major x column-major with k < 8 — what `&CsMat * &Array2`
+ * makes for fewer than 8 columns — runs column by column through the SpMV.  SPRS_HIP_DIM_MISMATCH unless lhs.cols == rhs_rows
+ * && lhs.rows == out_rows (prod.rs:199-201, 228-230, 257-259, 284-289). */
+int32_t sprs_hip_csmat_mulacc_dense_f64(const sprs_hip_csmat *lhs, const double *rhs_dev, uint64_t rhs_rows, uint64_t k,
+                                        int32_t rhs_layout, uint64_t ld_rhs, double *out_dev, uint64_t out_rows,
+                                        int32_t out_layout, uint64_t ld_out, int32_t accumulate, void *stream);
+
+/* Twin of `&CsMat * &Array2` / `CsMat::dot(&Array2)` (csmat.rs:1989-2048, 2119-2137): the four arms (CSR | CSC) x (>= 8 columns |
+ * fewer).  out_dev: lhs.rows x k doubles, contiguous; written in the layout the reference allocates — row-major for k >= 8,
+ * column-major (`.f()`) below — which *out_layout reports. */
+int32_t sprs_hip_csmat_mul_dense_f64(const sprs_hip_csmat *lhs, const double *rhs_dev, uint64_t rhs_rows, uint64_t k,
+                                     int32_t rhs_layout, uint64_t ld_rhs, double *out_dev, int32_t *out_layout, void *stream);
+
+/* Twin of `Array2::dot(&CsMat)` (csmat.rs:2050-2117): lhs (lhs_rows x lhs_cols, dense) . rhs (sparse) as (rhs^T lhs^T)^T with
+ * the reference's free transposes (transpose_view, .t(), reversed_axes).  out_dev: lhs_rows x rhs.cols doubles, contiguous, in
+ * the layout *out_layout reports (the reversed axes of what the transposed product allocates).  Synchronous (the transposed
+ * operand is a temporary view).  A CSR rhs is converted once to CSC (cached in the handle). */
+int32_t sprs_hip_dense_dot_csmat_f64(const double *lhs_dev, uint64_t lhs_rows, uint64_t lhs_cols, int32_t lhs_layout,
+                                     uint64_t ld_lhs, const sprs_hip_csmat *rhs, double *out_dev, int32_t *out_layout,
+                                     void *stream);
 
 /* ---- BiCGSTAB: a caller that loops on the SpMV -------------- */
 
@@ -315,6 +360,8 @@ int32_t sprs_hip_dist_create(sprs_hip_dist **d, const void *id_128_bytes, int32_
                              int32_t nsub);
 int32_t sprs_hip_dist_spmv_f64(sprs_hip_dist *d, const double *x_dev, uint64_t x_len, double *y_dev, uint64_t y_len,
                                void *stream);
+/* the rank count the RCCL communicator itself reports (ncclCommCount); a world of one has no communicator and reports 1 */
+int32_t sprs_hip_dist_comm_count(const sprs_hip_dist *d, int32_t *ranks);
 int32_t sprs_hip_dist_free(sprs_hip_dist *d);
 
 /* Triplet (COO) assembly: twin of TriMatBase::to_csr / to_csc (triplet.rs:262-276) = TriMatIter::into_cs

@@ -125,12 +125,61 @@ private:
     sprs_hip_csmat *h_ = nullptr;
 };
 
+// Dense f64 matrix in HBM in one of ndarray's two contiguous layouts: `Array2` in standard (row-major) order or
+// `Array::zeros(shape.f())` (column-major) — what `&CsMat * &Array2` returns for fewer than 8 columns (csmat.rs:2017-2024).
+class DeviceMat {
+public:
+    DeviceMat(uint64_t rows, uint64_t cols, bool col_major = false) : buf_(rows * cols), rows_(rows), cols_(cols), col_major_(col_major) {}
+    // elements in memory order of the chosen layout
+    DeviceMat(uint64_t rows, uint64_t cols, const std::vector<double> &elems, bool col_major = false)
+        : buf_(elems), rows_(rows), cols_(cols), col_major_(col_major) {
+        if (elems.size() != rows * cols) throw Error(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    }
+    uint64_t rows() const { return rows_; }
+    uint64_t cols() const { return cols_; }
+    bool is_standard_layout() const { return !col_major_; }
+    int32_t layout() const { return col_major_ ? SPRS_HIP_COL_MAJOR : SPRS_HIP_ROW_MAJOR; }
+    uint64_t ld() const { return col_major_ ? rows_ : cols_; }
+    double *ptr() { return buf_.ptr(); }
+    const double *ptr() const { return buf_.ptr(); }
+    void set_layout(int32_t layout) { col_major_ = layout == SPRS_HIP_COL_MAJOR; }
+    double at(const std::vector<double> &host, uint64_t i, uint64_t j) const { return col_major_ ? host[j * rows_ + i] : host[i * cols_ + j]; }
+    std::vector<double> to_host() const { return buf_.to_host(); }       // memory order
+
+private:
+    DeviceVec buf_;
+    uint64_t rows_, cols_;
+    bool col_major_;
+};
+
 namespace prod {
 // prod::mul_acc_mat_vec_csr (prod.rs:103-127): res_vec += mat * in_vec
 inline void mul_acc_mat_vec_csr(const DeviceCsMat &mat, const DeviceVec &in_vec, DeviceVec &res_vec,
                                 void *stream = nullptr) {
     check(sprs_hip_spmv_f64(mat.handle(), in_vec.ptr(), in_vec.dim(), res_vec.ptr(), res_vec.dim(), 1, stream));
 }
+// prod::mul_acc_mat_vec_csc (prod.rs:74-99): res_vec += mat * in_vec for a CSC matrix
+inline void mul_acc_mat_vec_csc(const DeviceCsMat &mat, const DeviceVec &in_vec, DeviceVec &res_vec, void *stream = nullptr) {
+    check(sprs_hip_mul_acc_mat_vec_csc_f64(mat.handle(), in_vec.ptr(), in_vec.dim(), res_vec.ptr(), res_vec.dim(), stream));
+}
+namespace detail {
+inline void mulacc_dense(const DeviceCsMat &lhs, bool want_csr, const DeviceMat &rhs, DeviceMat &out, void *stream) {
+    if (rhs.cols() != out.cols()) throw Error(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");       // prod.rs:201, 230, 259, 287
+    if (lhs.is_csr() != want_csr) {                                                                // prod.rs:202, 231, 258, 288 (after the dimensions)
+        if (lhs.cols() != rhs.rows() || lhs.rows() != out.rows()) throw Error(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+        throw Error(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    }
+    check(sprs_hip_csmat_mulacc_dense_f64(lhs.handle(), rhs.ptr(), rhs.rows(), rhs.cols(), rhs.layout(), rhs.ld(), out.ptr(),
+                                          out.rows(), out.layout(), out.ld(), 1, stream));
+}
+}  // namespace detail
+// prod::csr_mulacc_dense_rowmaj / _colmaj (prod.rs:189-214, 274-298), csc_mulacc_dense_rowmaj / _colmaj (prod.rs:219-270):
+// out += lhs * rhs.  In the reference the four differ in their loop order; the device entry is told by the operands' own
+// layouts how to address them.
+inline void csr_mulacc_dense_rowmaj(const DeviceCsMat &lhs, const DeviceMat &rhs, DeviceMat &out, void *stream = nullptr) { detail::mulacc_dense(lhs, true, rhs, out, stream); }
+inline void csr_mulacc_dense_colmaj(const DeviceCsMat &lhs, const DeviceMat &rhs, DeviceMat &out, void *stream = nullptr) { detail::mulacc_dense(lhs, true, rhs, out, stream); }
+inline void csc_mulacc_dense_rowmaj(const DeviceCsMat &lhs, const DeviceMat &rhs, DeviceMat &out, void *stream = nullptr) { detail::mulacc_dense(lhs, false, rhs, out, stream); }
+inline void csc_mulacc_dense_colmaj(const DeviceCsMat &lhs, const DeviceMat &rhs, DeviceMat &out, void *stream = nullptr) { detail::mulacc_dense(lhs, false, rhs, out, stream); }
 }  // namespace prod
 
 namespace smmp {
@@ -156,11 +205,82 @@ inline void numeric(const DeviceCsMat &lhs, const DeviceCsMat &rhs, DeviceCsMat 
 }
 }  // namespace smmp
 
-inline DeviceVec operator*(const DeviceCsMat &a, const DeviceVec &x) {
+inline DeviceVec operator*(const DeviceCsMat &a, const DeviceVec &x) {      // CSR or CSC: dispatched below the C ABI (csmat.rs:2140-2156)
     DeviceVec y(a.rows());
-    check(sprs_hip_spmv_f64(a.handle(), x.ptr(), x.dim(), y.ptr(), y.dim(), 0, nullptr));
+    check(sprs_hip_csmat_mul_vec_f64(a.handle(), x.ptr(), x.dim(), y.ptr(), y.dim(), nullptr));
     return y;
 }
+
+// `&A * &M` (csmat.rs:1989-2048): the four arms (CSR | CSC) x (>= 8 columns | fewer) below the C ABI; the result is in standard
+// layout from 8 columns on and in `.f()` layout below, like the reference's
+inline DeviceMat operator*(const DeviceCsMat &a, const DeviceMat &m) {
+    DeviceMat out(a.rows(), m.cols());
+    int32_t lay = SPRS_HIP_ROW_MAJOR;
+    check(sprs_hip_csmat_mul_dense_f64(a.handle(), m.ptr(), m.rows(), m.cols(), m.layout(), m.ld(), out.ptr(), &lay, nullptr));
+    out.set_layout(lay);
+    return out;
+}
+
+// `Array2::dot(&CsMat)` (csmat.rs:2050-2117): dense . sparse
+inline DeviceMat dot(const DeviceMat &lhs, const DeviceCsMat &rhs) {
+    DeviceMat out(lhs.rows(), rhs.cols());
+    int32_t lay = SPRS_HIP_ROW_MAJOR;
+    check(sprs_hip_dense_dot_csmat_f64(lhs.ptr(), lhs.rows(), lhs.cols(), lhs.layout(), lhs.ld(), rhs.handle(), out.ptr(), &lay, nullptr));
+    out.set_layout(lay);
+    return out;
+}
+
+// TriMatBase::to_csr / to_csc (triplet_iter.rs:127-224) for triplets in HBM: sorted by (row, col), duplicates summed in
+// triplet order — the device assembly kernel (sprs_hip_triplets_to_cs), usize indices
+inline DeviceCsMat triplets_to_cs(uint64_t rows, uint64_t cols, const std::vector<uint64_t> &row_inds, const std::vector<uint64_t> &col_inds,
+                                  const std::vector<double> &data, int32_t storage = SPRS_HIP_CSR) {
+    if (row_inds.size() != data.size() || col_inds.size() != data.size()) throw Error(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    const uint64_t n = data.size();
+    void *r = nullptr, *c = nullptr;
+    DeviceVec v(data);
+    check(sprs_hip_malloc(&r, n * 8));
+    if (int32_t st = sprs_hip_malloc(&c, n * 8)) { sprs_hip_free(r); check(st); }
+    sprs_hip_csmat *h = nullptr;
+    int32_t st = sprs_hip_memcpy_h2d(r, row_inds.data(), n * 8);
+    if (st == SPRS_HIP_OK) st = sprs_hip_memcpy_h2d(c, col_inds.data(), n * 8);
+    if (st == SPRS_HIP_OK) st = sprs_hip_triplets_to_cs(rows, cols, n, r, c, 8, v.ptr(), storage, 8, 8, &h);
+    sprs_hip_free(r);
+    sprs_hip_free(c);
+    check(st);
+    return DeviceCsMat(h);
+}
+
+// Row-sharded SpMV over the GPUs of one node (no counterpart in the reference; the shard of a rank is a.slice_outer(r0..r1),
+// slicing.rs:65-89): one process per GPU; DistSpMV::unique_id() on one rank, handed to all (MPI, a file, ...)
+class DistSpMV {
+public:
+    static std::vector<unsigned char> unique_id() {
+        std::vector<unsigned char> id(128);
+        check(sprs_hip_dist_unique_id(id.data()));
+        return id;
+    }
+    DistSpMV(const std::vector<unsigned char> &id, int32_t world, int32_t rank, uint64_t rows, uint64_t cols,
+             const std::vector<uint64_t> &row_starts, const DeviceCsMat &local_block, int32_t nsub = 2) {
+        if ((int64_t)row_starts.size() != (int64_t)world + 1) throw Error(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+        check(sprs_hip_dist_create(&d_, world > 1 ? id.data() : nullptr, world, rank, rows, cols, row_starts.data(), local_block.handle(), nsub));
+    }
+    DistSpMV(const DistSpMV &) = delete;
+    DistSpMV &operator=(const DistSpMV &) = delete;
+    ~DistSpMV() {
+        if (d_) sprs_hip_dist_free(d_);
+    }
+    void mul(const DeviceVec &x, DeviceVec &y, void *stream = nullptr) {     // collective: y = A * x
+        check(sprs_hip_dist_spmv_f64(d_, x.ptr(), x.dim(), y.ptr(), y.dim(), stream));
+    }
+    int32_t comm_count() const {                                             // ranks of the RCCL communicator (ncclCommCount)
+        int32_t n = 0;
+        check(sprs_hip_dist_comm_count(d_, &n));
+        return n;
+    }
+
+private:
+    sprs_hip_dist *d_ = nullptr;
+};
 
 // `&A * &B` (csmat.rs:1866-1888)
 // `&A * &B`: csmat_mul_csmat (csmat.rs:1895-1949) — the storage dispatch is done below the C ABI

@@ -14,6 +14,8 @@ pub const SPRS_HIP_HIP_ERROR: i32 = 7;
 pub const SPRS_HIP_NO_DEVICE: i32 = 8;
 pub const SPRS_HIP_CSR: i32 = 0;
 pub const SPRS_HIP_CSC: i32 = 1;
+pub const SPRS_HIP_ROW_MAJOR: i32 = 0;
+pub const SPRS_HIP_COL_MAJOR: i32 = 1;
 
 #[repr(C)]
 pub struct sprs_hip_spgemm_plan {
@@ -112,6 +114,24 @@ extern "C" {
         a: *const sprs_hip_csmat, rhs_dev: *const f64, rhs_rows: u64, k: u64, ld_rhs: u64,
         out_dev: *mut f64, out_rows: u64, ld_out: u64, accumulate: i32, stream: *mut c_void,
     ) -> i32;
+    pub fn sprs_hip_mul_acc_mat_vec_csc_f64(
+        a: *const sprs_hip_csmat, x_dev: *const f64, x_len: u64, y_dev: *mut f64, y_len: u64, stream: *mut c_void,
+    ) -> i32;
+    pub fn sprs_hip_csmat_mul_vec_f64(
+        a: *const sprs_hip_csmat, x_dev: *const f64, x_len: u64, y_dev: *mut f64, y_len: u64, stream: *mut c_void,
+    ) -> i32;
+    pub fn sprs_hip_csmat_mulacc_dense_f64(
+        lhs: *const sprs_hip_csmat, rhs_dev: *const f64, rhs_rows: u64, k: u64, rhs_layout: i32, ld_rhs: u64,
+        out_dev: *mut f64, out_rows: u64, out_layout: i32, ld_out: u64, accumulate: i32, stream: *mut c_void,
+    ) -> i32;
+    pub fn sprs_hip_csmat_mul_dense_f64(
+        lhs: *const sprs_hip_csmat, rhs_dev: *const f64, rhs_rows: u64, k: u64, rhs_layout: i32, ld_rhs: u64,
+        out_dev: *mut f64, out_layout: *mut i32, stream: *mut c_void,
+    ) -> i32;
+    pub fn sprs_hip_dense_dot_csmat_f64(
+        lhs_dev: *const f64, lhs_rows: u64, lhs_cols: u64, lhs_layout: i32, ld_lhs: u64, rhs: *const sprs_hip_csmat,
+        out_dev: *mut f64, out_layout: *mut i32, stream: *mut c_void,
+    ) -> i32;
     pub fn sprs_hip_spgemm_f64(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_spgemm_symbolic(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c_structure: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_spgemm_numeric(a: *const sprs_hip_csmat, b: *const sprs_hip_csmat, c: *mut sprs_hip_csmat) -> i32;
@@ -128,6 +148,7 @@ extern "C" {
         row_starts: *const u64, local_block: *const sprs_hip_csmat, nsub: i32,
     ) -> i32;
     pub fn sprs_hip_dist_spmv_f64(d: *mut sprs_hip_dist, x_dev: *const f64, x_len: u64, y_dev: *mut f64, y_len: u64, stream: *mut c_void) -> i32;
+    pub fn sprs_hip_dist_comm_count(d: *const sprs_hip_dist, ranks: *mut i32) -> i32;
     pub fn sprs_hip_dist_free(d: *mut sprs_hip_dist) -> i32;
     pub fn sprs_hip_csmat_mul_csmat(lhs: *const sprs_hip_csmat, rhs: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_triplets_to_cs(

@@ -156,12 +156,150 @@ impl Drop for DeviceCsMat {
     }
 }
 
+/// A dense f64 matrix in HBM with ndarray's two contiguous layouts: `Array2` in standard (row-major) order or `.f()` order.
+pub struct DeviceMat {
+    buf: DeviceVec,
+    rows: usize,
+    cols: usize,
+    col_major: bool,
+}
+
+impl DeviceMat {
+    pub fn zeros(shape: (usize, usize)) -> Self {
+        DeviceMat { buf: DeviceVec::zeros(shape.0 * shape.1), rows: shape.0, cols: shape.1, col_major: false }
+    }
+    /// `Array::zeros(shape.f())`
+    pub fn zeros_f(shape: (usize, usize)) -> Self {
+        DeviceMat { buf: DeviceVec::zeros(shape.0 * shape.1), rows: shape.0, cols: shape.1, col_major: true }
+    }
+    /// from an ndarray in standard layout (`as_slice()` order)
+    pub fn from_rows(shape: (usize, usize), row_major: &[f64]) -> Self {
+        assert_eq!(shape.0 * shape.1, row_major.len(), "Dimension mismatch");
+        DeviceMat { buf: DeviceVec::from_slice(row_major), rows: shape.0, cols: shape.1, col_major: false }
+    }
+    pub fn shape(&self) -> (usize, usize) { (self.rows, self.cols) }
+    pub fn is_standard_layout(&self) -> bool { !self.col_major }
+    /// the elements in memory order (row-major, or column-major when `!is_standard_layout()`)
+    pub fn to_vec(&self) -> Vec<f64> { self.buf.to_vec() }
+    fn layout(&self) -> i32 { if self.col_major { sys::SPRS_HIP_COL_MAJOR } else { sys::SPRS_HIP_ROW_MAJOR } }
+    fn ld(&self) -> u64 { (if self.col_major { self.rows } else { self.cols }) as u64 }
+}
+
 pub mod prod {
     use super::*;
     /// Twin of `sprs::prod::mul_acc_mat_vec_csr` (prod.rs:103-127): `res_vec += mat * in_vec`.
     pub fn mul_acc_mat_vec_csr(mat: &DeviceCsMat, in_vec: &DeviceVec, res_vec: &mut DeviceVec) {
         unsafe {
             check(sys::sprs_hip_spmv_f64(mat.h, in_vec.ptr, in_vec.len as u64, res_vec.ptr, res_vec.len as u64, 1, std::ptr::null_mut()));
+        }
+    }
+    /// Twin of `sprs::prod::mul_acc_mat_vec_csc` (prod.rs:74-99): `res_vec += mat * in_vec` for a CSC matrix.
+    pub fn mul_acc_mat_vec_csc(mat: &DeviceCsMat, in_vec: &DeviceVec, res_vec: &mut DeviceVec) {
+        unsafe {
+            check(sys::sprs_hip_mul_acc_mat_vec_csc_f64(mat.h, in_vec.ptr, in_vec.len as u64, res_vec.ptr, res_vec.len as u64, std::ptr::null_mut()));
+        }
+    }
+    fn mulacc_dense(lhs: &DeviceCsMat, rhs: &DeviceMat, out: &mut DeviceMat) {
+        assert_eq!(rhs.cols, out.cols, "Dimension mismatch");                       // prod.rs:201
+        unsafe {
+            check(sys::sprs_hip_csmat_mulacc_dense_f64(lhs.h, rhs.buf.ptr, rhs.rows as u64, rhs.cols as u64, rhs.layout(), rhs.ld(),
+                                                       out.buf.ptr, out.rows as u64, out.layout(), out.ld(), 1, std::ptr::null_mut()));
+        }
+    }
+    /// Twins of `csr_mulacc_dense_rowmaj` / `_colmaj` (prod.rs:189-214, 274-298) and `csc_mulacc_dense_rowmaj` / `_colmaj`
+    /// (prod.rs:219-270): `out += lhs * rhs`.  The four differ in their loop order in the reference; on the device one entry
+    /// serves them, told by the operands' own layouts how to address them; the storage asserts are the reference's.
+    pub fn csr_mulacc_dense_rowmaj(lhs: &DeviceCsMat, rhs: &DeviceMat, out: &mut DeviceMat) {
+        assert!(lhs.is_csr(), "Storage mismatch");
+        mulacc_dense(lhs, rhs, out)
+    }
+    pub fn csr_mulacc_dense_colmaj(lhs: &DeviceCsMat, rhs: &DeviceMat, out: &mut DeviceMat) {
+        assert!(lhs.is_csr(), "Storage mismatch");
+        mulacc_dense(lhs, rhs, out)
+    }
+    pub fn csc_mulacc_dense_rowmaj(lhs: &DeviceCsMat, rhs: &DeviceMat, out: &mut DeviceMat) {
+        assert!(lhs.is_csc(), "Storage mismatch");
+        mulacc_dense(lhs, rhs, out)
+    }
+    pub fn csc_mulacc_dense_colmaj(lhs: &DeviceCsMat, rhs: &DeviceMat, out: &mut DeviceMat) {
+        assert!(lhs.is_csc(), "Storage mismatch");
+        mulacc_dense(lhs, rhs, out)
+    }
+}
+
+/// Twin of `TriMatBase::to_csr` / `to_csc` (triplet_iter.rs:127-224) for triplets already in HBM: sorted by (row, col),
+/// duplicates summed in triplet order.
+pub fn triplets_to_cs(shape: (usize, usize), rows: &DeviceIdx, cols: &DeviceIdx, data: &DeviceVec, csc: bool) -> DeviceCsMat {
+    assert!(rows.len == cols.len && rows.len == data.len, "Dimension mismatch");
+    let mut h = std::ptr::null_mut();
+    unsafe {
+        check(sys::sprs_hip_triplets_to_cs(shape.0 as u64, shape.1 as u64, data.len as u64, rows.ptr, cols.ptr, 8, data.ptr,
+                                           if csc { sys::SPRS_HIP_CSC } else { sys::SPRS_HIP_CSR }, 8, 8, &mut h));
+    }
+    DeviceCsMat { h }
+}
+
+/// usize indices in HBM (the row / column arrays of a `TriMat`).
+pub struct DeviceIdx {
+    ptr: *mut c_void,
+    len: usize,
+}
+
+impl DeviceIdx {
+    pub fn from_slice(x: &[usize]) -> Self {
+        let mut p: *mut c_void = std::ptr::null_mut();
+        unsafe {
+            check(sys::sprs_hip_malloc(&mut p, (x.len() * 8) as u64));
+            check(sys::sprs_hip_memcpy_h2d(p, x.as_ptr() as *const c_void, (x.len() * 8) as u64));
+        }
+        DeviceIdx { ptr: p, len: x.len() }
+    }
+}
+
+impl Drop for DeviceIdx {
+    fn drop(&mut self) {
+        unsafe { sys::sprs_hip_free(self.ptr) };
+    }
+}
+
+/// Row-sharded SpMV over the GPUs of one node (no counterpart in the reference; the shard of a rank is
+/// `a.slice_outer(r0..r1)`, slicing.rs:65-89): one process per GPU, `unique_id()` on one rank handed to all.
+pub mod dist {
+    use super::*;
+    pub struct DistSpMV {
+        d: *mut sys::sprs_hip_dist,
+    }
+    pub fn unique_id() -> [u8; 128] {
+        let mut id = [0u8; 128];
+        unsafe { check(sys::sprs_hip_dist_unique_id(id.as_mut_ptr() as *mut c_void)) };
+        id
+    }
+    impl DistSpMV {
+        /// collective: `local_block` = this rank's rows (all columns), `row_starts` = world + 1 global row offsets
+        pub fn new(id: &[u8; 128], world: usize, rank: usize, shape: (usize, usize), row_starts: &[u64], local_block: &DeviceCsMat,
+                   nsub: usize) -> Self {
+            assert_eq!(row_starts.len(), world + 1, "Dimension mismatch");
+            let mut d = std::ptr::null_mut();
+            unsafe {
+                check(sys::sprs_hip_dist_create(&mut d, id.as_ptr() as *const c_void, world as i32, rank as i32, shape.0 as u64,
+                                                shape.1 as u64, row_starts.as_ptr(), local_block.h, nsub as i32));
+            }
+            DistSpMV { d }
+        }
+        /// collective: `y = A * x`, x replicated (length cols), y gathered on every rank (length rows)
+        pub fn mul(&self, x: &DeviceVec, y: &mut DeviceVec) {
+            unsafe { check(sys::sprs_hip_dist_spmv_f64(self.d, x.ptr, x.len as u64, y.ptr, y.len as u64, std::ptr::null_mut())) };
+        }
+        /// ranks of the RCCL communicator (ncclCommCount)
+        pub fn comm_count(&self) -> usize {
+            let mut n = 0i32;
+            unsafe { check(sys::sprs_hip_dist_comm_count(self.d, &mut n)) };
+            n as usize
+        }
+    }
+    impl Drop for DistSpMV {
+        fn drop(&mut self) {
+            unsafe { sys::sprs_hip_dist_free(self.d) };
         }
     }
 }
@@ -240,14 +378,44 @@ pub fn pool_trim() -> u64 {
     freed
 }
 
-/// `&A * &x`  (csmat.rs:2119-2160): fresh result, no accumulation.
+/// `&A * &x`  (csmat.rs:2119-2160): fresh result, no accumulation, CSR or CSC (the dispatch lives below the C ABI).
 impl<'a, 'b> std::ops::Mul<&'b DeviceVec> for &'a DeviceCsMat {
     type Output = DeviceVec;
     fn mul(self, rhs: &'b DeviceVec) -> DeviceVec {
         let out = DeviceVec::zeros(self.shape().0);
         unsafe {
-            check(sys::sprs_hip_spmv_f64(self.h, rhs.ptr, rhs.len as u64, out.ptr, out.len as u64, 0, std::ptr::null_mut()));
+            check(sys::sprs_hip_csmat_mul_vec_f64(self.h, rhs.ptr, rhs.len as u64, out.ptr, out.len as u64, std::ptr::null_mut()));
         }
+        out
+    }
+}
+
+/// `&A * &M`  (csmat.rs:1989-2048): the four arms (CSR | CSC) x (>= 8 columns | fewer) below the C ABI; the result is in
+/// standard layout for >= 8 columns and in `.f()` layout below, like the reference's.
+impl<'a, 'b> std::ops::Mul<&'b DeviceMat> for &'a DeviceCsMat {
+    type Output = DeviceMat;
+    fn mul(self, rhs: &'b DeviceMat) -> DeviceMat {
+        let mut out = DeviceMat::zeros((self.shape().0, rhs.cols));
+        let mut lay = 0i32;
+        unsafe {
+            check(sys::sprs_hip_csmat_mul_dense_f64(self.h, rhs.buf.ptr, rhs.rows as u64, rhs.cols as u64, rhs.layout(), rhs.ld(),
+                                                    out.buf.ptr, &mut lay, std::ptr::null_mut()));
+        }
+        out.col_major = lay == sys::SPRS_HIP_COL_MAJOR;
+        out
+    }
+}
+
+impl DeviceMat {
+    /// `Array2::dot(&CsMat)` (csmat.rs:2050-2117): dense . sparse
+    pub fn dot(&self, rhs: &DeviceCsMat) -> DeviceMat {
+        let mut out = DeviceMat::zeros((self.rows, rhs.shape().1));
+        let mut lay = 0i32;
+        unsafe {
+            check(sys::sprs_hip_dense_dot_csmat_f64(self.buf.ptr, self.rows as u64, self.cols as u64, self.layout(), self.ld(), rhs.h,
+                                                    out.buf.ptr, &mut lay, std::ptr::null_mut()));
+        }
+        out.col_major = lay == sys::SPRS_HIP_COL_MAJOR;
         out
     }
 }

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("SPRS_HIP_LIBRARY") or os.path.join(_HERE, "libsprs_hi
 OK, DIM_MISMATCH, STORAGE_MISMATCH, INDEX_OVERFLOW, BAD_STRUCTURE, INVALID_ARG, \
     OUT_OF_MEMORY, HIP_ERROR, NO_DEVICE = range(9)
 CSR, CSC = 0, 1
+ROW_MAJOR, COL_MAJOR = 0, 1
 
 STATUS_NAMES = {
     OK: "OK", DIM_MISMATCH: "DIM_MISMATCH", STORAGE_MISMATCH: "STORAGE_MISMATCH",
@@ -41,6 +42,12 @@ SIGNATURES = {
     "sprs_hip_memset": (i32, [vp, i32, u64, vp]),
     "sprs_hip_synchronize": (i32, [vp]),
     "sprs_hip_pool_trim": (i32, [P(u64)]),
+    "sprs_hip_mul_acc_mat_vec_csc_f64": (i32, [vp, vp, u64, vp, u64, vp]),
+    "sprs_hip_csmat_mul_vec_f64": (i32, [vp, vp, u64, vp, u64, vp]),
+    "sprs_hip_csmat_mulacc_dense_f64": (i32, [vp, vp, u64, u64, i32, u64, vp, u64, i32, u64, i32, vp]),
+    "sprs_hip_csmat_mul_dense_f64": (i32, [vp, vp, u64, u64, i32, u64, vp, P(i32), vp]),
+    "sprs_hip_dense_dot_csmat_f64": (i32, [vp, u64, u64, i32, u64, vp, vp, P(i32), vp]),
+    "sprs_hip_dist_comm_count": (i32, [vp, P(i32)]),
     "sprs_hip_spgemm_symbolic": (i32, [vp, vp, P(vp)]),
     "sprs_hip_spgemm_numeric": (i32, [vp, vp, vp]),
     "sprs_hip_spgemm_plan_create": (i32, [vp, vp, P(vp)]),

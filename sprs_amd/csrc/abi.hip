@@ -535,6 +535,8 @@ int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m) {
     m->plan.release();
     m->mm.release();
     m->gs.release();
+    if (m->as_other) (void)sprs_hip_csmat_free(m->as_other);
+    m->as_other = nullptr;
     return SPRS_HIP_OK;
 }
 
@@ -591,6 +593,8 @@ int32_t sprs_hip_csmat_free(sprs_hip_csmat *m) {
     m->plan.release();
     m->mm.release();
     m->gs.release();
+    if (m->as_other) (void)sprs_hip_csmat_free(m->as_other);
+    m->as_other = nullptr;
     if (m->owns) {
         if (m->indptr) (void)hipFree(m->indptr);
         pool_free(m->indices, m->cap_indices, m->device);
@@ -889,6 +893,133 @@ int32_t sprs_hip_dist_spmv_f64(sprs_hip_dist *d, const double *x_dev, uint64_t x
     if (dist_cols(d) != x_len || dist_rows(d) != y_len) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
     if ((x_len && !x_dev) || (y_len && !y_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL vector");
     return dist_spmv(d, x_dev, y_dev, (hipStream_t)stream);
+}
+
+// ---- products with dense operands: the storage dispatch of the reference below the ABI -----------------------------------------
+// The CSR form of a handle: itself, or — for a CSC handle — its to_other_storage() copy (csmat.rs:1405-1426), made once and kept
+// IN THE HANDLE (as_other): every later product of the same CSC matrix reuses it, from any host language.  The reference walks a
+// CSC matrix column by column and scatters (prod.rs:74-99, 219-270): every result element receives its products by ascending
+// column index, which is the order of the CSR kernels on the converted matrix.
+static int32_t other_form(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
+    auto *mm = const_cast<sprs_hip_csmat *>(m);
+    std::lock_guard<std::recursive_mutex> lock(mm->mu);
+    if (!mm->as_other) SPRS_TRY(to_other_storage(m, &mm->as_other));
+    *out = mm->as_other;
+    return SPRS_HIP_OK;
+}
+static int32_t csr_form(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
+    if (m->storage == SPRS_HIP_CSR) {
+        *out = const_cast<sprs_hip_csmat *>(m);
+        return SPRS_HIP_OK;
+    }
+    return other_form(m, out);
+}
+
+static int32_t vec_args_ok(const double *x_dev, uint64_t x_len, double *y_dev, uint64_t y_len) {
+    if ((x_len && !x_dev) || (y_len && !y_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL vector");
+    if (x_len && y_len && x_dev < y_dev + y_len && y_dev < x_dev + x_len)
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "the result vector overlaps the input vector");
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_mul_acc_mat_vec_csc_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t x_len, double *y_dev,
+                                         uint64_t y_len, void *stream) {
+    clear_error();
+    if (!a) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    // prod.rs:88-92: dimensions first, then storage
+    if (a->cols != x_len || a->rows != y_len) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if (a->storage != SPRS_HIP_CSC) SPRS_FAIL(SPRS_HIP_STORAGE_MISMATCH, "Storage mismatch");
+    SPRS_TRY(vec_args_ok(x_dev, x_len, y_dev, y_len));
+    sprs_hip_csmat *csr = nullptr;
+    SPRS_TRY(csr_form(a, &csr));
+    return spmv_f64(csr, x_dev, y_dev, true, (hipStream_t)stream);
+}
+
+int32_t sprs_hip_csmat_mul_vec_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t x_len, double *y_dev, uint64_t y_len,
+                                   void *stream) {
+    clear_error();
+    if (!a) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    // csmat.rs:2119-2160 -> csr_/csc_mulacc_dense_colmaj with one column (prod.rs:284-289 / 257-259: "Dimension mismatch")
+    if (a->cols != x_len || a->rows != y_len) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    SPRS_TRY(vec_args_ok(x_dev, x_len, y_dev, y_len));
+    sprs_hip_csmat *csr = nullptr;
+    SPRS_TRY(csr_form(a, &csr));
+    return spmv_f64(csr, x_dev, y_dev, false, (hipStream_t)stream);
+}
+
+int32_t sprs_hip_csmat_mulacc_dense_f64(const sprs_hip_csmat *lhs, const double *rhs_dev, uint64_t rhs_rows, uint64_t k,
+                                        int32_t rhs_layout, uint64_t ld_rhs, double *out_dev, uint64_t out_rows,
+                                        int32_t out_layout, uint64_t ld_out, int32_t accumulate, void *stream) {
+    clear_error();
+    if (!lhs) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    if ((rhs_layout != SPRS_HIP_ROW_MAJOR && rhs_layout != SPRS_HIP_COL_MAJOR) || (out_layout != SPRS_HIP_ROW_MAJOR && out_layout != SPRS_HIP_COL_MAJOR))
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "bad layout tag");
+    // prod.rs:199-201, 228-230, 257-259, 284-289: the three dimension asserts of the four dense kernels (the column counts of rhs
+    // and out are one argument here)
+    if (lhs->cols != rhs_rows || lhs->rows != out_rows) SPRS_FAIL(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+    if (ld_rhs < (rhs_layout == SPRS_HIP_ROW_MAJOR ? k : rhs_rows) || ld_out < (out_layout == SPRS_HIP_ROW_MAJOR ? k : out_rows))
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "leading dimension smaller than the extent it strides over");
+    if (k && ((rhs_rows && !rhs_dev) || (out_rows && !out_dev))) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL matrix");
+    sprs_hip_csmat *csr = nullptr;
+    SPRS_TRY(csr_form(lhs, &csr));
+    hipStream_t st = (hipStream_t)stream;
+    if (rhs_layout == SPRS_HIP_COL_MAJOR && out_layout == SPRS_HIP_COL_MAJOR && k < 8) {
+        // the shape `&CsMat * &Array2` gives csr_mulacc_dense_colmaj (fewer than 8 columns, csmat.rs:2002-2016): column by column
+        // through the SpMV — on a power-law matrix the banded plan multiplies a column in 1/7 of what the lane-group kernel
+        // needs for up to eight
+        for (uint64_t j = 0; j < k; ++j) SPRS_TRY(spmv_f64(csr, rhs_dev + j * ld_rhs, out_dev + j * ld_out, accumulate != 0, st));
+        return SPRS_HIP_OK;
+    }
+    const uint64_t rs_r = rhs_layout == SPRS_HIP_ROW_MAJOR ? ld_rhs : 1, cs_r = rhs_layout == SPRS_HIP_ROW_MAJOR ? 1 : ld_rhs;
+    const uint64_t rs_o = out_layout == SPRS_HIP_ROW_MAJOR ? ld_out : 1, cs_o = out_layout == SPRS_HIP_ROW_MAJOR ? 1 : ld_out;
+    return spmm_strided_f64(csr, rhs_dev, k, rs_r, cs_r, out_dev, rs_o, cs_o, accumulate != 0, st);
+}
+
+int32_t sprs_hip_csmat_mul_dense_f64(const sprs_hip_csmat *lhs, const double *rhs_dev, uint64_t rhs_rows, uint64_t k,
+                                     int32_t rhs_layout, uint64_t ld_rhs, double *out_dev, int32_t *out_layout, void *stream) {
+    clear_error();
+    if (!lhs || !out_layout) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    // csmat.rs:2002-2045: Array::zeros((rows, cols)) for >= 8 columns, Array::zeros((rows, cols).f()) below — in both storages
+    const int32_t lay = k >= 8 ? SPRS_HIP_ROW_MAJOR : SPRS_HIP_COL_MAJOR;
+    *out_layout = lay;
+    return sprs_hip_csmat_mulacc_dense_f64(lhs, rhs_dev, rhs_rows, k, rhs_layout, ld_rhs, out_dev, lhs->rows, lay,
+                                           lay == SPRS_HIP_ROW_MAJOR ? k : lhs->rows, 0, stream);
+}
+
+int32_t sprs_hip_dense_dot_csmat_f64(const double *lhs_dev, uint64_t lhs_rows, uint64_t lhs_cols, int32_t lhs_layout, uint64_t ld_lhs,
+                                     const sprs_hip_csmat *rhs, double *out_dev, int32_t *out_layout, void *stream) {
+    clear_error();
+    if (!rhs || !out_layout) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    if (lhs_layout != SPRS_HIP_ROW_MAJOR && lhs_layout != SPRS_HIP_COL_MAJOR) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "bad layout tag");
+    // csmat.rs:2064-2117: (rhs^T * lhs^T)^T with free transposes — rhs.transpose_view(), lhs.t(), res.reversed_axes()
+    // the CSR form of rhs^T: the transpose view of a CSC rhs, or of the (cached) CSC copy of a CSR rhs — either way a view
+    const sprs_hip_csmat *src = rhs;
+    if (rhs->storage == SPRS_HIP_CSR) {
+        sprs_hip_csmat *csc = nullptr;
+        SPRS_TRY(other_form(rhs, &csc));
+        src = csc;
+    }
+    sprs_hip_csmat *rt = nullptr;
+    SPRS_TRY(sprs_hip_csmat_transpose_view(src, &rt));
+    int32_t lay_t = 0;
+    // lhs^T: lhs_cols x lhs_rows, the other layout over the same memory
+    const int32_t st = sprs_hip_csmat_mul_dense_f64(rt, lhs_dev, lhs_cols, lhs_rows, lhs_layout == SPRS_HIP_ROW_MAJOR ? SPRS_HIP_COL_MAJOR : SPRS_HIP_ROW_MAJOR,
+                                                    ld_lhs, out_dev, &lay_t, stream);
+    if (st == SPRS_HIP_OK) {
+        // the kernels read the chunk plan cached in the view: wait before the view goes
+        const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) { (void)sprs_hip_csmat_free(rt); return fail_hip(e, "dense . sparse"); }
+    }
+    (void)sprs_hip_csmat_free(rt);
+    if (st != SPRS_HIP_OK) return st;
+    *out_layout = lay_t == SPRS_HIP_ROW_MAJOR ? SPRS_HIP_COL_MAJOR : SPRS_HIP_ROW_MAJOR;     // reversed_axes()
+    return SPRS_HIP_OK;
+}
+
+int32_t sprs_hip_dist_comm_count(const sprs_hip_dist *d, int32_t *ranks) {
+    clear_error();
+    if (!d || !ranks) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    return dist_comm_count(d, ranks);
 }
 
 int32_t sprs_hip_dist_free(sprs_hip_dist *d) {

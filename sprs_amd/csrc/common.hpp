@@ -193,6 +193,7 @@ struct sprs_hip_csmat {
     sprs_hip::SpmvPlan plan;
     sprs_hip::SpmmPlan mm;
     sprs_hip::GsPlan gs;
+    sprs_hip_csmat *as_other = nullptr;  // the handle in the OTHER storage order (to_other_storage, csmat.rs:1405-1426): made by the first product that needs it (a CSC operand of a dense product / SpMV runs on its CSR form), dropped by refresh / free
 
     uint64_t outer() const { return storage == SPRS_HIP_CSR ? rows : cols; }
     uint64_t inner() const { return storage == SPRS_HIP_CSR ? cols : rows; }
@@ -225,6 +226,8 @@ void spgemm_plan_free(sprs_hip_spgemm_plan *pl);
 // spmm.hip
 int32_t spmm_rowmaj_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, double *out,
                         uint64_t ld_out, bool accumulate, hipStream_t stream);
+int32_t spmm_strided_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t rs_rhs, uint64_t cs_rhs, double *out,
+                         uint64_t rs_out, uint64_t cs_out, bool accumulate, hipStream_t stream);
 // dist.hip
 int32_t dist_unique_id(void *id128);
 int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world, int32_t rank, uint64_t rows, uint64_t cols,
@@ -233,6 +236,7 @@ int32_t dist_spmv(sprs_hip_dist *d, const double *x, double *y, hipStream_t stre
 void dist_free(sprs_hip_dist *d);
 uint64_t dist_rows(const sprs_hip_dist *d);
 uint64_t dist_cols(const sprs_hip_dist *d);
+int32_t dist_comm_count(const sprs_hip_dist *d, int32_t *ranks);
 // triplet.hip
 int32_t triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const void *row_inds, const void *col_inds, int32_t in_idx_bytes,
                        const double *data, int32_t storage, int32_t out_idx_bytes, int32_t out_iptr_bytes, sprs_hip_csmat **out);

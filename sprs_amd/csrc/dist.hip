@@ -34,6 +34,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(NcclId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, NcclId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(ncclComm_t, int *) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -52,6 +53,7 @@ int32_t rccl(Rccl **out) {
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
         r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
         r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
@@ -115,6 +117,21 @@ namespace sprs_hip {
 
 uint64_t dist_rows(const sprs_hip_dist *d) { return d->rows; }
 uint64_t dist_cols(const sprs_hip_dist *d) { return d->cols; }
+
+// what the communicator itself says its size is (ncclCommCount): a world of one never made one
+int32_t dist_comm_count(const sprs_hip_dist *d, int32_t *ranks) {
+    if (!d->comm) {
+        *ranks = d->world;
+        return SPRS_HIP_OK;
+    }
+    Rccl *R = nullptr;
+    SPRS_TRY(rccl(&R));
+    if (!R->CommCount) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "multi-GPU: librccl lacks ncclCommCount");
+    int n = 0;
+    SPRS_TRY_NCCL(R, R->CommCount((ncclComm_t)d->comm, &n));
+    *ranks = n;
+    return SPRS_HIP_OK;
+}
 
 int32_t dist_unique_id(void *id128) {
     Rccl *R = nullptr;

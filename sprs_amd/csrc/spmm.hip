@@ -55,8 +55,8 @@ __global__ void fill_chunks_kernel(const uint64_t *__restrict__ first_chunk, con
 template <typename IDX, typename PTR, int KP, bool ACC>
 __global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
                                                              const double *__restrict__ data, uint64_t rows,
-                                                             const double *__restrict__ rhs, uint64_t ld_rhs, uint32_t k,
-                                                             double *__restrict__ out, uint64_t ld_out, uint64_t long_row) {
+                                                             const double *__restrict__ rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k,
+                                                             double *__restrict__ out, uint64_t ld_out, uint64_t cs_out, uint64_t long_row) {
     constexpr int EB = KP <= 16 ? 32 / KP : 1;           // entries a lane loads per turn
     constexpr int NB = EB * KP;                          // entries of a turn (32, or KP)
     constexpr int UN = NB < 32 ? NB : 32;                // rhs rows in flight per group
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restri
         mine = end - cur <= long_row;
         if (!mine) cur = end;
         if constexpr (ACC)
-            if (mine && col_ok) acc = out[r * ld_out + j];
+            if (mine && col_ok) acc = out[r * ld_out + j * cs_out];
         if (r + ng < rows) {
             ncur = (uint64_t)indptr[r + ng];
             nend = (uint64_t)indptr[r + ng + 1];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restri
                 const int t = t0 + u;
                 // (an entry past the end reads rhs row 0 and is not added: no branch in the load sequence)
                 const uint64_t c = __shfl(col[t / KP], t % KP, KP);
-                x[u] = col_ok ? rhs[c * ld_rhs + j] : 0.0;
+                x[u] = col_ok ? rhs[c * ld_rhs + j * cs_rhs] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restri
         }
         cur += nb;
         if (active && cur == end) {
-            if (mine && col_ok) out[r * ld_out + j] = acc;
+            if (mine && col_ok) out[r * ld_out + j * cs_out] = acc;
             r += ng;
             active = r < rows;
             cur = ncur;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_rows_kernel(const PTR *__restri
                 mine = end - cur <= long_row;
                 if (!mine) cur = end;
                 if constexpr (ACC)
-                    if (mine && col_ok) acc = out[r * ld_out + j];
+                    if (mine && col_ok) acc = out[r * ld_out + j * cs_out];
                 if (r + ng < rows) {
                     ncur = (uint64_t)indptr[r + ng];
                     nend = (uint64_t)indptr[r + ng + 1];
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_chunk_kernel(const PTR *__restr
                                                               const uint64_t *__restrict__ chunk_row,
                                                               const uint64_t *__restrict__ first_chunk,
                                                               uint64_t nchunks, const double *__restrict__ rhs,
-                                                              uint64_t ld_rhs, uint32_t k, double *__restrict__ out,
-                                                              uint64_t ld_out, double *__restrict__ partial) {
+                                                              uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k, double *__restrict__ out,
+                                                              uint64_t ld_out, uint64_t cs_out, double *__restrict__ partial) {
     constexpr int G = WAVE / KP;                       // entries processed concurrently by one wave
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t j = lane % KP, g = lane / KP;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_chunk_kernel(const PTR *__restr
                     a[u] = ok ? data[p + (uint64_t)u * G] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = rhs[col[u] * ld_rhs + j];
+                for (int u = 0; u < 4; ++u) x[u] = rhs[col[u] * ld_rhs + j * cs_rhs];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const double sum = acc + a[u] * x[u];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_chunk_kernel(const PTR *__restr
         for (int o = KP; o < WAVE; o <<= 1) acc += __shfl_xor(acc, o, WAVE);
         if (g == 0 && j < k) {
             if (nc == 1) {
-                double *dst = out + r * ld_out + j;
+                double *dst = out + r * ld_out + j * cs_out;
                 if constexpr (ACC) *dst = *dst + acc;
                 else *dst = acc;
             } else {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_chunk_kernel(const PTR *__restr
 template <bool ACC>
 __global__ void spmm_combine_kernel(const uint64_t *__restrict__ multi_rows, uint64_t n_multi,
                                     const uint64_t *__restrict__ first_chunk, const double *__restrict__ partial,
-                                    uint32_t k, double *__restrict__ out, uint64_t ld_out) {
+                                    uint32_t k, double *__restrict__ out, uint64_t ld_out, uint64_t cs_out) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_multi * k) return;
     const uint64_t r = multi_rows[t / k];
@@ -197,7 +197,7 @@ __global__ void spmm_combine_kernel(const uint64_t *__restrict__ multi_rows, uin
     const uint64_t f = first_chunk[r], n = first_chunk[r + 1] - f;
     double s = 0.0;
     for (uint64_t c = 0; c < n; ++c) s += partial[(f + c) * (uint64_t)k + j];
-    double *dst = out + r * ld_out + j;
+    double *dst = out + r * ld_out + j * cs_out;
     if constexpr (ACC) *dst = *dst + s;
     else *dst = s;
 }
@@ -240,8 +240,8 @@ int32_t build_spmm_plan(sprs_hip_csmat *a, hipStream_t stream) {
 }
 
 template <typename IDX, typename PTR, int KP>
-int32_t launch_block(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint32_t k, double *out, uint64_t ld_out,
-                     bool acc, double *partial, hipStream_t stream) {
+int32_t launch_block(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k, double *out, uint64_t ld_out,
+                     uint64_t cs_out, bool acc, double *partial, hipStream_t stream) {
     const SpmmPlan &pl = a->mm;
     {
         // short rows: groups of KP lanes, group-stride; enough workgroups to fill the chip eight deep
@@ -251,10 +251,10 @@ int32_t launch_block(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint
         const dim3 grid((unsigned)blocks), block(MM_BLOCK);
         if (acc)
             hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, true>), grid, block, 0, stream, (const PTR *)a->indptr,
-                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, k, out, ld_out, pl.long_row);
+                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, pl.long_row);
         else
             hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, false>), grid, block, 0, stream, (const PTR *)a->indptr,
-                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, k, out, ld_out, pl.long_row);
+                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, pl.long_row);
         SPRS_TRY_HIP(hipGetLastError());
     }
     if (!pl.nchunks) return SPRS_HIP_OK;
@@ -263,30 +263,30 @@ int32_t launch_block(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint
     const dim3 grid((unsigned)blocks), block(MM_BLOCK);
     if (acc)
         hipLaunchKernelGGL((spmm_chunk_kernel<IDX, PTR, KP, true>), grid, block, 0, stream, (const PTR *)a->indptr,
-                           (const IDX *)a->indices, a->data, pl.chunk_row, pl.first_chunk, pl.nchunks, rhs, ld_rhs, k,
-                           out, ld_out, partial);
+                           (const IDX *)a->indices, a->data, pl.chunk_row, pl.first_chunk, pl.nchunks, rhs, ld_rhs, cs_rhs, k,
+                           out, ld_out, cs_out, partial);
     else
         hipLaunchKernelGGL((spmm_chunk_kernel<IDX, PTR, KP, false>), grid, block, 0, stream, (const PTR *)a->indptr,
-                           (const IDX *)a->indices, a->data, pl.chunk_row, pl.first_chunk, pl.nchunks, rhs, ld_rhs, k,
-                           out, ld_out, partial);
+                           (const IDX *)a->indices, a->data, pl.chunk_row, pl.first_chunk, pl.nchunks, rhs, ld_rhs, cs_rhs, k,
+                           out, ld_out, cs_out, partial);
     SPRS_TRY_HIP(hipGetLastError());
     if (pl.n_multi) {
         const uint64_t th = pl.n_multi * k;
         const dim3 g2((unsigned)((th + 255) / 256)), b2(256);
         if (acc)
             hipLaunchKernelGGL(spmm_combine_kernel<true>, g2, b2, 0, stream, pl.multi_rows, pl.n_multi, pl.first_chunk,
-                               partial, k, out, ld_out);
+                               partial, k, out, ld_out, cs_out);
         else
             hipLaunchKernelGGL(spmm_combine_kernel<false>, g2, b2, 0, stream, pl.multi_rows, pl.n_multi, pl.first_chunk,
-                               partial, k, out, ld_out);
+                               partial, k, out, ld_out, cs_out);
         SPRS_TRY_HIP(hipGetLastError());
     }
     return SPRS_HIP_OK;
 }
 
 template <typename IDX, typename PTR>
-int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, double *out, uint64_t ld_out,
-                  bool acc, hipStream_t stream) {
+int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, uint64_t cs_rhs, double *out, uint64_t ld_out,
+                  uint64_t cs_out, bool acc, hipStream_t stream) {
     double *partial = nullptr;
     std::lock_guard<std::recursive_mutex> lock(a->mu);   // held until the kernels that read the plan are launched
     {
@@ -308,7 +308,8 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
     if (a->nnz == 0) {
         // nothing stored: the operator form is all zeros (csmat.rs:2004), the accumulate form leaves `out` alone
         if (!acc) {
-            if (ld_out == k) SPRS_TRY_HIP(hipMemsetAsync(out, 0, a->rows * k * sizeof(double), stream));
+            if (cs_out != 1) SPRS_TRY_HIP(hipMemset2DAsync(out, cs_out * sizeof(double), 0, a->rows * sizeof(double), k, stream));   // column-major: k columns of `rows` doubles
+            else if (ld_out == k) SPRS_TRY_HIP(hipMemsetAsync(out, 0, a->rows * k * sizeof(double), stream));
             else SPRS_TRY_HIP(hipMemset2DAsync(out, ld_out * sizeof(double), 0, k * sizeof(double), a->rows, stream));
         }
         return SPRS_HIP_OK;
@@ -316,13 +317,13 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
     // every row is written by exactly one kernel (an empty row as zeros): no memset of `out`
     for (uint64_t j0 = 0; j0 < k; j0 += 64) {          // column blocks of 64
         const uint32_t kb = (uint32_t)(k - j0 < 64 ? k - j0 : 64);
-        const double *r = rhs + j0;
-        double *o = out + j0;
+        const double *r = rhs + j0 * cs_rhs;
+        double *o = out + j0 * cs_out;
         int32_t st;
-        if (kb <= 8) st = launch_block<IDX, PTR, 8>(a, r, ld_rhs, kb, o, ld_out, acc, partial, stream);
-        else if (kb <= 16) st = launch_block<IDX, PTR, 16>(a, r, ld_rhs, kb, o, ld_out, acc, partial, stream);
-        else if (kb <= 32) st = launch_block<IDX, PTR, 32>(a, r, ld_rhs, kb, o, ld_out, acc, partial, stream);
-        else st = launch_block<IDX, PTR, 64>(a, r, ld_rhs, kb, o, ld_out, acc, partial, stream);
+        if (kb <= 8) st = launch_block<IDX, PTR, 8>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+        else if (kb <= 16) st = launch_block<IDX, PTR, 16>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+        else if (kb <= 32) st = launch_block<IDX, PTR, 32>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+        else st = launch_block<IDX, PTR, 64>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
         SPRS_TRY(st);
     }
     return SPRS_HIP_OK;
@@ -344,13 +345,21 @@ void SpmmPlan::release() {
     built = false;
 }
 
+// General strides: element (r, j) of the rhs at rhs[r * rs_rhs + j * cs_rhs], of out at out[r * rs_out + j * cs_out] — row-major
+// operands have cs = 1, column-major ones rs = 1.  One kernel family serves the four layout pairs `&CsMat * &Array2` can meet
+// (csmat.rs:1989-2048: the result is row-major for >= 8 columns, column-major below, whatever the rhs is).
+int32_t spmm_strided_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t rs_rhs, uint64_t cs_rhs, double *out,
+                         uint64_t rs_out, uint64_t cs_out, bool accumulate, hipStream_t stream) {
+    if (a->rows == 0 || k == 0) return SPRS_HIP_OK;
+    if (a->idx_bytes == 8 && a->iptr_bytes == 8) return spmm_impl<uint64_t, uint64_t>(a, rhs, k, rs_rhs, cs_rhs, out, rs_out, cs_out, accumulate, stream);
+    if (a->idx_bytes == 4 && a->iptr_bytes == 8) return spmm_impl<uint32_t, uint64_t>(a, rhs, k, rs_rhs, cs_rhs, out, rs_out, cs_out, accumulate, stream);
+    if (a->idx_bytes == 8 && a->iptr_bytes == 4) return spmm_impl<uint64_t, uint32_t>(a, rhs, k, rs_rhs, cs_rhs, out, rs_out, cs_out, accumulate, stream);
+    return spmm_impl<uint32_t, uint32_t>(a, rhs, k, rs_rhs, cs_rhs, out, rs_out, cs_out, accumulate, stream);
+}
+
 int32_t spmm_rowmaj_f64(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, double *out,
                         uint64_t ld_out, bool accumulate, hipStream_t stream) {
-    if (a->rows == 0 || k == 0) return SPRS_HIP_OK;
-    if (a->idx_bytes == 8 && a->iptr_bytes == 8) return spmm_impl<uint64_t, uint64_t>(a, rhs, k, ld_rhs, out, ld_out, accumulate, stream);
-    if (a->idx_bytes == 4 && a->iptr_bytes == 8) return spmm_impl<uint32_t, uint64_t>(a, rhs, k, ld_rhs, out, ld_out, accumulate, stream);
-    if (a->idx_bytes == 8 && a->iptr_bytes == 4) return spmm_impl<uint64_t, uint32_t>(a, rhs, k, ld_rhs, out, ld_out, accumulate, stream);
-    return spmm_impl<uint32_t, uint32_t>(a, rhs, k, ld_rhs, out, ld_out, accumulate, stream);
+    return spmm_strided_f64(a, rhs, k, ld_rhs, 1, out, ld_out, 1, accumulate, stream);
 }
 
 }  // namespace sprs_hip

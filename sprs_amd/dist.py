@@ -139,6 +139,14 @@ class DistSpMV:
         dist.broadcast(buf, src=src, group=group)
         return bytes(buf.cpu().numpy().tobytes())
 
+    def comm_count(self):
+        """ranks of the RCCL communicator as RCCL itself counts them (ncclCommCount; 1 for a world of one)"""
+        import ctypes as C
+        from ._ffi import check, lib
+        n = C.c_int32(0)
+        check(lib.sprs_hip_dist_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
     def spmv(self, x, y, stream=None):
         """y = A * x (collective); x, y: DeviceVec of length cols / rows on this rank's device"""
         import ctypes as C

@@ -21,111 +21,122 @@ def mul_acc_mat_vec_csr(mat, in_vec, res_vec, stream=None):
 
 
 def mul_acc_mat_vec_csc(mat, in_vec, res_vec, stream=None):
-    """prod::mul_acc_mat_vec_csc (prod.rs:74-99): res_vec += mat * in_vec for a CSC matrix.
-    The reference scatters column by column; on the device the matrix is converted once to CSR
-    (to_other_storage, csmat.rs:1405-1426 — cached on the Python object) and the CSR kernel
-    runs: same result up to the summation order inside a row."""
-    if not mat.is_csc():
-        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")       # prod.rs:92
-    if mat.cols() != in_vec.n or mat.rows() != res_vec.n:
-        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:88-91
-    mul_acc_mat_vec_csr(_csr_of(mat), in_vec, res_vec, stream)
-
-
-def csr_mulacc_dense_colmaj(lhs, rhs_cols, out_cols, stream=None):
-    """prod::csr_mulacc_dense_colmaj (prod.rs:274-298) with the rhs / out given
-    as lists of column vectors: out[:, j] += lhs * rhs[:, j]."""
-    if len(rhs_cols) != len(out_cols):
-        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
-    for r, o in zip(rhs_cols, out_cols):
-        mul_acc_mat_vec_csr(lhs, r, o, stream)
+    """prod::mul_acc_mat_vec_csc (prod.rs:74-99): res_vec += mat * in_vec for a CSC matrix (sprs_hip_mul_acc_mat_vec_csc_f64:
+    the matrix is converted once to CSR on the device, the copy is cached in the HANDLE, the CSR kernel runs — every result
+    element still receives its products by ascending column)."""
+    check(lib.sprs_hip_mul_acc_mat_vec_csc_f64(mat._h, C.c_void_p(in_vec.ptr), in_vec.n, C.c_void_p(res_vec.ptr), res_vec.n,
+                                               _stream_ptr(stream)))
 
 
 class DeviceMat:
-    """Dense row-major f64 matrix in HBM (what `Array2<f64>` in standard layout is on the host)."""
+    """Dense f64 matrix in HBM in one of ndarray's two contiguous layouts: `Array2` in standard (row-major) order, or
+    `Array::zeros(shape.f())` (column-major) — what `&CsMat * &Array2` returns for fewer than 8 columns (csmat.rs:2017-2024)."""
 
-    def __init__(self, rows, cols, vec=None):
-        self.rows, self.cols = int(rows), int(cols)
+    def __init__(self, rows, cols, vec=None, col_major=False):
+        self.rows, self.cols, self.col_major = int(rows), int(cols), bool(col_major)
         self.vec = vec if vec is not None else DeviceVec.zeros(self.rows * self.cols)
         assert self.vec.n == self.rows * self.cols
 
     @classmethod
-    def from_host(cls, arr):
+    def from_host(cls, arr, col_major=False):
         import numpy as np
-        arr = np.ascontiguousarray(arr, dtype=np.float64)
-        return cls(arr.shape[0], arr.shape[1], DeviceVec.from_host(arr.reshape(-1)))
+        arr = np.asarray(arr, dtype=np.float64)
+        flat = np.asfortranarray(arr).reshape(-1, order="F") if col_major else np.ascontiguousarray(arr).reshape(-1)
+        return cls(arr.shape[0], arr.shape[1], DeviceVec.from_host(np.ascontiguousarray(flat)), col_major)
 
     def to_host(self):
-        return self.vec.to_host().reshape(self.rows, self.cols)
+        flat = self.vec.to_host()
+        return flat.reshape(self.cols, self.rows).T if self.col_major else flat.reshape(self.rows, self.cols)
+
+    @property
+    def layout(self):
+        return _ffi.COL_MAJOR if self.col_major else _ffi.ROW_MAJOR
+
+    @property
+    def ld(self):
+        return self.rows if self.col_major else self.cols
+
+
+def _mulacc_dense(lhs, rhs, out, stream):
+    if rhs.cols != out.cols:
+        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:201, 230, 259, 287
+    check(lib.sprs_hip_csmat_mulacc_dense_f64(lhs._h, C.c_void_p(rhs.vec.ptr), rhs.rows, rhs.cols, rhs.layout, rhs.ld,
+                                              C.c_void_p(out.vec.ptr), out.rows, out.layout, out.ld, 1, _stream_ptr(stream)))
+
+
+def _storage(lhs, want_csr):
+    if lhs.is_csc() == want_csr:
+        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")       # prod.rs:202, 231, 258, 288
 
 
 def csr_mulacc_dense_rowmaj(lhs, rhs, out, stream=None):
-    """prod::csr_mulacc_dense_rowmaj (prod.rs:189-214): out += lhs * rhs, rhs/out dense row-major."""
-    if rhs.cols != out.cols:
-        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:201
-    check(lib.sprs_hip_spmm_rowmaj_f64(lhs._h, C.c_void_p(rhs.vec.ptr), rhs.rows, rhs.cols, rhs.cols,
-                                       C.c_void_p(out.vec.ptr), out.rows, out.cols, 1, _stream_ptr(stream)))
+    """prod::csr_mulacc_dense_rowmaj (prod.rs:189-214): out += lhs * rhs."""
+    _storage(lhs, True)
+    _mulacc_dense(lhs, rhs, out, stream)
 
 
-def _csr_of(mat):
-    """the CSR form of a CSC handle (to_other_storage on the device, csmat.rs:1405-1426), made once per Python object"""
-    csr = getattr(mat, "_as_csr", None)
-    if csr is None:
-        csr = mat.to_other_storage()
-        mat._as_csr = csr
-    return csr
+def csr_mulacc_dense_colmaj(lhs, rhs, out, stream=None):
+    """prod::csr_mulacc_dense_colmaj (prod.rs:274-298): out += lhs * rhs (the reference walks the rhs column by column; the
+    device entry is told by the operands' layouts how to address them).  rhs / out: DeviceMat, or two equally long lists of
+    column vectors (out[:, j] += lhs * rhs[:, j])."""
+    _storage(lhs, True)
+    if isinstance(rhs, (list, tuple)):
+        if len(rhs) != len(out):
+            raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
+        for r, o in zip(rhs, out):
+            mul_acc_mat_vec_csr(lhs, r, o, stream)
+        return
+    _mulacc_dense(lhs, rhs, out, stream)
 
 
 def csc_mulacc_dense_rowmaj(lhs, rhs, out, stream=None):
-    """prod::csc_mulacc_dense_rowmaj (prod.rs:219-241): out += lhs * rhs for a CSC lhs, rhs / out dense row-major.  The
-    reference walks the columns of lhs in order and adds `lval * rhs[col, :]` into out[row, :], so every out[i, j]
-    receives its products by ascending column — the order the CSR kernel uses on the converted matrix."""
-    if not lhs.is_csc():
-        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")       # prod.rs:231
-    if lhs.cols() != rhs.rows or lhs.rows() != out.rows or rhs.cols != out.cols:
-        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:228-230
-    csr_mulacc_dense_rowmaj(_csr_of(lhs), rhs, out, stream)
+    """prod::csc_mulacc_dense_rowmaj (prod.rs:219-241): out += lhs * rhs for a CSC lhs.  The reference walks the columns of
+    lhs in order and adds `lval * rhs[col, :]` into out[row, :], so every out[i, j] receives its products by ascending column —
+    the order the CSR kernel uses on the converted matrix (cached in the handle, below the C ABI)."""
+    _storage(lhs, False)
+    _mulacc_dense(lhs, rhs, out, stream)
 
 
-def csc_mulacc_dense_colmaj(lhs, rhs_cols, out_cols, stream=None):
-    """prod::csc_mulacc_dense_colmaj (prod.rs:246-270) with rhs / out as lists of column vectors: out[:, j] += lhs * rhs[:, j]
-    (per column the reference's scatter loop = mul_acc_mat_vec_csc)."""
-    if not lhs.is_csc():
-        raise _ffi.SprsHipError(_ffi.STORAGE_MISMATCH, "Storage mismatch")       # prod.rs:258
-    if len(rhs_cols) != len(out_cols):
-        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:257
-    for r, o in zip(rhs_cols, out_cols):
-        mul_acc_mat_vec_csc(lhs, r, o, stream)
+def csc_mulacc_dense_colmaj(lhs, rhs, out, stream=None):
+    """prod::csc_mulacc_dense_colmaj (prod.rs:246-270); rhs / out as in csr_mulacc_dense_colmaj."""
+    _storage(lhs, False)
+    if isinstance(rhs, (list, tuple)):
+        if len(rhs) != len(out):
+            raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")      # prod.rs:257
+        for r, o in zip(rhs, out):
+            mul_acc_mat_vec_csc(lhs, r, o, stream)
+        return
+    _mulacc_dense(lhs, rhs, out, stream)
 
 
 def csmat_mul_dense(mat, rhs, stream=None):
-    """`&CsMat * &Array2` (csmat.rs:1989-2048): fresh zero result; a CSC lhs is converted once on the device; >= 8 columns use the
-    row-major kernel, fewer go column by column like csr_mulacc_dense_colmaj (prod.rs:274-298) —
-    here through one strided pass of the same kernel, the result stays row-major."""
-    if mat.is_csc():                     # (CSC, _) arms of the dispatch, csmat.rs:2026-2045: the same product on the CSR form
-        if mat.cols() != rhs.rows:
-            raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
-        mat = _csr_of(mat)
+    """`&CsMat * &Array2` (csmat.rs:1989-2048), ONE call below the C ABI (sprs_hip_csmat_mul_dense_f64): the four arms
+    (CSR | CSC) x (>= 8 columns | fewer); the result comes back row-major for >= 8 columns and column-major (`.f()`) below,
+    like the reference's."""
     out = DeviceMat(mat.rows(), rhs.cols, DeviceVec(mat.rows() * rhs.cols))
-    check(lib.sprs_hip_spmm_rowmaj_f64(mat._h, C.c_void_p(rhs.vec.ptr), rhs.rows, rhs.cols, rhs.cols,
-                                       C.c_void_p(out.vec.ptr), out.rows, out.cols, 0, _stream_ptr(stream)))
+    lay = C.c_int32(0)
+    check(lib.sprs_hip_csmat_mul_dense_f64(mat._h, C.c_void_p(rhs.vec.ptr), rhs.rows, rhs.cols, rhs.layout, rhs.ld,
+                                           C.c_void_p(out.vec.ptr), C.byref(lay), _stream_ptr(stream)))
+    out.col_major = lay.value == _ffi.COL_MAJOR
+    return out
+
+
+def dense_dot_csmat(lhs, mat, stream=None):
+    """`Array2::dot(&CsMat)` (csmat.rs:2050-2117): dense . sparse through the transposes of the reference, below the C ABI."""
+    out = DeviceMat(lhs.rows, mat.cols(), DeviceVec(lhs.rows * mat.cols()))
+    lay = C.c_int32(0)
+    check(lib.sprs_hip_dense_dot_csmat_f64(C.c_void_p(lhs.vec.ptr), lhs.rows, lhs.cols, lhs.layout, lhs.ld, mat._h,
+                                           C.c_void_p(out.vec.ptr), C.byref(lay), _stream_ptr(stream)))
+    out.col_major = lay.value == _ffi.COL_MAJOR
     return out
 
 
 def csmat_mul_vec(mat, vec, out=None, stream=None):
-    """`&CsMat * &Array1` (csmat.rs:2119-2160): fresh zero result, CSR goes
-    through csr_mulacc_dense_colmaj with one column."""
+    """`&CsMat * &Array1` (csmat.rs:2119-2160): fresh zero result; CSR goes through csr_mulacc_dense_colmaj with one column,
+    CSC through csc_mulacc_dense_colmaj (csmat.rs:2140-2156) — dispatched below the C ABI (sprs_hip_csmat_mul_vec_f64)."""
     if out is None:
         out = DeviceVec(mat.rows())
-    if mat.is_csc():
-        # csmat.rs:2149-2156 (csc_mulacc_dense_colmaj): one conversion to CSR, then the CSR kernel
-        if mat.cols() != vec.n or mat.rows() != out.n:
-            raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
-        check(lib.sprs_hip_memset(C.c_void_p(out.ptr), 0, out.n * 8, _stream_ptr(stream)))
-        mul_acc_mat_vec_csc(mat, vec, out, stream)
-        return out
-    check(lib.sprs_hip_spmv_f64(mat._h, C.c_void_p(vec.ptr), vec.n, C.c_void_p(out.ptr), out.n, 0,
-                                _stream_ptr(stream)))
+    check(lib.sprs_hip_csmat_mul_vec_f64(mat._h, C.c_void_p(vec.ptr), vec.n, C.c_void_p(out.ptr), out.n, _stream_ptr(stream)))
     return out
 
 

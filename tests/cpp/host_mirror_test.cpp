@@ -111,6 +111,96 @@ int main() {
         REQUIRE((ix == std::vector<uint64_t>{0, 3, 2, 1}));
         REQUIRE((dt == std::vector<double>{0.0, 5.0, 7.0, (1e16 + 1.0) + -1e16}));
     }
+    {   // prod.rs:545-597 through the header: mat1 (CSC and CSR) * mat_dense1 — mul_csc_dense_rowmaj, mul_csc_dense_colmaj,
+        // mul_csr_dense_colmaj — and `&a * &b` with its layout rule (csmat.rs:2002-2045); the CSC -> CSR copy lives in the handle
+        DeviceCsMat csc(SPRS_HIP_CSC, 5, 5, std::vector<uint64_t>{0, 0, 1, 3, 6, 7},
+                        std::vector<uint64_t>{3, 0, 2, 0, 1, 4, 1}, std::vector<double>{8., 3., 5., 4., 2., 7., 5.});
+        DeviceCsMat csr = mat1();
+        std::vector<double> dense_rm(25), dense_cm(25), expect_rm(25, 0.0);     // mat_dense1: [[0..4], [5..9], ...] (test_data.rs:40-48)
+        for (int i = 0; i < 5; ++i)
+            for (int j = 0; j < 5; ++j) dense_rm[i * 5 + j] = dense_cm[j * 5 + i] = (double)(i * 5 + j);
+        const uint64_t ip[6] = {0, 2, 4, 5, 6, 7}, ix[7] = {2, 3, 3, 4, 2, 1, 3};
+        const double dv[7] = {3., 4., 2., 5., 5., 8., 7.};
+        for (int i = 0; i < 5; ++i)
+            for (uint64_t p = ip[i]; p < ip[i + 1]; ++p)
+                for (int j = 0; j < 5; ++j) expect_rm[i * 5 + j] += dv[p] * dense_rm[ix[p] * 5 + j];
+        for (int storage = 0; storage < 2; ++storage) {
+            const DeviceCsMat &a = storage ? csc : csr;
+            for (int rhs_cm = 0; rhs_cm < 2; ++rhs_cm) {
+                DeviceMat b(5, 5, rhs_cm ? dense_cm : dense_rm, rhs_cm != 0);
+                DeviceMat c = a * b;                                     // 5 columns: `.f()` result (csmat.rs:2017-2024, 2036-2044)
+                REQUIRE(!c.is_standard_layout());
+                auto h = c.to_host();
+                for (int i = 0; i < 5; ++i)
+                    for (int j = 0; j < 5; ++j) REQUIRE(c.at(h, i, j) == expect_rm[i * 5 + j]);
+                for (int out_cm = 0; out_cm < 2; ++out_cm) {             // the four accumulate kernels on a zero result
+                    DeviceMat res(5, 5, out_cm != 0);
+                    if (storage && out_cm) prod::csc_mulacc_dense_colmaj(a, b, res);
+                    else if (storage) prod::csc_mulacc_dense_rowmaj(a, b, res);
+                    else if (out_cm) prod::csr_mulacc_dense_colmaj(a, b, res);
+                    else prod::csr_mulacc_dense_rowmaj(a, b, res);
+                    auto hr = res.to_host();
+                    for (int i = 0; i < 5; ++i)
+                        for (int j = 0; j < 5; ++j) REQUIRE(res.at(hr, i, j) == expect_rm[i * 5 + j]);
+                }
+            }
+            // 9 columns: standard-layout result; first 5 columns as above, the rest zero columns of the rhs
+            std::vector<double> wide(5 * 9, 0.0);
+            for (int i = 0; i < 5; ++i)
+                for (int j = 0; j < 5; ++j) wide[i * 9 + j] = dense_rm[i * 5 + j];
+            DeviceMat c9 = a * DeviceMat(5, 9, wide);
+            REQUIRE(c9.is_standard_layout());
+            auto h9 = c9.to_host();
+            for (int i = 0; i < 5; ++i)
+                for (int j = 0; j < 9; ++j) REQUIRE(c9.at(h9, i, j) == (j < 5 ? expect_rm[i * 5 + j] : 0.0));
+            // `&a * &x` on either storage (csmat.rs:2140-2156) and the CSC accumulate kernel (prod.rs:74-99)
+            DeviceVec x(std::vector<double>{1., 2., 3., 4., 5.});
+            auto y = (a * x).to_host();
+            for (int i = 0; i < 5; ++i) {
+                double e = 0;
+                for (uint64_t p = ip[i]; p < ip[i + 1]; ++p) e += dv[p] * (double)(ix[p] + 1);
+                REQUIRE(y[i] == e);
+            }
+        }
+        DeviceVec x(std::vector<double>{1., 2., 3., 4., 5.}), acc(std::vector<double>(5, 1.0));
+        prod::mul_acc_mat_vec_csc(csc, x, acc);
+        auto ya = acc.to_host(), y0 = (csr * x).to_host();
+        for (int i = 0; i < 5; ++i) REQUIRE(ya[i] == 1.0 + y0[i]);
+        bool threw = false;
+        try {
+            prod::mul_acc_mat_vec_csc(csr, x, acc);                      // assert!(mat.is_csc(), "Storage mismatch") prod.rs:92
+        } catch (const Error &e) {
+            threw = e.status == SPRS_HIP_STORAGE_MISMATCH;
+        }
+        REQUIRE(threw);
+        // dense . sparse (csmat.rs:2050-2117): I(5) . mat1 == mat1
+        std::vector<double> eye5(25, 0.0);
+        for (int i = 0; i < 5; ++i) eye5[i * 5 + i] = 1.0;
+        DeviceMat d = dot(DeviceMat(5, 5, eye5), csr);
+        auto hd = d.to_host();
+        for (int i = 0; i < 5; ++i)
+            for (int j = 0; j < 5; ++j) {
+                double e = 0;
+                for (uint64_t p = ip[i]; p < ip[i + 1]; ++p) e += ix[p] == (uint64_t)j ? dv[p] : 0.0;
+                REQUIRE(d.at(hd, i, j) == e);
+            }
+    }
+    {   // the device triplet assembly through the header (triplet_iter.rs:127-224) and a world of one through the RCCL-side entry
+        DeviceCsMat m = triplets_to_cs(4, 4, std::vector<uint64_t>{2, 0, 2, 0, 2, 1}, std::vector<uint64_t>{1, 3, 1, 0, 1, 2},
+                                       std::vector<double>{1e16, 5.0, 1.0, 0.0, -1e16, 7.0});
+        std::vector<uint64_t> ip, ix;
+        std::vector<double> dt;
+        m.to_host(ip, ix, dt);
+        REQUIRE((ip == std::vector<uint64_t>{0, 2, 3, 4, 4}));
+        REQUIRE((ix == std::vector<uint64_t>{0, 3, 2, 1}));
+        REQUIRE((dt == std::vector<double>{0.0, 5.0, 7.0, (1e16 + 1.0) + -1e16}));
+        DeviceCsMat a = mat1();
+        DistSpMV d(std::vector<unsigned char>(), 1, 0, 5, 5, std::vector<uint64_t>{0, 5}, a, 2);
+        REQUIRE(d.comm_count() == 1);
+        DeviceVec x(std::vector<double>{1., 2., 3., 4., 5.}), y(5);
+        d.mul(x, y);
+        REQUIRE(y.to_host() == (a * x).to_host());
+    }
     {   // panics -> exceptions with the reference's text
         DeviceCsMat a = mat1();
         DeviceVec x4(4), y5(5);

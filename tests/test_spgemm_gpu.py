@@ -476,6 +476,27 @@ def test_config5_full_size_row_blocks(hip, idx_bytes):
     assert d["structure_checks"]["rows_strictly_increasing"] and d["structure_checks"]["indptr_monotone"]
 
 
+def test_config5_developer_build(hip):
+    """The hang guard: config 5 once on the DEVELOPER library (make DEVTOOLS=1, libsprs_hip_dev.so), under a timeout.  In
+    round 3 a mis-compiled row loop (`for (;;)` + `break` around a wave-uniform draw) made config 5 spin forever in
+    one build variant only while small products and the CPU emulator passed: both libraries therefore run the full-size
+    product in this suite, and a variant that no longer terminates fails here instead of hanging a bench."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev_lib = os.path.join(root, "sprs_amd", "libsprs_hip_dev.so")
+    if not os.path.exists(dev_lib):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(root, "sprs_amd", "csrc"), "DEVTOOLS=1"])
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "spgemm_bench.py"), "1000000", "8", "8", "100"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, SPRS_HIP_LIBRARY=dev_lib))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["nnz_c"] > 3_000_000_000
+    assert d["parity"]["structure_bit_exact"] and d["parity"]["values_bit_exact"], d["parity"]
+
+
 def test_config5_five_products_bit_identical(hip):
     """BASELINE config 5 at full size, five times: nnz, indptr and position-weighted 64-bit checksums of the
     indices and of the value BITS must be identical from product to product (the accumulation order is fixed:

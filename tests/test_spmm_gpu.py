@@ -184,3 +184,77 @@ def test_ragged_and_contract(hip, golden):
     csc = DeviceCsMat.from_host(shape, ip, ix, dt, storage=_ffi.CSC)
     with pytest.raises(SprsHipError, match="Storage mismatch"):             # prod.rs:202
         prod.csr_mulacc_dense_rowmaj(csc, prod.DeviceMat(5, 2), prod.DeviceMat(5, 2))
+
+
+def test_dense_dispatch_below_the_abi(hip):
+    """`&CsMat * &Array2` / `&CsMat * &Array1` / `Array2::dot(&CsMat)` dispatched by the LIBRARY (csmat.rs:1989-2160):
+    both storages, both rhs layouts, both result layouts (row-major from 8 columns, `.f()` below), the accumulate kernels of
+    prod.rs with explicit layouts, the CSC -> CSR copy cached in the handle (second product of the same handle; refresh)."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from sprs_amd import _ffi, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec, CSC
+    rng = np.random.default_rng(12)
+    u = lambda v: np.asarray(v, dtype=np.uint64)
+    m = sp.random(700, 500, density=0.03, random_state=9, format="csr")
+    m.data[:] = rng.standard_normal(m.nnz)
+    m.sort_indices()
+    mc = m.tocsc()
+    mc.sort_indices()
+    a_csr = DeviceCsMat.from_host((700, 500), u(m.indptr), u(m.indices), m.data)
+    a_csc = DeviceCsMat.from_host((700, 500), u(mc.indptr), u(mc.indices), mc.data, storage=CSC)
+    for a in (a_csr, a_csc):
+        for k in (1, 3, 7, 8, 20):
+            rhs = rng.standard_normal((500, k))
+            ref = oracle_spmm((700, 500), u(m.indptr), u(m.indices), m.data, rhs)
+            for rhs_col_major in (False, True):
+                out = a * prod.DeviceMat.from_host(rhs, col_major=rhs_col_major)
+                assert out.col_major == (k < 8)                       # csmat.rs:2002-2045: `.f()` below 8 columns
+                assert rel_err(out.to_host(), ref) <= TOL
+                for out_col_major in (False, True):                   # the accumulate kernels, every layout pair
+                    out0 = rng.standard_normal((700, k))
+                    acc = prod.DeviceMat.from_host(out0, col_major=out_col_major)
+                    kernel = {(False, False): prod.csr_mulacc_dense_rowmaj, (False, True): prod.csr_mulacc_dense_colmaj,
+                              (True, False): prod.csc_mulacc_dense_rowmaj, (True, True): prod.csc_mulacc_dense_colmaj}[(a.is_csc(), out_col_major)]
+                    kernel(a, prod.DeviceMat.from_host(rhs, col_major=rhs_col_major), acc)
+                    ref_acc = oracle_spmm((700, 500), u(m.indptr), u(m.indices), m.data, rhs, out0)
+                    assert rel_err(acc.to_host(), ref_acc) <= TOL
+        x = rng.standard_normal(500)
+        y = (a * DeviceVec.from_host(x)).to_host()                    # `&A * &x`, CSC included (csmat.rs:2140-2156)
+        assert rel_err(y, m @ x) <= TOL
+    # prod::mul_acc_mat_vec_csc and its contract (prod.rs:88-92)
+    y0 = rng.standard_normal(700)
+    yv = DeviceVec.from_host(y0)
+    prod.mul_acc_mat_vec_csc(a_csc, DeviceVec.from_host(x), yv)
+    assert rel_err(yv.to_host(), y0 + m @ x) <= TOL
+    with pytest.raises(hip.SprsHipError) as e:
+        prod.mul_acc_mat_vec_csc(a_csr, DeviceVec.from_host(x), yv)
+    assert e.value.status == _ffi.STORAGE_MISMATCH
+    with pytest.raises(hip.SprsHipError) as e:
+        prod.mul_acc_mat_vec_csc(a_csc, DeviceVec.from_host(np.zeros(499)), yv)
+    assert e.value.status == _ffi.DIM_MISMATCH
+    with pytest.raises(hip.SprsHipError) as e:                         # the twin of mul_acc_mat_vec_csr keeps ITS storage assert
+        prod.mul_acc_mat_vec_csr(a_csc, DeviceVec.from_host(x), yv)
+    assert e.value.status == _ffi.STORAGE_MISMATCH
+    # dense . sparse (csmat.rs:2050-2117), both storages of the sparse operand, both layouts of the dense one
+    for a, ms in ((a_csr, m), (a_csc, m)):
+        for k in (3, 9):
+            lhs = rng.standard_normal((k, 700))
+            for cm in (False, True):
+                got = prod.dense_dot_csmat(prod.DeviceMat.from_host(lhs, col_major=cm), a).to_host()
+                assert got.shape == (k, 500) and rel_err(got, lhs @ ms.toarray()) <= 1e-9
+    # a wrapped CSC handle whose values change in place: refresh drops the cached CSR copy
+    import torch
+    if not torch.cuda.is_available():                                  # (the CPU kernel emulator runs this test up to here)
+        return
+    dev = torch.device("cuda", 0)
+    ip = torch.from_numpy(mc.indptr.astype(np.int64)).to(dev)
+    ix = torch.from_numpy(mc.indices.astype(np.int64)).to(dev)
+    dt = torch.from_numpy(mc.data.copy()).to(dev)
+    w = DeviceCsMat.wrap_torch((700, 500), ip, ix, dt, storage=CSC)
+    xv = DeviceVec.from_host(x)
+    assert rel_err((w * xv).to_host(), m @ x) <= TOL
+    dt.mul_(2.0)
+    torch.cuda.synchronize()
+    _ffi.check(_ffi.lib.sprs_hip_csmat_refresh(w._h))
+    assert rel_err((w * xv).to_host(), 2.0 * (m @ x)) <= TOL
