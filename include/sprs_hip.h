@@ -389,13 +389,17 @@ int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const 
  *                          spmv_band_overlap, spmv_band_split_permute, spmv_band_phases, spmv_band_hot_cut;
  * name = "spgemm_ordered":  1 (default): SpGEMM adds the products of an entry in the reference's order (values bit-identical
  *                          to sprs', deterministic); 0: unordered atomic adds in the large-row kernel (same products, rounding-
- *                          level differences, not reproducible run to run, ~12 % faster on BASELINE config 5);
+ *                          level differences, not reproducible run to run; since round 4 no faster: the order costs nothing
+ *                          once a wave instruction's products go out as ONE ds_add_f64, option spgemm_lane_order);
  * name = "gauss_seidel_blocks": workgroups of the Gauss-Seidel sweep kernel (0 = default: one per CU), "gauss_seidel_naps";
  * name = "spgemm_*", "spmm_long_row", "pool", "pool_max_bytes": INTEGRATION.md, "Options".
  * The whole table (name, default, range) is SPRS_HIP_OPTIONS in sprs_amd/csrc/common.hpp.  Developer switches — timing
  * experiments with WRONG results (spgemm_debug, spmv_xmask, spmv_band_debug) and the profiling printout spgemm_prof — exist
  * only in libraries built with -DSPRS_HIP_DEVTOOLS; this one rejects them.  get_option("devtools") tells which build it is.
  * Process-wide.  Unknown names / bad values return SPRS_HIP_INVALID_ARG. */
+/* Contract: every option has a closed range (the table in sprs_amd/csrc/common.hpp); a value outside it — including a value
+ * other than 0 / 1 for an on / off switch — and an unknown or retired name return SPRS_HIP_INVALID_ARG and change nothing
+ * (sprs_hip_last_error() names the option and its range).  Nothing is coerced. */
 int32_t sprs_hip_set_option(const char *name, int64_t value);
 int32_t sprs_hip_get_option(const char *name, int64_t *value);
 

@@ -170,15 +170,16 @@ __global__ __launch_bounds__(GS_BLOCK) void gs_sweep_kernel(const PTR *__restric
                             out = GS_QNAN;
                         }
                         if (out == GS_PENDING) out = GS_QNAN;   // (a NaN payload handed through from rhs / x: still a NaN, but not "pending")
-                        if constexpr (ONE_XCD) __hip_atomic_store(x_new + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // plain store: into the shared L2
-                        else __hip_atomic_store(x_new + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                         // write-through (sc1): every XCD sees it
+                        __hip_atomic_store(x_new + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // agent scope in both modes: the pollers sit on other CUs
                         done = true;
                     }
                 }
             }
             more = __ballot(!done) != 0ull;
             if (more) {
-                spins = moved ? 0u : spins + 1u;
+                // rounds in which NO lane of the wave got anywhere (a lane that has finished its row would otherwise count every
+                // round its neighbours are still busy with theirs and raise the timeout on a healthy sweep)
+                spins = __ballot(moved) != 0ull ? 0u : spins + 1u;
                 unsigned int st = 0;
                 if ((spins & 63u) == 63u) st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (spins > GS_SPIN_LIMIT) {
@@ -311,7 +312,7 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
                   (unsigned long long)no_diag_row);
 
     const uint64_t nchunks = (n + SUM_CHUNK - 1) / SUM_CHUNK;
-    unsigned int st = 0;                       // (declared before `w`: its destructor drains the stream that may still write them)
+    unsigned int sweep_words[2] = {0, 0};      // (declared before `w`: its destructor drains the stream that may still write them)
     double h_sum = 0.0;
     Work w;
     w.stream = stream;
@@ -363,11 +364,17 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
                                (const IDX *)a->indices, (const double *)a->data, order, (const double *)cur,
                                (unsigned long long *)nxt, rhs, n, next_chunk, status, max_naps);
         SPRS_TRY_HIP(hipGetLastError());
-        SPRS_TRY_HIP(hipMemcpyAsync(&st, status, sizeof(st), hipMemcpyDeviceToHost, stream));
+        SPRS_TRY_HIP(hipMemcpyAsync(sweep_words, w.words, sizeof(sweep_words), hipMemcpyDeviceToHost, stream));   // [0] chunks drawn, [1] status
         double *t = cur;
         cur = nxt;
         nxt = t;
-        SPRS_TRY(residual_error(cur, error));                                  // (drains the stream: st is valid after it)
+        SPRS_TRY(residual_error(cur, error));                                  // (drains the stream: the two words are valid after it)
+        const unsigned int st = sweep_words[1];
+        // every position of the level order must have been drawn by some wave: in the one-XCD mode the workgroups that do not
+        // find themselves on XCD 0 leave at once, and a device that puts none there would return the 0xFF fill as the iterate
+        if ((uint64_t)sweep_words[0] * 64u < n)
+            SPRS_FAIL(SPRS_HIP_HIP_ERROR, "Gauss-Seidel sweep: only %llu of %llu rows were swept (no workgroup took part: gauss_seidel_xcd on a device without workgroups on XCD 0?)",
+                      (unsigned long long)sweep_words[0] * 64ull, (unsigned long long)n);
         if (st & GS_TIMEOUT)
             SPRS_FAIL(SPRS_HIP_HIP_ERROR, "Gauss-Seidel sweep: a row waited for a value that was never published (level order broken)");
         if (st & GS_NO_DIAG) SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Gauss-Seidel: a row has no stored diagonal entry");

@@ -634,7 +634,9 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         // of every row's sum on a third stream beside the second launch (the first 64 of 128 slices of R-MAT 10M hold 94 % of
         // the hot entries and 78 % of the partial sums).  Measured NEGATIVE, so off by default: the reduction then competes
         // with the gather kernels and the second launch for the same fabric — 1.060 .. 1.090 ms for c = 32 .. 80 against
-        // 1.045 ms in one part (medians of 3, profiles/r05o); bit-identical results either way (tests/test_spmv_band_gpu.py).
+        // 1.045 ms in one part (medians of 3, profiles/r05o).  The cut changes the ASSOCIATION of a row's sum (which slices are added
+        // together first): results with and without it agree to rounding (1e-13, tests/test_spmv_band_gpu.py::test_two_part_reduction), not
+        // bit for bit; each setting on its own is deterministic run to run.
         uint32_t cut = 0;
         if (o.spmv_band_hot_cut > 0) {
             cut = (uint32_t)o.spmv_band_hot_cut / RU * RU;

@@ -16,6 +16,7 @@ the RCCL backend).  The same code runs on gloo for the CPU tests.
 torch / torch.distributed are plumbing here (device memory, process group);
 the multiply itself is `local_spmv`, by default the HIP path.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -206,7 +207,10 @@ class RowShardedBiCGSTAB:
         t = torch.dot(u, v).reshape(1)
         if self.sh.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return float(t.item())
+        # IEEE scalars (numpy float64), not Python floats: an exact breakdown or exact convergence (r == 0, A = I: rho / 0, 0 / 0)
+        # gives inf / NaN and the iteration goes on to Err / Ok like the reference (bicgstab.rs:193-223), where a Python float
+        # would raise ZeroDivisionError
+        return np.float64(t.item())
 
     # ---- the reference's solver, operand for operand ------------------------------------------------------------------
     def soft_restart(self):
@@ -218,11 +222,15 @@ class RowShardedBiCGSTAB:
     def hard_restart(self):
         self.hard_restart_count += 1
         self.r = self.b - self._matvec(self.x)
-        self.err = self._dot(self.r, self.r) ** 0.5
+        self.err = np.sqrt(self._dot(self.r, self.r))
         self.soft_restart()
         self.soft_restart_count -= 1
 
     def step(self):
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            return self._step()
+
+    def _step(self):
         self.iteration_count += 1
         v = self._matvec(self.p)
         alpha = self.rho / self._dot(self.rhat, v)
@@ -232,7 +240,7 @@ class RowShardedBiCGSTAB:
         omega = self._dot(t, s) / self._dot(t, t)
         self.x = h + s * omega
         self.r = s - t * omega
-        self.err = self._dot(self.r, self.r) ** 0.5
+        self.err = np.sqrt(self._dot(self.r, self.r))
         rho_prev = self.rho
         self.rho = self._dot(self.rhat, self.r)
         if abs(self.rho) / (self.err * self.err) < self.soft_restart_threshold:

@@ -181,3 +181,30 @@ def test_row_sharded_bicgstab_gloo(world):
         assert conv and conv_ref
         assert abs(it - it_ref) <= 2, (it, it_ref)
         assert dx <= 1e-9 and res <= 1e-8
+
+
+def test_row_sharded_bicgstab_breakdown_like_the_reference():
+    """A = I, b = x0 + e: the first step solves the system exactly and the recurrences divide 0 by 0.  The reference computes in
+    IEEE floats (bicgstab.rs:193-223: omega = NaN, the iteration goes on and ends in Err / Ok through solve()); the row-sharded
+    solver must not raise ZeroDivisionError there (world of one: no process group needed)."""
+    from oracle import oracle
+    from sprs_amd.dist import RowShardedBiCGSTAB, RowShardedSpMV
+    n = 50
+    indptr = torch.arange(n + 1, dtype=torch.int64)
+    indices = torch.arange(n, dtype=torch.int64)
+    data = torch.ones(n, dtype=torch.float64)
+
+    def local_spmv(block, x, y_block):
+        rows, cols, bip, bix, bdt = block
+        y = np.zeros(rows)
+        oracle.mul_acc_mat_vec_csr((rows, cols), bip.numpy().astype(np.uint64), bix.numpy().astype(np.uint64), bdt.numpy(), x.numpy(), y)
+        y_block.copy_(torch.from_numpy(y))
+
+    sh = RowShardedSpMV((n, n), indptr, indices, data, local_spmv)
+    b = torch.linspace(1.0, 2.0, n, dtype=torch.float64)
+    for x0 in (b.clone(), torch.zeros(n, dtype=torch.float64)):       # x0 already the solution (r = 0), and one exact step away
+        sol = RowShardedBiCGSTAB.solve(sh, x0, b, 1e-12, 5)
+        _, info = oracle.bicgstab((n, n), indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy(),
+                                  x0.numpy(), b.numpy(), 1e-12, 5)
+        assert bool(sol.converged) == bool(info["converged"])
+        assert int(sol.iteration_count) == int(info["iteration_count"])
