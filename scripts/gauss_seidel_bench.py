@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Gauss-Seidel sweep (twin of gauss_seidel() of the reference's heat example, heat.rs:103-139) on the heat system of a
 G x G grid: time per sweep on the device (sweep kernel + the residual SpMV + the convergence scalar, as the reference's loop
-has them), the one-time plan (level order on the host, SpMV plan), the CPU oracle's time per sweep beside it, and parity:
+has them), the one-time plan (level order on the device, SpMV plan), the CPU oracle's time per sweep beside it, and parity:
 the iterate after K sweeps bit for bit against the oracle (at the full size: the oracle sweeps 1.7e7 rows in ~0.4 s).
 usage: gauss_seidel_bench.py [G] [K] [blocks[:naps[:xcd]] ...]     (defaults 4096 3 and the library's defaults; blocks = workgroups
 of the sweep kernel, naps = longest pause of a waiting wave)"""
