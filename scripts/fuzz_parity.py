@@ -286,6 +286,8 @@ def case_bicgstab(rng):
     # two solvers reach comparable residuals, and where both converged the solutions agree to the tolerance asked for.
     r_gpu, r_ref = np.linalg.norm(b - m @ x), np.linalg.norm(b - m @ ref)
     ok = bool(np.isfinite(r_gpu) and r_gpu <= 1e3 * max(r_ref, tol) and res.iteration_count() <= it)
+    if not np.isfinite(r_ref) and not np.isfinite(r_gpu):        # a breakdown (0 / 0 in the recurrences) on both sides: the same NaN story
+        ok = res.iteration_count() == info["iteration_count"] and bool(res.converged) == bool(info["converged"])
     if res.converged:
         ok = ok and abs(res.err() - r_gpu) <= 1e-6 * max(r_gpu, 1e-300) + 1e-14 * np.linalg.norm(b) and res.err() < tol
     if res.converged and info["converged"]:
@@ -293,7 +295,44 @@ def case_bicgstab(rng):
     return bool(ok), dict(kind="bicgstab", n=n, tol=tol, max_iter=it, gpu=(res.iteration_count(), float(r_gpu)), ref=(info["iteration_count"], float(r_ref)))
 
 
-CASES = (case_spmv, case_spgemm, case_spmm, case_gauss_seidel, case_dispatch, case_kept_plan, case_triplets, case_sliced_view,
+def case_dense(rng):
+    """the dense-operand dispatch below the ABI: `&CsMat * &Array2` (both storages, both layouts of the rhs, the layout rule of the
+    result), the four accumulate kernels with explicit layouts, `&CsMat * &Array1` on CSC, dense . sparse"""
+    import scipy.sparse as sp
+    from sprs_amd import prod
+    from sprs_amd.device import CSC
+    idx, ptr = types(rng)
+    rows, cols, k = int(rng.integers(1, 900)), int(rng.integers(1, 1200)), int(rng.choice([1, 2, 5, 7, 8, 9, 17, 40]))
+    shape, ip, ix, dt = random_csr(rng, rows, cols, idx, ptr)
+    m = sp.csr_matrix((dt, ix.astype(np.int64), ip.astype(np.int64)), shape=shape)
+    absm = abs(m)
+    csc = bool(rng.integers(0, 2))
+    if csc:
+        mc = m.tocsc()
+        mc.sort_indices()
+        a = DeviceCsMat.from_host(shape, mc.indptr.astype(ptr), mc.indices.astype(idx), mc.data, storage=CSC)
+    else:
+        a = DeviceCsMat.from_host(shape, ip, ix, dt)
+    rhs = rng.standard_normal((cols, k))
+    rcm, ocm = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    tol = lambda got, ref, mag: np.abs(got - ref) <= 1e-10 * np.maximum(np.abs(ref), 1e-300) + 256 * np.finfo(float).eps * mag
+    out = a * prod.DeviceMat.from_host(rhs, col_major=rcm)
+    ok = out.col_major == (k < 8) and bool(tol(out.to_host(), m @ rhs, absm @ np.abs(rhs)).all())
+    out0 = rng.standard_normal((rows, k))
+    acc = prod.DeviceMat.from_host(out0, col_major=ocm)
+    kern = {(False, False): prod.csr_mulacc_dense_rowmaj, (False, True): prod.csr_mulacc_dense_colmaj,
+            (True, False): prod.csc_mulacc_dense_rowmaj, (True, True): prod.csc_mulacc_dense_colmaj}[(csc, ocm)]
+    kern(a, prod.DeviceMat.from_host(rhs, col_major=rcm), acc)
+    ok = ok and bool(tol(acc.to_host(), out0 + m @ rhs, np.abs(out0) + absm @ np.abs(rhs)).all())
+    x = rng.standard_normal(cols)
+    ok = ok and bool(tol((a * DeviceVec.from_host(x)).to_host(), m @ x, absm @ np.abs(x)).all())
+    lhs = rng.standard_normal((int(rng.choice([1, 3, 9])), rows))
+    got = prod.dense_dot_csmat(prod.DeviceMat.from_host(lhs, col_major=rcm), a).to_host()
+    ok = ok and bool(tol(got, lhs @ m.toarray(), np.abs(lhs) @ absm.toarray()).all())
+    return ok, dict(kind="dense", rows=rows, cols=cols, k=k, csc=csc, rhs_col_major=rcm, out_col_major=ocm, idx=str(np.dtype(idx)), ptr=str(np.dtype(ptr)))
+
+
+CASES = (case_dense, case_spmv, case_spgemm, case_spmm, case_gauss_seidel, case_dispatch, case_kept_plan, case_triplets, case_sliced_view,
          case_spmv, case_spgemm, case_bicgstab)
 
 

@@ -386,7 +386,9 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     *out = nullptr;
     if (rows >= 0xFFFFFFFFull || cols >= 0x7FFFFFFFull || !nnz) return SPRS_HIP_OK;   // bit 31 of a label flags a row start
     // rows with at least this many entries are "long" (cut into pieces)
-    const uint64_t split = o.spmv_band_split > 0 ? (uint64_t)o.spmv_band_split : 24ull;
+    // (24 measured best on R-MAT 10M; a small matrix — fewer than ~400 hot tiles per CU, the `small` plans below — does better
+    // with 8: R-MAT 1M 0.087 against 0.092 ms with two rounds of hot workgroups, profiles/r10u, r10v)
+    const uint64_t split = o.spmv_band_split > 0 ? (uint64_t)o.spmv_band_split : (nnz < 400ull * 256ull * 512ull ? 8ull : 24ull);
     const uint32_t xt_log2 = o.spmv_band_tile == 8192 ? 13u : 14u;
     const uint64_t XT = 1ull << xt_log2;
 
@@ -627,7 +629,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         // bound — every wave gets only a few tiles — and does better with more, shorter shares and single-tile ranges
         // (hot kernel 45 against 61 us, profiles/r05p)
         const bool small_hot = hot_tiles < 400ull * (uint64_t)ncu;
-        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : (small_hot ? 4 : 2);
+        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : 2;      // (small plans: 4 rounds until round 4; 2 measured better with split 8, profiles/r10u)
         if (o.spmv_band_hot_run <= 0 && small_hot) bp->hot_run = 1;
         bp->small = small_hot;
         // Option spmv_band_hot_cut = c: two hot launches, slices [0, c) then [c, nh), and the first slices' carries and their part
