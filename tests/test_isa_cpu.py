@@ -1,0 +1,75 @@
+"""Guards of two compiler-level facts this path depends on (hipcc cross-compiles without a GPU):
+
+* the entry loads of a chunk / batch of the SpGEMM window kernels go out back to back.  A load under a per-lane condition is
+  compiled as a branch whose arm ends in `s_waitcnt vmcnt(0)` for that one load; rounds 1 - 3 shipped kernels whose "independent"
+  loads were four / eight memory round trips one after the other and nothing but the ISA shows it;
+* the row loop of the wave-per-row kernels draws its rows in the loop HEADER (`for (q = draw(); q < n; q = draw())`): written as
+  `for (;;) { q = draw(); if (q >= n) break; ... }` one build variant was compiled into a loop that never ended on config 5.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def spgemm_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "spgemm.s"
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "--cuda-device-only", "-S",
+                           os.path.join(ROOT, "sprs_amd", "csrc", "spgemm.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    kernels = {}
+    for m in re.finditer(r"^(_ZN8sprs_hip\S+):\s*; @\S+\n(.*?)^\s*s_endpgm", text, flags=re.S | re.M):
+        kernels[m.group(1)] = m.group(2)
+    return kernels
+
+
+def longest_load_burst(body):
+    """most global loads issued without a wait for memory in between"""
+    best = cur = 0
+    for line in body.splitlines():
+        ins = line.strip().split(" ")[0]
+        if ins.startswith("global_load"):
+            cur += 1
+            best = max(best, cur)
+        elif ins == "s_waitcnt" and "vmcnt" in line:
+            cur = 0
+    return best
+
+
+def pick(kernels, *parts):
+    names = [k for k in kernels if all(p in k for p in parts)]
+    assert names, parts
+    return names
+
+
+def test_chunk_loads_of_the_wave_kernels_are_issued_together(spgemm_isa):
+    # numeric, usize / usize, windows of 2^15, chunks of 8 wave instructions: 8 records = 16 loads (column dword + value dwordx2)
+    for name in pick(spgemm_isa, "mid_rows_kernelImmLb1ELi15ELi8E"):
+        assert longest_load_burst(spgemm_isa[name]) >= 16, name
+    # counting twin: 8 column loads
+    for name in pick(spgemm_isa, "mid_rows_kernelImmLb0ELi14ELi8E"):
+        assert longest_load_burst(spgemm_isa[name]) >= 8, name
+
+
+def test_batch_loads_of_the_workgroup_kernel_are_issued_together(spgemm_isa):
+    # numeric: 4 records per batch = 8 loads; counting: 4 column loads
+    for name in pick(spgemm_isa, "large_rows_kernelILi17EmmLb1ELi6E"):
+        assert longest_load_burst(spgemm_isa[name]) >= 8, name
+    for name in pick(spgemm_isa, "large_rows_kernelILi18EmmLb0ELi1E"):
+        assert longest_load_burst(spgemm_isa[name]) >= 4, name
+
+
+def test_row_draw_sits_in_the_loop_header():
+    src = open(os.path.join(ROOT, "sprs_amd", "csrc", "spgemm.hip")).read()
+    assert "for (uint64_t q = draw_row(); q < n_mid; q = draw_row())" in src
+    body = src[src.index("void mid_rows_kernel("):src.index("// ranks of the batch's columns")]
+    body = re.sub(r"//[^\n]*", "", body)                     # (the comment that tells the story quotes the bad form)
+    assert "for (;;)" not in body, "a wave-uniform draw inside `for (;;)` + `break` was mis-compiled once (DESIGN 4.2)"
