@@ -23,6 +23,8 @@ def main():
     g = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     blocks = [tuple(int(t) for t in (v + ":0:0").split(":")[:3]) for v in sys.argv[3:]] or [(0, 0, 0)]
+    if os.environ.get("GS_CHAIN"):                       # 1: level order only; S > 1: the band schedule with this stride (default auto)
+        sprs_amd.set_option("gauss_seidel_chain", int(os.environ["GS_CHAIN"]))
     if os.environ.get("GS_BANDED"):
         # experiment: the same number of rows, entries per row and levels as the heat system, but the rows of a level are
         # CONTIGUOUS (row i reads rows i - W and i - W + 1): hand-offs of neighbouring lanes share cache lines

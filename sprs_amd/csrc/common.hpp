@@ -92,7 +92,8 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_minwin, 13, 11, 16, 0)     /* log2 of the narrowest column window of a heavy row */                                  \
     X(spgemm_heavy, 524288, 1024, INT64_MAX, 0) /* a row of more products is cut into one task per (narrower) column window */    \
     X(gauss_seidel_blocks, 0, 0, 65536, 0) /* workgroups (4 waves) of the Gauss-Seidel sweep kernel (0 = default: one per CU) */          \
-    X(gauss_seidel_chain, 0, 0, 1ll << 30, 0) /* rows one lane sweeps one after the other: 0 auto, 1 one row per lane in level order, L > 1 chains of L consecutive rows */ \
+    X(gauss_seidel_chain, 0, 0, 1ll << 30, 0) /* 0 / 1: rows in dependency-level order, one row per lane; S > 1: the band schedule — chains of S consecutive rows per lane, skewed, hand-offs through LDS inside a workgroup (bit-identical; measured not faster as built: DESIGN 4.5) — with this stride, INVALID_ARG when the matrix does not fit it */ \
+    X(gauss_seidel_debug, 0, 0, 255, 1) /* TIMING EXPERIMENTS ONLY (wrong results): band kernel without 1 any pipeline work, 2 operand loads, 4 entry loads, 8 index loads */ \
     X(gauss_seidel_xcd, 0, 0, 2, 0)     /* sweep kernel: 1 only the workgroups that find themselves on XCD 0 take part (hand-offs through ONE L2), 0 / 2 every XCD (measured: one XCD is not faster) */ \
     X(gauss_seidel_naps, 0, 0, 64, 0)   /* longest pause of a wave whose rows all wait, in s_sleep(1) units, growing with the wait (0 = default 1) */ \
     X(pool, 1, 0, 1, 0)                 /* keep released result blocks (>= 1 MiB) for the next result instead of hipFree */        \
@@ -166,6 +167,8 @@ struct GsPlan {
     uint32_t *order = nullptr;         // device, rows entries: row swept at position q (levels ascending, rows ascending inside a level)
     uint64_t nlevels = 0;
     uint64_t no_diag_row = UINT64_MAX; // first row without a stored diagonal entry (the reference's diag.unwrap() panics there)
+    uint64_t chain_tried = 0;          // stride the band schedule was last checked for (0: never) ...
+    bool chain_ok = false;             // ... and whether every dependency fits it (gs_band_check_kernel)
     void release();
 };
 

@@ -42,6 +42,8 @@ void GsPlan::release() {
     built = false;
     nlevels = 0;
     no_diag_row = UINT64_MAX;
+    chain_tried = 0;
+    chain_ok = false;
 }
 
 namespace {
@@ -400,6 +402,272 @@ int32_t gs_plan_build(sprs_hip_csmat *a) {
     return SPRS_HIP_OK;
 }
 
+// ---- chains of consecutive rows: a systolic sweep for banded / grid systems (option gauss_seidel_chain) -------------------------------
+// In level order a sweep costs one publish -> poll hop through the memory system per LEVEL (2.3 us; 8 188 levels on the 4096 x 4096 heat
+// system).  When the matrix is a band — row i reads row i - 1 and row i - S, the 5-point stencil with S = the grid width — the hops
+// can stay inside a workgroup.  A BAND is 64 S consecutive rows; lane l of the workgroup owns the chain of rows B + l S ... B + l S +
+// S - 1 and walks it in order, one row per STEP, skewed: at global step T lane l sweeps its row t = T - l.  Its two band
+// neighbours are then exactly one step old — row i - 1 is the lane's own previous row, row i - S is what lane l - 1 swept at step
+// T - 1 — and come out of a two-row ring in LDS.  The GB_WAVES waves of the workgroup take the steps in turn (wave w: steps w, w + 8, ...):
+// while seven waves sweep their steps, the eighth's loads for its next steps are in flight (index pair three turns ahead, entries
+// two, operands one), and an LDS word hands the turn on.  Every other stored column c < i is polled in the next iterate like in the
+// level-order kernel (lane 0's row above lives in the previous band, 64 steps ahead of it).  Same operands, same order, same
+// arithmetic per row: the iterates stay bit-identical to the CPU sweep.
+// The schedule must respect every dependency, so the plan CHECKS it (gs_band_check_kernel): rows of at most GB_E entries, and every
+// stored c < i inside i's band must be swept at an earlier step than i; a matrix that fails keeps the level-order kernel.
+constexpr int GB_WAVES = 8, GB_BLOCK = GB_WAVES * 64, GB_E = 8;
+
+#ifdef SPRS_HIP_EMU
+__device__ __forceinline__ uint32_t gb_lds_load(const uint32_t *p) { return *(const volatile uint32_t *)p; }
+__device__ __forceinline__ void gb_lds_store(uint32_t *p, uint32_t v) { *(volatile uint32_t *)p = v; }
+#else
+typedef __attribute__((address_space(3))) volatile uint32_t gb_lds_vu32;
+__device__ __forceinline__ uint32_t gb_lds_load(const uint32_t *p) { return *(const gb_lds_vu32 *)p; }
+__device__ __forceinline__ void gb_lds_store(uint32_t *p, uint32_t v) { *(gb_lds_vu32 *)p = v; }
+#endif
+
+template <typename IDX, typename PTR>
+__global__ void gs_band_check_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices, uint64_t n, uint64_t S,
+                                     unsigned int *__restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t p0 = (uint64_t)indptr[i], p1 = (uint64_t)indptr[i + 1];
+    if (p1 - p0 > (uint64_t)GB_E) {
+        atomicOr(bad, 1u);
+        return;
+    }
+    const uint64_t band = 64 * S, B = i / band * band;
+    const uint64_t Ti = (i - B) / S + (i - B) % S;                       // lane + step
+    for (uint64_t p = p0; p < p1; ++p) {
+        const uint64_t c = (uint64_t)indices[p];
+        if (c >= i) break;
+        if (c >= B && (c - B) / S + (c - B) % S >= Ti) atomicOr(bad, 2u);
+    }
+}
+
+struct GbRow {                       // one row on its way to the sweep
+    uint32_t col[GB_E];
+    double val[GB_E];
+    double b;
+};
+
+template <typename IDX, typename PTR>
+__global__ __launch_bounds__(GB_BLOCK) void gs_band_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
+                                                           const double *__restrict__ data, const double *__restrict__ x_old,
+                                                           unsigned long long *x_new, const double *__restrict__ rhs, uint64_t n,
+                                                           uint64_t S, unsigned int *next_band, unsigned int *status, uint32_t dbg) {
+    __shared__ double xs[2][64];
+    __shared__ uint32_t step_done, band_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t nsteps = S + 63;
+    for (;;) {
+        if (tid == 0) {
+            band_s = atomicAdd(next_band, 1u);
+            gb_lds_store(&step_done, 0u);
+        }
+        __syncthreads();
+        const uint64_t B = (uint64_t)band_s * 64u * S;
+        if (B >= n) return;
+        const uint64_t chain0 = B + (uint64_t)lane * S;
+        auto row_of = [&](uint64_t T, bool &act) -> uint64_t {           // my row at global step T
+            const uint64_t t = T - lane;
+            act = T >= lane && t < S && chain0 + t < n;
+            return act ? chain0 + t : 0ull;
+        };
+        // the pipeline of one wave: q3 = index pair of step T + 3 W, r2 = entries of step T + 2 W, r1 = entries and operands of T + W.
+        // Everything that can be decided ahead of a row's step is decided in stage 3, two turns ahead, and travels as bit masks: the
+        // step itself — the only thing on the band's critical path — is two LDS reads, eight select / multiply / add triples in entry
+        // order and the division.  (First version: the step classified its entries itself, ~1 200 instructions of divergent code for a
+        // wave that runs alone on its SIMD: 1.7 us per step, no faster than a level of the level-order kernel.)
+        uint64_t q3s = 0, q3e = 0, q2s = 0, q2e = 0;
+        GbRow r2, r1;
+        double valc[GB_E], opc[GB_E], op1[GB_E], bc = 0.0, dg1 = 0.0, dgc = 0.0;
+        uint32_t nb2 = 0, nb1 = 0, m1 = 0, mc = 0;     // masks, one bit per entry: 0-7 own previous row, 8-15 chain above, 16-23 not added (diagonal, past the row), 24-31 polled, 32: has a diagonal (bit 31 of the high half: kept in hd)
+        bool hd1 = false, hdc = false;
+        auto stage1 = [&](uint64_t T) {                                   // index pair
+            bool act;
+            const uint64_t r = row_of(T, act);
+            q3s = (uint64_t)indptr[r];
+            q3e = act ? (uint64_t)indptr[r + 1] : q3s;
+        };
+        auto stage2 = [&](uint64_t T) {                                   // entries and rhs of the row whose pair arrived
+            bool act;
+            const uint64_t r = row_of(T, act);
+            nb2 = (uint32_t)(q2e - q2s);
+#pragma unroll
+            for (int u = 0; u < GB_E; ++u) {
+                const uint64_t at = nb2 ? q2s + ((uint32_t)u < nb2 ? (uint64_t)u : 0ull) : 0ull;      // (unconditional loads)
+                r2.col[u] = (uint32_t)indices[at];
+                r2.val[u] = data[at];
+            }
+            r2.b = rhs[r];
+        };
+        auto stage3 = [&](uint64_t T) {                                   // operands and masks of the row whose entries arrived
+            bool act;
+            const uint64_t r = row_of(T, act);
+            // eight UNCONDITIONAL loads through a selected pointer: the previous iterate for columns behind the row, this sweep's word
+            // (value or GS_PENDING) for columns before it
+            unsigned long long bits[GB_E];
+#pragma unroll
+            for (int u = 0; u < GB_E; ++u) {
+                const uint32_t c = (uint32_t)u < nb1 ? r1.col[u] : (uint32_t)r;
+                // (the two band neighbours come out of LDS at the step: their words in the next iterate are being written right now by
+                // the neighbouring lanes — nothing to fetch there; the load goes to the previous iterate and is dropped)
+                const bool nb_prev = (uint64_t)c + 1 == r && T > lane, nb_above = lane > 0 && (uint64_t)c + S == r;
+                const unsigned long long *src = ((uint64_t)c > r || nb_prev || nb_above || (uint32_t)u >= nb1) ? (const unsigned long long *)(x_old + c)
+                                                                                                              : (const unsigned long long *)(x_new + c);
+                bits[u] = gs_peek(src);
+            }
+            uint32_t m = 0;
+            dg1 = 0.0;
+            hd1 = false;
+#pragma unroll
+            for (int u = 0; u < GB_E; ++u) {
+                const uint64_t c = r1.col[u];
+                const bool in = (uint32_t)u < nb1 && act;
+                const bool is_dg = in && c == r;
+                const bool prev = in && c + 1 == r && T > lane;
+                const bool above = in && !prev && lane > 0 && c + S == r;
+                if (is_dg) {
+                    dg1 = r1.val[u];
+                    hd1 = true;
+                }
+                m |= (prev ? 1u : 0u) << u;
+                m |= (above ? 1u : 0u) << (8 + u);
+                m |= ((!in || is_dg) ? 1u : 0u) << (16 + u);
+                m |= ((in && c < r && !prev && !above) ? 1u : 0u) << (24 + u);
+            }
+            m1 = m;
+            // A row of an EARLIER band (lane 0's row above) is waited for HERE, two turns before its use: the band then trails the band
+            // above by the depth of this pipeline and finds the value in a register when its step comes (waiting at the use keeps the
+            // band "just in time": every step then pays a poll's round trip).  Rows of this band are not waited for here — the wave
+            // itself may be the one that sweeps them.
+            if (__ballot((m >> 24) != 0u) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < GB_E; ++u) {
+                    if (((m >> (24 + u)) & 1u) && (uint64_t)r1.col[u] < B) {
+                        uint32_t sp = 0;
+                        while (bits[u] == GS_PENDING) {
+                            SPRS_POLL_PAUSE();
+                            bits[u] = gs_peek(x_new + r1.col[u]);
+                            if (++sp > GS_SPIN_LIMIT) {
+                                atomicOr(status, GS_TIMEOUT);
+                                break;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GB_E; ++u) op1[u] = __longlong_as_double((long long)bits[u]);
+        };
+        uint32_t colc[GB_E];                                              // columns of the current row: only the rare poll at the use reads them
+        auto rotate_to_current = [&]() {
+#pragma unroll
+            for (int u = 0; u < GB_E; ++u) {
+                valc[u] = r1.val[u];
+                colc[u] = r1.col[u];
+                opc[u] = op1[u];
+            }
+            bc = r1.b;
+            mc = m1;
+            dgc = dg1;
+            hdc = hd1;
+        };
+        // fill the pipeline for my first step T = wave
+        stage1((uint64_t)wave);
+        q2s = q3s; q2e = q3e;
+        stage2((uint64_t)wave);
+        r1 = r2; nb1 = nb2;
+        stage3((uint64_t)wave);
+        rotate_to_current();
+        stage1((uint64_t)wave + GB_WAVES);
+        q2s = q3s; q2e = q3e;
+        stage2((uint64_t)wave + GB_WAVES);
+        r1 = r2; nb1 = nb2;
+        stage3((uint64_t)wave + GB_WAVES);
+        stage1((uint64_t)wave + 2 * GB_WAVES);
+        q2s = q3s; q2e = q3e;
+        stage2((uint64_t)wave + 2 * GB_WAVES);
+        stage1((uint64_t)wave + 3 * GB_WAVES);
+        bool dead = false;
+        for (uint64_t T = wave; T < nsteps; T += GB_WAVES) {
+            // ---- my turn ----
+            uint32_t spins = 0;
+            while (gb_lds_load(&step_done) != (uint32_t)T) {
+                SPRS_POLL_PAUSE();
+                if (++spins > GS_SPIN_LIMIT) {
+                    atomicOr(status, GS_TIMEOUT);
+                    dead = true;
+                    break;
+                }
+            }
+            if (dead) break;
+            wave_sync_lds();
+            bool act;
+            const uint64_t row = row_of(T, act);
+            // rare: a polled operand (a row of this band outside the two band neighbours, or of an earlier band when the pipeline
+            // was filled) that was not there two turns ago
+            {
+                uint32_t pend = 0;
+#pragma unroll
+                for (int u = 0; u < GB_E; ++u)
+                    if (((mc >> (24 + u)) & 1u) && (unsigned long long)__double_as_longlong(opc[u]) == GS_PENDING) pend |= 1u << u;
+                if (__ballot(pend != 0u) != 0ull) {
+#pragma unroll
+                    for (int u = 0; u < GB_E; ++u)
+                        if ((pend >> u) & 1u) {
+                            unsigned long long bits = GS_PENDING;
+                            uint32_t sp = 0;
+                            while (bits == GS_PENDING) {
+                                bits = gs_peek(x_new + colc[u]);
+                                if (++sp > GS_SPIN_LIMIT) {
+                                    atomicOr(status, GS_TIMEOUT);
+                                    break;
+                                }
+                            }
+                            opc[u] = __longlong_as_double((long long)bits);
+                        }
+                }
+            }
+            const uint32_t prev = (uint32_t)((T + 1) & 1);                // ring row written at step T - 1
+            const double own = xs[prev][lane], left = xs[prev][lane ? lane - 1 : 0];
+            double sigma = 0.0;
+#pragma unroll
+            for (int u = 0; u < GB_E; ++u) {                              // entry order; an entry that is not added contributes +0.0 (a sum that starts at +0.0 never is -0.0)
+                const double xv = ((mc >> u) & 1u) ? own : ((mc >> (8 + u)) & 1u) ? left : opc[u];
+                const double prod = valc[u] * xv;
+                const double term = ((mc >> (16 + u)) & 1u) ? 0.0 : prod;
+                sigma = sigma + term;
+            }
+            if (act) {
+                const double xr = (bc - sigma) / dgc;                     // heat.rs:128-130
+                unsigned long long out = (unsigned long long)__double_as_longlong(xr);
+                if (!hdc && !(DEVTOOLS && dbg)) {
+                    atomicOr(status, GS_NO_DIAG);
+                    out = GS_QNAN;
+                }
+                if (out == GS_PENDING) out = GS_QNAN;
+                xs[T & 1][lane] = __longlong_as_double((long long)out);
+                __hip_atomic_store(x_new + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            SPRS_LDS_FENCE();
+            wave_sync_lds();
+            if (lane == 0) gb_lds_store(&step_done, (uint32_t)T + 1u);
+            // ---- rotate the pipeline: the loads issued a turn ago have had seven steps of the other waves to arrive ----
+            if (DEVTOOLS && (dbg & 1u)) continue;                        // timing experiment (WRONG results): no pipeline work at all
+            rotate_to_current();
+            r1 = r2; nb1 = nb2;
+            if (!(DEVTOOLS && (dbg & 2u))) stage3(T + 2 * GB_WAVES);     // timing experiment (WRONG results): no operand loads
+            q2s = q3s; q2e = q3e;
+            if (!(DEVTOOLS && (dbg & 4u))) stage2(T + 3 * GB_WAVES);
+            if (!(DEVTOOLS && (dbg & 8u))) stage1(T + 4 * GB_WAVES);
+        }
+        __syncthreads();                                                 // the band is done (or the sweep is being abandoned)
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & GS_TIMEOUT) return;
+    }
+}
+
 struct Work {
     double *buf = nullptr;
     unsigned int *words = nullptr;
@@ -414,15 +682,45 @@ struct Work {
 template <typename IDX, typename PTR>
 int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uint64_t max_iter, double eps,
                 sprs_hip_gauss_seidel_info *info, hipStream_t stream) {
-    if (options().gauss_seidel_chain > 1)
-        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "gauss_seidel_chain = %lld: chains of consecutive rows per lane are not built yet (0 / 1: one row per lane in level order)",
-                  (long long)options().gauss_seidel_chain);
     // held for the whole solve: the level order (and the SpMV plan of the residual) must outlive every launch that reads them;
     // sprs_hip_csmat_refresh / _free on another thread wait (recursive: the SpMV of the residual locks again)
     std::lock_guard<std::recursive_mutex> lock(a->mu);
     if (!a->gs.built) SPRS_TRY((gs_plan_build<IDX, PTR>(a)));
     const uint32_t *order = a->gs.order;
     const uint64_t nlevels = a->gs.nlevels, no_diag_row = a->gs.no_diag_row;
+    // ---- the band schedule, when the matrix fits one ----
+    uint64_t chain_S = 0;
+    {
+        const int64_t opt = options().gauss_seidel_chain;
+        uint64_t want = opt > 1 ? (uint64_t)opt : 0;
+        // (auto = level order: the band schedule is correct and bit-identical but NOT faster as built — 1.6 us per step on the
+        // 4096 x 4096 heat system against 2.3 us per level, and twice as many steps as levels once 64 bands trail each other:
+        // 19.0 against 18.6 ms per sweep, profiles/r10z.  Its step alone takes 0.7 us; the rest is the workgroup's loads: 64 chains
+        // x 27 loads per step, each a 128-byte line of a different region, i.e. ~220 KB per step through ONE CU's 64 B / clk path
+        // from L2.  It wants its operands fetched a line at a time and kept across the steps that share the line; until then it is
+        // an explicit choice, gauss_seidel_chain = S.)
+        if (want > 1 && want < n) {
+            if (a->gs.chain_tried != want) {
+                DevTmp flag;
+                SPRS_TRY_HIP(flag.alloc(4));
+                SPRS_TRY_HIP(hipMemsetAsync(flag.p, 0, 4, stream));
+                hipLaunchKernelGGL((gs_band_check_kernel<IDX, PTR>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const PTR *)a->indptr,
+                                   (const IDX *)a->indices, n, want, flag.as<unsigned int>());
+                SPRS_TRY_HIP(hipGetLastError());
+                unsigned int bad = 0;
+                SPRS_TRY_HIP(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, stream));
+                SPRS_TRY_HIP(hipStreamSynchronize(stream));
+                a->gs.chain_tried = want;
+                a->gs.chain_ok = bad == 0;
+            }
+            if (a->gs.chain_ok) chain_S = want;
+            else if (opt > 1)
+                SPRS_FAIL(SPRS_HIP_INVALID_ARG, "gauss_seidel_chain = %lld: the matrix does not fit a band schedule of this stride (a row of more than %d "
+                          "entries, or a dependency inside a band that the skewed chains would sweep later)", (long long)opt, GB_E);
+        } else if (opt > 1) {
+            SPRS_FAIL(SPRS_HIP_INVALID_ARG, "gauss_seidel_chain = %lld: the stride must be smaller than the number of rows", (long long)opt);
+        }
+    }
     if (max_iter > 0 && no_diag_row != UINT64_MAX)
         SPRS_FAIL(SPRS_HIP_BAD_STRUCTURE, "Gauss-Seidel: row %llu has no stored diagonal entry (the reference's diag.unwrap() panics, heat.rs:127)",
                   (unsigned long long)no_diag_row);
@@ -471,7 +769,13 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
     for (uint64_t it = 0; it < max_iter; ++it) {
         SPRS_TRY_HIP(hipMemsetAsync(nxt, 0xFF, n * sizeof(double), stream));   // every row of the next iterate "pending"
         SPRS_TRY_HIP(hipMemsetAsync(w.words, 0, 64, stream));
-        if (one_xcd)       // 8 x the workgroups: an eighth of them lands on XCD 0 and stays
+        if (chain_S) {     // one workgroup per band, bands drawn in order
+            uint64_t nbands = (n + 64 * chain_S - 1) / (64 * chain_S);
+            if (nbands > (uint64_t)(ncu > 0 ? ncu : 1)) nbands = (uint64_t)(ncu > 0 ? ncu : 1);
+            hipLaunchKernelGGL((gs_band_kernel<IDX, PTR>), dim3((unsigned)nbands), dim3(GB_BLOCK), 0, stream, (const PTR *)a->indptr,
+                               (const IDX *)a->indices, (const double *)a->data, (const double *)cur, (unsigned long long *)nxt, rhs, n, chain_S,
+                               next_chunk, status, DEVTOOLS ? (uint32_t)options().gauss_seidel_debug : 0u);
+        } else if (one_xcd)       // 8 x the workgroups: an eighth of them lands on XCD 0 and stays
             hipLaunchKernelGGL((gs_sweep_kernel<IDX, PTR, true>), dim3((unsigned)(grid * 8)), dim3(GS_BLOCK), 0, stream, (const PTR *)a->indptr,
                                (const IDX *)a->indices, (const double *)a->data, order, (const double *)cur,
                                (unsigned long long *)nxt, rhs, n, next_chunk, status, max_naps);
@@ -488,7 +792,7 @@ int32_t gs_impl(sprs_hip_csmat *a, double *x, const double *rhs, uint64_t n, uin
         const unsigned int st = sweep_words[1];
         // every position of the level order must have been drawn by some wave: in the one-XCD mode the workgroups that do not
         // find themselves on XCD 0 leave at once, and a device that puts none there would return the 0xFF fill as the iterate
-        if ((uint64_t)sweep_words[0] * 64u < n)
+        if ((uint64_t)sweep_words[0] * 64u * (chain_S ? chain_S : 1u) < n)
             SPRS_FAIL(SPRS_HIP_HIP_ERROR, "Gauss-Seidel sweep: only %llu of %llu rows were swept (no workgroup took part: gauss_seidel_xcd on a device without workgroups on XCD 0?)",
                       (unsigned long long)sweep_words[0] * 64ull, (unsigned long long)n);
         if (st & GS_TIMEOUT)

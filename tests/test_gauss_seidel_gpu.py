@@ -215,3 +215,31 @@ def test_plan_is_kept_and_follows_the_handle(hip):
         outs.append(x.to_host())
         assert r.levels == 20
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("rows,sweeps", [(64, 1), (80, 3), (130, 2)])
+def test_band_schedule_bit_for_bit(hip, rows, sweeps):
+    """option gauss_seidel_chain = S (the grid width): chains of S consecutive rows per lane, skewed, hand-offs through LDS inside a
+    workgroup — 64 x 64 is one band, 80 x 80 two bands (dependencies across the band edge polled in memory), 130 x 130 a band whose
+    chains end inside it.  Every iterate bit for bit, like the level-order kernel; a stride the matrix does not fit is refused."""
+    from oracle import oracle
+    if EMU and rows > 80:
+        rows, sweeps = 66, 2
+    shape, ip, ix, dt, rhs = heat_system(rows)
+    x0 = np.random.default_rng(5).standard_normal(rows * rows)
+    x_ref, info = oracle.gauss_seidel(shape, ip, ix, dt, x0, rhs, sweeps, -1.0)
+    hip.set_option("gauss_seidel_chain", rows)
+    try:
+        x, res = gpu_gs(shape, ip, ix, dt, x0, rhs, sweeps, -1.0)
+    finally:
+        hip.set_option("gauss_seidel_chain", 0)
+    assert res.iterations == sweeps and np.array_equal(x, x_ref)
+    x1, _ = gpu_gs(shape, ip, ix, dt, x0, rhs, sweeps, -1.0)           # level order (auto: the grid is too narrow for a band)
+    assert np.array_equal(x1, x_ref)
+    hip.set_option("gauss_seidel_chain", rows - 1)                        # row i - 1 of a chain's first row is swept later: refused
+    try:
+        with pytest.raises(hip.SprsHipError) as e:
+            gpu_gs(shape, ip, ix, dt, x0, rhs, 1, -1.0)
+        assert e.value.status == hip._ffi.INVALID_ARG
+    finally:
+        hip.set_option("gauss_seidel_chain", 0)
