@@ -285,7 +285,13 @@ def case_bicgstab(rng):
     # the reported err is the norm of the true residual of the returned x when convergence was claimed (hard restart), the
     # two solvers reach comparable residuals, and where both converged the solutions agree to the tolerance asked for.
     r_gpu, r_ref = np.linalg.norm(b - m @ x), np.linalg.norm(b - m @ ref)
-    ok = bool(np.isfinite(r_gpu) and r_gpu <= 1e3 * max(r_ref, tol) and res.iteration_count() <= it)
+    bound = 1e3 * max(r_ref, tol)
+    if not res.converged and not info["converged"]:
+        # both stopped by the iteration cap: a history branches on the soft-restart test |rho| / err^2 < 0.1 by rounding alone (seeds 57863
+        # and 60527: profiles/r11b_bicgstab_history.jsonl next to the two dot orders on the CPU, profiles/r11b_bicgstab_dot_order_cpu.txt),
+        # and a restarted run trails the other by orders of magnitude for the rest of it — only progress can be asked of such a run
+        bound = max(bound, 1e-3 * np.linalg.norm(b - m @ x0))
+    ok = bool(np.isfinite(r_gpu) and r_gpu <= bound and res.iteration_count() <= it)
     if not np.isfinite(r_ref) and not np.isfinite(r_gpu):        # a breakdown (0 / 0 in the recurrences) on both sides: the same NaN story
         ok = res.iteration_count() == info["iteration_count"] and bool(res.converged) == bool(info["converged"])
     if res.converged:
