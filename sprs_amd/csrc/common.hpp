@@ -70,7 +70,8 @@ constexpr bool DEVTOOLS = false;
     X(spmv_band_cold_tiles, 0, 0, 64, 0) /* consecutive wave tiles per wave of the cold kernel (0 = default 4) */                 \
     X(spmv_band_overlap, 0, 0, 2, 0)    /* cold pieces + short rows on a second stream beside the hot kernel: 0/1 on, 2 off */     \
     X(spmv_band_split_permute, 0, 0, 2, 0) /* with the overlap: hot labels of x gathered first, the rest scattered on the second stream: 0/1 on, 2 off */ \
-    X(spmm_long_row, -1, -1, INT64_MAX, 0) /* SpMM: -1 default (0: all rows by chunks); L > 0: rows of <= L entries summed in entry order (reference bits, 3x slower) */ \
+    X(spmm_long_row, -1, -1, INT64_MAX, 0) /* SpMM: -1 / 0 default (the entry-stream kernel); L > 0: rows of <= L entries summed in entry order by lane groups, longer ones by 512-entry chunks (reference bits for the short rows, several times slower) */ \
+    X(spmm_stream, 1, 0, 1, 0)          /* SpMM: 1 tiles of 256 consecutive entries per wave (default); 0 one wave per row chunk (the kernel of rounds 1-3; also what a matrix with 2^32 or more columns runs) */ \
     X(spgemm_task_order, 0, 0, 2, 0)    /* large-row tasks: 0/1 costliest first (stable sort by cost class), 2 row order (A/B) */  \
     X(spgemm_xcd_chunk, 0, -1, 0, 0)    /* large-row task list -> XCDs: 0 round-robin, -1 one contiguous run per XCD */            \
     X(spgemm_bucket, 1, 0, 1, 0)        /* column-bucket table of B instead of binary searches (A/B) */                           \
@@ -157,6 +158,9 @@ struct SpmmPlan {
     uint64_t *first_chunk = nullptr;   // device, rows + 1
     uint64_t *chunk_row = nullptr;     // device, nchunks
     uint64_t *multi_rows = nullptr;    // device, rows spanning several chunks
+    uint64_t *tile_row = nullptr;      // device, ntiles + 1: the row that holds entry t * 256 (entry-stream kernel)
+    uint64_t ntiles = 0;
+    bool stream = false;               // built for the entry-stream kernel (no chunk lists then)
     std::unordered_map<void *, std::pair<double *, uint64_t>> partial;   // per stream: buffer, bytes
     void release();
 };

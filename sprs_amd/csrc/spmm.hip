@@ -202,6 +202,246 @@ __global__ void spmm_combine_kernel(const uint64_t *__restrict__ multi_rows, uin
     else *dst = s;
 }
 
+// ---- the entry stream (default) ---------------------------------------------------------------------------------------
+// The chunk kernel above walks ROWS: per row of ~32 entries a wave pays four dependent round trips (chunk -> bounds -> indices
+// -> rhs rows) — 9.7 ms at k = 16 even when the whole rhs sits in L2 (profiles/r11c), the gathers themselves add a quarter.
+// This kernel walks ENTRIES: a wave takes a TILE of 256 consecutive entries of the CSR arrays (coalesced, unconditional loads
+// into LDS), finds the row of every entry from the handful of indptr values that fall into the tile (row starts scattered as
+// marks, then a max-scan — the rows of a tile are known after ONE round trip whatever their lengths), and its G = 64 / KP lane
+// groups each walk a RUN of 256 / G consecutive entries with 16 rhs rows in flight per lane, adding in entry order.  A row
+// that lies inside one run is stored directly (its sum has the reference's own order, prod.rs:203-210); the first and the last
+// row piece of every run go through LDS and are joined in run order by the wave; a row that crosses tiles leaves a `lead` /
+// `trail` partial per tile, added in tile order by a fix-up kernel.  Deterministic, no float atomics.
+constexpr int ST_TILE = 256;                 // entries of a tile (one wave)
+constexpr int ST_Q = ST_TILE / WAVE;
+constexpr uint32_t ST_NONE = 0xffffffffu;
+struct alignas(16) Row4 {
+    uint32_t x, y, z, w;
+};
+struct alignas(16) Val2 {
+    double x, y;
+};
+
+// tile_row[t] = the row that holds entry t * ST_TILE (the last row starting at or before it); tile_row[ntiles] = rows
+template <typename PTR>
+__global__ void tile_rows_kernel(const PTR *__restrict__ indptr, uint64_t rows, uint64_t ntiles, uint64_t *__restrict__ tile_row) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > ntiles) return;
+    if (t == ntiles) {
+        tile_row[t] = rows;
+        return;
+    }
+    const uint64_t target = t * ST_TILE;
+    uint64_t lo = 0, hi = rows;                          // indptr[lo] <= target < indptr[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if ((uint64_t)indptr[mid] <= target) lo = mid;
+        else hi = mid;
+    }
+    tile_row[t] = lo;
+}
+
+template <typename IDX, typename PTR, int KP, bool ACC>
+__global__ __launch_bounds__(MM_BLOCK) void spmm_stream_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
+                                                               const double *__restrict__ data, uint64_t rows, uint64_t nnz,
+                                                               const uint64_t *__restrict__ tile_row, uint64_t ntiles,
+                                                               const double *__restrict__ rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k,
+                                                               double *__restrict__ out, uint64_t ld_out, uint64_t cs_out,
+                                                               double *__restrict__ carry) {
+    constexpr int G = WAVE / KP;                         // lane groups = runs of a tile
+    constexpr int L = ST_TILE / G;                       // entries of a run
+    constexpr int U = L < 16 ? L : 16;                   // rhs rows in flight per lane
+    __shared__ uint32_t ecol_s[MM_WAVES][ST_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t erow_s[MM_WAVES][ST_TILE];
+    __shared__ __attribute__((aligned(16))) double eval_s[MM_WAVES][ST_TILE];
+    __shared__ double seg_s[MM_WAVES][2 * WAVE];         // first / last row piece of every run: [which * 64 + g * KP + j]
+    __shared__ uint32_t segrow_s[MM_WAVES][2 * G];
+    const uint32_t lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    const uint32_t j = lane % KP, g = lane / KP;
+    const uint64_t t = (uint64_t)blockIdx.x * MM_WAVES + w;
+    if (t >= ntiles) return;                             // (whole waves; the kernel has no workgroup barrier)
+    uint32_t *ecol = ecol_s[w], *erow = erow_s[w], *segrow = segrow_s[w];
+    double *eval = eval_s[w], *seg = seg_s[w];
+    const uint64_t e0 = t * ST_TILE;
+    const uint32_t nt = (uint32_t)(nnz - e0 < (uint64_t)ST_TILE ? nnz - e0 : (uint64_t)ST_TILE);
+    // the entries of the tile (past the end of the matrix: the last entry again, never added)
+#pragma unroll
+    for (int q = 0; q < ST_Q; ++q) {
+        const uint32_t pos = (uint32_t)q * WAVE + lane;
+        const uint64_t at = e0 + pos < nnz ? e0 + pos : nnz - 1;
+        ecol[pos] = (uint32_t)indices[at];
+        eval[pos] = data[at];
+        erow[pos] = 0u;
+    }
+    // rows: every non-empty row that starts inside the tile marks its first entry with its distance from r0.  The walk covers
+    // the rows (r0, r1] — tile 0 also the rows before r0, the last tile the rows after the last entry — so every EMPTY row is
+    // met by exactly one tile, which gives it the zeros of the operator form (csmat.rs:2004; the accumulate form leaves it alone)
+    const uint64_t r0 = tile_row[t], r1 = tile_row[t + 1];
+    const uint64_t s0 = (uint64_t)indptr[r0];
+    const uint64_t rhi = r1 < rows ? r1 : rows - 1;
+    wave_sync_lds();
+    for (uint64_t r = (t == 0 ? 0 : r0 + 1) + lane; r <= rhi; r += WAVE) {
+        const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
+        if (e > s) {
+            if (r > r0 && s < e0 + nt) erow[s - e0] = (uint32_t)(r - r0);
+        } else if constexpr (!ACC) {
+            for (uint32_t c = 0; c < k; ++c) out[r * ld_out + (uint64_t)c * cs_out] = 0.0;
+        }
+    }
+    wave_sync_lds();
+    uint32_t run_max = 0;
+#pragma unroll
+    for (int q = 0; q < ST_Q; ++q) {
+        const uint32_t pos = (uint32_t)q * WAVE + lane;
+        uint32_t o = wave_incl_max_u32(erow[pos]);
+        o = o > run_max ? o : run_max;
+        run_max = (uint32_t)__builtin_amdgcn_readlane((int)o, WAVE - 1);
+        erow[pos] = o;
+    }
+    wave_sync_lds();
+    const uint32_t row_last = erow[nt - 1];
+    // the runs
+    const uint32_t jj = j < k ? j : k - 1;               // lanes past the last column load what the last column loads, and store nothing
+    const bool col_ok = j < k;
+    const double *rbase = rhs + (uint64_t)jj * cs_rhs;
+    double *obase = out + r0 * ld_out + (uint64_t)jj * cs_out;
+    const uint32_t rb = g * L;
+    const uint32_t rn = rb < nt ? (nt - rb < (uint32_t)L ? nt - rb : (uint32_t)L) : 0u;
+    uint32_t cur = erow[rb < nt ? rb : 0u], first_row = ST_NONE, last_row = ST_NONE;
+    bool first = true;
+    double acc = 0.0;
+    for (uint32_t b = 0; b < (uint32_t)L; b += U) {
+        if (__ballot(b < rn) == 0ull) break;             // wave-uniform (the last tile only)
+        double x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = rbase[(uint64_t)ecol[rb + b + u] * ld_rhs];
+#pragma unroll
+        for (int u4 = 0; u4 < U; u4 += 4) {              // rows and values of four entries per LDS read
+            const Row4 rw4 = *reinterpret_cast<const Row4 *>(erow + rb + b + u4);
+            const Val2 va = *reinterpret_cast<const Val2 *>(eval + rb + b + u4);
+            const Val2 vb = *reinterpret_cast<const Val2 *>(eval + rb + b + u4 + 2);
+            const uint32_t rw[4] = {rw4.x, rw4.y, rw4.z, rw4.w};
+            const double vv[4] = {va.x, va.y, vb.x, vb.y};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool in = b + (uint32_t)(u4 + e) < rn;
+                if (in && rw[e] != cur) {
+                    if (first) {
+                        seg[lane] = acc;
+                        first_row = cur;
+                        first = false;
+                    } else if (col_ok) {
+                        double *dst = obase + (uint64_t)cur * ld_out;
+                        if constexpr (ACC) *dst = *dst + acc;
+                        else *dst = acc;
+                    }
+                    cur = rw[e];
+                    acc = 0.0;
+                }
+                const double sum = acc + vv[e] * x[u4 + e];
+                acc = in ? sum : acc;
+            }
+        }
+    }
+    if (rn) {
+        if (first) {
+            seg[lane] = acc;
+            first_row = cur;
+        } else {
+            seg[WAVE + lane] = acc;
+            last_row = cur;
+        }
+    }
+    if (j == 0) {
+        segrow[2 * g] = first_row;
+        segrow[2 * g + 1] = last_row;
+    }
+    wave_sync_lds();
+    // the pieces at the run boundaries, joined in run order by the lanes of the first group (lane = column)
+    if (lane < (uint32_t)KP && col_ok) {
+        const bool lead = s0 < e0;                                    // row r0 began in an earlier tile
+        const bool cont = e0 + nt < nnz && r1 == r0 + row_last;       // the last row goes on in the next tile
+        double *cbase = carry + 2 * t * (uint64_t)k;
+        bool have = false, head = true;
+        uint32_t mrow = 0;
+        double msum = 0.0;
+        auto emit = [&](bool last) {
+            if (head && lead) cbase[j] = msum;                        // (a tile inside one long row: its whole sum is a lead)
+            else if (last && cont) cbase[k + j] = msum;
+            else {
+                double *dst = obase + (uint64_t)mrow * ld_out;
+                if constexpr (ACC) *dst = *dst + msum;
+                else *dst = msum;
+            }
+            head = false;
+        };
+        for (int s = 0; s < 2 * G; ++s) {
+            const uint32_t row = segrow[s];
+            if (row == ST_NONE) continue;
+            const double val = seg[(s & 1) * WAVE + (s >> 1) * KP + (int)j];
+            if (have && row == mrow) {
+                msum = msum + val;
+            } else {
+                if (have) emit(false);
+                mrow = row;
+                msum = val;
+                have = true;
+            }
+        }
+        if (have) emit(true);
+    }
+}
+
+// rows that cross tiles: trail of the tile the row starts in, then the leads of the tiles it goes on in, in tile order.
+// One lane group per tile boundary (most rows end in the next tile); a row that goes on for more than FIX_SPAN tiles is
+// summed by the whole wave afterwards, one such row at a time (its leads dealt to the groups, joined by xor-shuffles).
+constexpr uint64_t FIX_SPAN = 8;
+template <typename PTR, int KP, bool ACC>
+__global__ __launch_bounds__(MM_BLOCK) void spmm_stream_fixup_kernel(const PTR *__restrict__ indptr, const uint64_t *__restrict__ tile_row,
+                                                                     uint64_t ntiles, const double *__restrict__ carry, uint32_t k,
+                                                                     double *__restrict__ out, uint64_t ld_out, uint64_t cs_out) {
+    constexpr int G = WAVE / KP;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t j = lane % KP, g = lane / KP;
+    const uint32_t jj = j < k ? j : k - 1;
+    const uint64_t t = ((uint64_t)blockIdx.x * MM_BLOCK + threadIdx.x) / KP;
+    uint64_t r = 0, tb = 0;
+    bool work = false;
+    if (t + 1 < ntiles) {                                // (the last tile has no trail)
+        const uint64_t e0 = t * ST_TILE, e1 = e0 + ST_TILE;
+        r = tile_row[t + 1];                             // the row that holds entry e1
+        const uint64_t s = (uint64_t)indptr[r];
+        work = s >= e0 && s < e1;                        // it starts in this tile
+        if (work) tb = ((uint64_t)indptr[r + 1] - 1) / ST_TILE;       // its last tile
+    }
+    const bool is_long = work && tb - t > FIX_SPAN;
+    if (work && !is_long) {
+        double sum = carry[(2 * t + 1) * (uint64_t)k + jj];
+        for (uint64_t u = t + 1; u <= tb; ++u) sum = sum + carry[2 * u * (uint64_t)k + jj];
+        if (j < k) {
+            double *dst = out + r * ld_out + (uint64_t)j * cs_out;
+            if constexpr (ACC) *dst = *dst + sum;
+            else *dst = sum;
+        }
+    }
+    uint64_t todo = __ballot(is_long && j == 0);
+    while (todo) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint64_t lt = __shfl(t, src, WAVE), ltb = __shfl(tb, src, WAVE), lr = __shfl(r, src, WAVE);
+        double sum = 0.0;
+        for (uint64_t u = lt + 1 + g; u <= ltb; u += G) sum = sum + carry[2 * u * (uint64_t)k + jj];
+#pragma unroll
+        for (int o = KP; o < WAVE; o <<= 1) sum += __shfl_xor(sum, o, WAVE);
+        if (g == 0 && j < k) {
+            sum = carry[(2 * lt + 1) * (uint64_t)k + j] + sum;
+            double *dst = out + lr * ld_out + (uint64_t)j * cs_out;
+            if constexpr (ACC) *dst = *dst + sum;
+            else *dst = sum;
+        }
+    }
+}
+
 struct Tmp {
     void *p = nullptr;
     ~Tmp() {
@@ -212,11 +452,22 @@ struct Tmp {
 };
 
 template <typename PTR>
-int32_t build_spmm_plan(sprs_hip_csmat *a, hipStream_t stream) {
+int32_t build_spmm_plan(sprs_hip_csmat *a, bool stream_mode, hipStream_t stream) {
     SpmmPlan &pl = a->mm;
     pl.release();
     pl.long_row = options().spmm_long_row >= 0 ? (uint64_t)options().spmm_long_row : LONG_ROW;
+    pl.stream = stream_mode;
     const uint64_t rows = a->rows;
+    if (stream_mode) {
+        pl.ntiles = (a->nnz + ST_TILE - 1) / ST_TILE;
+        SPRS_TRY_HIP(hipMalloc((void **)&pl.tile_row, (pl.ntiles + 1) * 8));
+        hipLaunchKernelGGL(tile_rows_kernel<PTR>, dim3((unsigned)((pl.ntiles + 256) / 256)), dim3(256), 0, stream, (const PTR *)a->indptr,
+                           rows, pl.ntiles, pl.tile_row);
+        SPRS_TRY_HIP(hipGetLastError());
+        SPRS_TRY_HIP(hipStreamSynchronize(stream));
+        pl.built = true;
+        return SPRS_HIP_OK;
+    }
     Tmp nch, mflag, mpos;
     SPRS_TRY_HIP(nch.alloc(rows * 8));
     SPRS_TRY_HIP(mflag.alloc(rows * 8));
@@ -239,24 +490,51 @@ int32_t build_spmm_plan(sprs_hip_csmat *a, hipStream_t stream) {
     return SPRS_HIP_OK;
 }
 
+// rows of at most long_row entries (the empty ones among them): the lane-group kernel
+template <typename IDX, typename PTR, int KP>
+int32_t launch_short_rows(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k, double *out, uint64_t ld_out,
+                          uint64_t cs_out, bool acc, uint64_t long_row, hipStream_t stream) {
+    // groups of KP lanes, group-stride; enough workgroups to fill the chip eight deep
+    constexpr uint64_t groups_per_block = MM_BLOCK / KP;
+    uint64_t blocks = (a->rows + groups_per_block - 1) / groups_per_block;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const dim3 grid((unsigned)blocks), block(MM_BLOCK);
+    if (acc)
+        hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, true>), grid, block, 0, stream, (const PTR *)a->indptr,
+                           (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, long_row);
+    else
+        hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, false>), grid, block, 0, stream, (const PTR *)a->indptr,
+                           (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, long_row);
+    SPRS_TRY_HIP(hipGetLastError());
+    return SPRS_HIP_OK;
+}
+
+template <typename IDX, typename PTR, int KP>
+int32_t launch_stream(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k, double *out, uint64_t ld_out,
+                      uint64_t cs_out, bool acc, double *carry, hipStream_t stream) {
+    const SpmmPlan &pl = a->mm;
+    const dim3 grid((unsigned)((pl.ntiles + MM_WAVES - 1) / MM_WAVES)), block(MM_BLOCK);
+    const dim3 fgrid((unsigned)((pl.ntiles * KP + MM_BLOCK - 1) / MM_BLOCK));
+    if (acc) {
+        hipLaunchKernelGGL((spmm_stream_kernel<IDX, PTR, KP, true>), grid, block, 0, stream, (const PTR *)a->indptr, (const IDX *)a->indices,
+                           a->data, a->rows, a->nnz, pl.tile_row, pl.ntiles, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, carry);
+        hipLaunchKernelGGL((spmm_stream_fixup_kernel<PTR, KP, true>), fgrid, block, 0, stream, (const PTR *)a->indptr, pl.tile_row, pl.ntiles,
+                           carry, k, out, ld_out, cs_out);
+    } else {
+        hipLaunchKernelGGL((spmm_stream_kernel<IDX, PTR, KP, false>), grid, block, 0, stream, (const PTR *)a->indptr, (const IDX *)a->indices,
+                           a->data, a->rows, a->nnz, pl.tile_row, pl.ntiles, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, carry);
+        hipLaunchKernelGGL((spmm_stream_fixup_kernel<PTR, KP, false>), fgrid, block, 0, stream, (const PTR *)a->indptr, pl.tile_row, pl.ntiles,
+                           carry, k, out, ld_out, cs_out);
+    }
+    SPRS_TRY_HIP(hipGetLastError());
+    return SPRS_HIP_OK;
+}
+
 template <typename IDX, typename PTR, int KP>
 int32_t launch_block(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k, double *out, uint64_t ld_out,
                      uint64_t cs_out, bool acc, double *partial, hipStream_t stream) {
     const SpmmPlan &pl = a->mm;
-    {
-        // short rows: groups of KP lanes, group-stride; enough workgroups to fill the chip eight deep
-        constexpr uint64_t groups_per_block = MM_BLOCK / KP;
-        uint64_t blocks = (a->rows + groups_per_block - 1) / groups_per_block;
-        if (blocks > 256 * 8) blocks = 256 * 8;
-        const dim3 grid((unsigned)blocks), block(MM_BLOCK);
-        if (acc)
-            hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, true>), grid, block, 0, stream, (const PTR *)a->indptr,
-                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, pl.long_row);
-        else
-            hipLaunchKernelGGL((spmm_rows_kernel<IDX, PTR, KP, false>), grid, block, 0, stream, (const PTR *)a->indptr,
-                               (const IDX *)a->indices, a->data, a->rows, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, pl.long_row);
-        SPRS_TRY_HIP(hipGetLastError());
-    }
+    SPRS_TRY((launch_short_rows<IDX, PTR, KP>(a, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, acc, pl.long_row, stream)));
     if (!pl.nchunks) return SPRS_HIP_OK;
     uint64_t blocks = (pl.nchunks + MM_WAVES - 1) / MM_WAVES;
     if (blocks > 256 * 64) blocks = 256 * 64;
@@ -289,12 +567,14 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
                   uint64_t cs_out, bool acc, hipStream_t stream) {
     double *partial = nullptr;
     std::lock_guard<std::recursive_mutex> lock(a->mu);   // held until the kernels that read the plan are launched
+    const uint64_t want_long = options().spmm_long_row >= 0 ? (uint64_t)options().spmm_long_row : LONG_ROW;
+    // the entry stream keeps 32-bit column ids in LDS; the lane-group mode (reference bits for short rows) has its own kernels
+    const bool stream_mode = options().spmm_stream != 0 && want_long == 0 && a->cols <= 0xffffffffull && a->nnz != 0;
     {
-        const uint64_t want_long = options().spmm_long_row >= 0 ? (uint64_t)options().spmm_long_row : LONG_ROW;
-        if (!a->mm.built || a->mm.long_row != want_long) SPRS_TRY(build_spmm_plan<PTR>(a, stream));
+        if (!a->mm.built || a->mm.long_row != want_long || a->mm.stream != stream_mode) SPRS_TRY(build_spmm_plan<PTR>(a, stream_mode, stream));
         SpmmPlan &pl = a->mm;
         const uint64_t kb = k < 64 ? k : 64;
-        const uint64_t need = (pl.n_multi ? pl.nchunks : 0) * kb * sizeof(double);
+        const uint64_t need = (stream_mode ? 2 * pl.ntiles : pl.n_multi ? pl.nchunks : 0) * kb * sizeof(double);
         auto &slot = pl.partial[(void *)stream];
         if (slot.second < need) {
             if (slot.first) (void)hipFree(slot.first);
@@ -320,7 +600,12 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
         const double *r = rhs + j0 * cs_rhs;
         double *o = out + j0 * cs_out;
         int32_t st;
-        if (kb <= 8) st = launch_block<IDX, PTR, 8>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+        if (stream_mode) {
+            if (kb <= 8) st = launch_stream<IDX, PTR, 8>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+            else if (kb <= 16) st = launch_stream<IDX, PTR, 16>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+            else if (kb <= 32) st = launch_stream<IDX, PTR, 32>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+            else st = launch_stream<IDX, PTR, 64>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+        } else if (kb <= 8) st = launch_block<IDX, PTR, 8>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
         else if (kb <= 16) st = launch_block<IDX, PTR, 16>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
         else if (kb <= 32) st = launch_block<IDX, PTR, 32>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
         else st = launch_block<IDX, PTR, 64>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
@@ -338,7 +623,9 @@ void SpmmPlan::release() {
     drop(first_chunk);
     drop(chunk_row);
     drop(multi_rows);
-    first_chunk = chunk_row = multi_rows = nullptr;
+    drop(tile_row);
+    first_chunk = chunk_row = multi_rows = tile_row = nullptr;
+    ntiles = 0;
     for (auto &kv : partial) drop(kv.second.first);
     partial.clear();
     nchunks = n_multi = 0;

@@ -93,13 +93,16 @@ def test_golden_mul_csc_dense(hip, golden):
         assert rel_err(got, ref) <= 1e-10
 
 
-@pytest.fixture(params=[0, 2048], ids=["chunks", "entry-order"])
+@pytest.fixture(params=[(0, 1), (0, 0), (2048, 1)], ids=["stream", "chunks", "entry-order"])
 def long_row(request, hip):
-    """the two summation modes of spmm.hip: every row by 512-entry chunks (default), or rows of <= L entries in the
-    reference's own entry order (option spmm_long_row = L: bit-identical to prod.rs:203-210)"""
-    hip.set_option("spmm_long_row", request.param)
-    yield request.param
+    """the three summation modes of spmm.hip: tiles of 256 consecutive entries per wave (default), every row by 512-entry
+    chunks (option spmm_stream = 0: the kernel of rounds 1-3), or rows of <= L entries in the reference's own entry order
+    (option spmm_long_row = L: bit-identical to prod.rs:203-210)"""
+    hip.set_option("spmm_long_row", request.param[0])
+    hip.set_option("spmm_stream", request.param[1])
+    yield request.param[0]
     hip.set_option("spmm_long_row", -1)
+    hip.set_option("spmm_stream", 1)
 
 
 @pytest.mark.parametrize("k", [1, 3, 8, 16, 33, 64, 100])
@@ -135,7 +138,8 @@ def test_rmat_vs_oracle(hip, k, long_row):
 
 @pytest.mark.parametrize("k", [2, 16, 40])
 def test_long_rows_take_the_chunk_kernels(hip, k, long_row):
-    """rows above option spmm_long_row are cut into 512-entry chunks: same values up to the summation order"""
+    """rows above option spmm_long_row are cut into 512-entry chunks (or, in the stream mode, cross several 256-entry tiles):
+    same values up to the summation order"""
     from sprs_amd import prod
     from sprs_amd.device import DeviceCsMat
     rng = np.random.default_rng(100 + k)
@@ -160,6 +164,48 @@ def test_long_rows_take_the_chunk_kernels(hip, k, long_row):
     ref2 = oracle_spmm((n, m), ip, ix, dt, rhs, out0)
     assert np.abs(res.to_host() - ref2).max() <= 1e-12 * scale
     assert np.array_equal(res.to_host()[lens == 0], out0[lens == 0])
+
+
+@pytest.mark.parametrize("k", [1, 5, 8, 16, 24, 64, 70])
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS[:2])
+def test_stream_tiles_and_runs(hip, k, idx, ptr):
+    """the entry-stream kernel at its seams: rows that start exactly at a tile (256 entries) or run (256 / G) boundary, rows that
+    cover several whole tiles, a row that begins in one tile's last entry, runs of empty rows across tile boundaries and at both
+    ends, a last tile with a handful of entries; the accumulate form; strided (column-major) operands"""
+    from sprs_amd import prod
+    from sprs_amd.device import DeviceCsMat
+    rng = np.random.default_rng(7 * k + np.dtype(idx).itemsize)
+    lens = [0, 0, 256, 0, 32, 32, 64, 127, 1, 0, 0, 0, 255, 1, 256 * 3, 31, 1, 1000, 24, 0, 8, 8, 8, 8, 200, 56, 255, 257, 0, 0, 3]
+    lens += [int(v) for v in rng.integers(0, 70, 400)] + [0] * 70 + [513, 0, 0]
+    lens = np.array(lens)
+    n, m = lens.size, 1500
+    ip = np.zeros(n + 1, ptr)
+    ip[1:] = np.cumsum(lens)
+    ix = np.concatenate([np.sort(rng.choice(m, int(l), replace=False)) for l in lens]).astype(idx)
+    dt = rng.standard_normal(ix.size)
+    rhs = rng.standard_normal((m, k))
+    a = DeviceCsMat.from_host((n, m), ip, ix, dt)
+    ref = oracle_spmm((n, m), ip, ix, dt, rhs)
+    bound = oracle_spmm((n, m), ip, ix, np.abs(dt), np.abs(rhs))
+    for col_major in (False, True):
+        got = (a * prod.DeviceMat.from_host(rhs, col_major=col_major)).to_host()
+        assert np.all(np.abs(got - ref) <= 64 * np.finfo(float).eps * bound)
+        assert np.all(got[lens == 0] == 0.0)
+        assert np.array_equal(got[lens == 1], ref[lens == 1])
+    out0 = rng.standard_normal((n, k))
+    ref2 = oracle_spmm((n, m), ip, ix, dt, rhs, out0)
+    for col_major in (False, True):
+        res = prod.DeviceMat.from_host(out0, col_major=col_major)
+        kern = prod.csr_mulacc_dense_colmaj if col_major else prod.csr_mulacc_dense_rowmaj
+        kern(a, prod.DeviceMat.from_host(rhs), res)
+        assert np.all(np.abs(res.to_host() - ref2) <= 64 * np.finfo(float).eps * (np.abs(out0) + bound))
+        assert np.array_equal(res.to_host()[lens == 0], out0[lens == 0])
+    hip.set_option("spmm_stream", 0)                              # the chunk kernels agree to the summation order
+    try:
+        other = (a * prod.DeviceMat.from_host(rhs)).to_host()
+    finally:
+        hip.set_option("spmm_stream", 1)
+    assert np.all(np.abs(other - ref) <= 64 * np.finfo(float).eps * bound)
 
 
 def test_ragged_and_contract(hip, golden):
