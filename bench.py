@@ -659,6 +659,47 @@ def main():
         except Exception as e:   # the headline line must not depend on the secondary measurement
             out["spmv_u32"] = {"error": repr(e)[:200]}
 
+    # ---- SpMM on the headline matrix (prod::csr_mulacc_dense_rowmaj, k = 8 and 16 rhs columns) -----------------------
+    if rank == 0 and world == 1 and wl == "rmat10m" and args.idx_bytes == 8 and not args.no_secondary and handles:
+        try:
+            import ctypes as C
+            a8 = handles[id(sh.block)]
+            out["spmm"] = {"workload": name + ", rhs and result dense row-major (&CsMat * &Array2 with >= 8 columns)", "k": {}}
+            for kk in (8, 16):
+                rhs = gen.dense_vector(n * kk, seed=5, device=dev)
+                res = torch.empty(n * kk, dtype=torch.float64, device=dev)
+                call = lambda: _ffi.check(_ffi.lib.sprs_hip_spmm_rowmaj_f64(a8._h, C.c_void_p(rhs.data_ptr()), n, kk, kk, C.c_void_p(res.data_ptr()),
+                                                                            n, kk, 0, C.c_void_p(stream.cuda_stream)))
+                for _ in range(2):
+                    call()
+                torch.cuda.synchronize()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for p_, q_ in evs:
+                    p_.record(stream)
+                    call()
+                    q_.record(stream)
+                torch.cuda.synchronize()
+                msk = float(np.mean([p_.elapsed_time(q_) for p_, q_ in evs]))
+                # algorithmic bytes: the CSR arrays once, the rhs once, the result once (scripts/spmm_bench.py)
+                algk = nnz_total * 16 + (n + 1) * 8 + 2 * n * kk * 8
+                # parity of column 0 against the SpMV (itself checked against the oracle above)
+                x0 = rhs.view(n, kk)[:, 0].contiguous()
+                y0 = torch.empty(n, dtype=torch.float64, device=dev)
+                prod.csmat_mul_vec(a8, DeviceVec.borrow(x0), out=DeviceVec.borrow(y0), stream=stream)
+                torch.cuda.synchronize()
+                err = float(((res.view(n, kk)[:, 0] - y0).abs() / y0.abs().clamp_min(1e-300)).max())
+                out["spmm"]["k"][str(kk)] = {"kernel_ms_avg": round(msk, 4), "gflops": round(2.0 * nnz_total * kk / (msk * 1e-3) / 1e9, 1),
+                                             "algorithmic_bytes_per_launch": algk, "achieved_GBs": round(algk / (msk * 1e-3) / 1e9, 1),
+                                             "frac": round(algk / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "rhs_rows_gathered_per_s": round(nnz_total / (msk * 1e-3) / 1e9, 1),
+                                             "col0_vs_spmv_max_rel": err, "tolerance": 1e-10, "ok": bool(err <= 1e-10)}
+                del rhs, res
+            out["spmm"]["note"] = ("bound: one 128-byte fabric request per stored entry (the rhs row of its column); random 128-byte gathers top out at "
+                                   "57.5 G/s on this part (scripts/probes/hbm_patterns.hip, profiles/r11g_hbm_patterns.jsonl)")
+            torch.cuda.empty_cache()
+        except Exception as e:   # the headline line must not depend on the secondary measurement
+            out["spmm"] = {"error": repr(e)[:200]}
+
     # ---- BASELINE config 5 beside the headline (rank 0, N = 1, default workload): a short SpGEMM object -----------
     if rank == 0 and world == 1 and wl == "rmat10m" and not args.no_secondary and not args.no_cpu_baseline:
         try:

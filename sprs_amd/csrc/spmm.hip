@@ -6,17 +6,20 @@
 // becomes a whole ROW of the rhs — k contiguous doubles — so one L2 line access now carries
 // k/16 .. 1 full line of useful data instead of 8 bytes of it.
 //
-// Decomposition (plan cached in the handle):
-//  * DEFAULT: every row is cut into CHUNKS of 512 entries, one wave per chunk (lane j of group g takes entries g, g + G,
-//    ... of the chunk, groups of KP lanes — KP = k rounded up to a power of two — combined with xor-shuffles), partials of
-//    multi-chunk rows added in chunk order by a second kernel: deterministic, equal to the reference up to the summation
-//    order (tests: 1e-12 relative).  All 64 lanes stream entries and every lane has its gathers in flight: 12.1 ms at
-//    k = 16 on R-MAT 10M (3.4 TB/s of rhs-row gathers — the bound: 41 GB of 128-byte rows from a 1.28 GB operand).
+// Three decompositions (plan cached in the handle):
+//  * DEFAULT, the entry stream (spmm_stream_kernel below): a wave takes a tile of 256 consecutive entries, finds their rows
+//    from the indptr values that fall into the tile, and its lane groups walk runs of consecutive entries with 16 rhs rows
+//    in flight per lane.  5.8 ms at k = 16 on R-MAT 10M: 58 G rhs rows/s, the rate at which this part serves random
+//    128-byte lines (scripts/probes/hbm_patterns.hip).
+//  * option spmm_stream = 0 (rounds 1-3; also matrices with 2^32 or more columns): every row is cut into CHUNKS of 512
+//    entries, one wave per chunk (lane j of group g takes entries g, g + G, ... of the chunk, groups of KP lanes — KP = k
+//    rounded up to a power of two — combined with xor-shuffles), partials of multi-chunk rows added in chunk order by a
+//    second kernel: deterministic, equal to the reference up to the summation order.  12.1 ms at k = 16: four dependent
+//    round trips per ~32-entry row (9.7 ms even with the whole rhs in L2, profiles/r11c).
 //  * option spmm_long_row = L > 0: rows of at most L entries instead belong to a GROUP of KP lanes that walks its rows
 //    as a little state machine (32 entries and their rhs rows in flight per turn) and adds the products IN ENTRY ORDER
 //    into one accumulator per column — the reference's own order, bit for bit, the accumulate form included.  Measured
-//    3.4x slower (41 ms at k = 16, profiles/r03f: the serial chains and 64-bit shuffles leave the gathers idle), hence
-//    opt-in for callers that need the reference's bits.
+//    3.4x slower than the chunks (41 ms at k = 16, profiles/r03f), hence opt-in for callers that need the reference's bits.
 // Unfused multiply-add (-ffp-contract=off) like MulAcc (mul_acc.rs:28-30).
 #include "common.hpp"
 #include "scan.hpp"
@@ -269,8 +272,8 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_stream_kernel(const PTR *__rest
     for (int q = 0; q < ST_Q; ++q) {
         const uint32_t pos = (uint32_t)q * WAVE + lane;
         const uint64_t at = e0 + pos < nnz ? e0 + pos : nnz - 1;
-        ecol[pos] = (uint32_t)indices[at];
-        eval[pos] = data[at];
+        ecol[pos] = (uint32_t)__builtin_nontemporal_load(indices + at);      // the entries are used once: the L2s are for the rhs rows
+        eval[pos] = __builtin_nontemporal_load(data + at);
         erow[pos] = 0u;
     }
     // rows: every non-empty row that starts inside the tile marks its first entry with its distance from r0.  The walk covers
@@ -332,8 +335,8 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_stream_kernel(const PTR *__rest
                         first = false;
                     } else if (col_ok) {
                         double *dst = obase + (uint64_t)cur * ld_out;
-                        if constexpr (ACC) *dst = *dst + acc;
-                        else *dst = acc;
+                        if constexpr (ACC) __builtin_nontemporal_store(*dst + acc, dst);
+                        else __builtin_nontemporal_store(acc, dst);
                     }
                     cur = rw[e];
                     acc = 0.0;
