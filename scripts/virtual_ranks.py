@@ -42,7 +42,7 @@ def main():
     out = {"n": n, "nnz": nnz, "row_weight": RW, "model": "per-block kernel time measured on ONE MI355X; exchange modelled"}
     for G in (1, 2, 4, 8):
         cuts = gen.balanced_row_blocks(indptr, G, row_weight=RW)
-        times, rows = [], []
+        times, rows, subs = [], [], []
         for g in range(G):
             r0, r1 = cuts[g], cuts[g + 1]
             lo, hi = int(indptr[r0]), int(indptr[r1])
@@ -52,6 +52,19 @@ def main():
             y = torch.empty(r1 - r0, dtype=torch.float64, device=dev)
             times.append(time_spmv(a, x, y))
             rows.append(r1 - r0)
+            # the same block as TWO sub-blocks of equal cost (nnz + 8 per row: the cut of dist.hip, nsub = 2), each with its own plan
+            if G > 1:
+                cost = ip.double() + 8.0 * torch.arange(ip.numel(), device=dev, dtype=torch.float64)
+                c = int(torch.searchsorted(cost, cost[-1] / 2).item())
+                c = min(max(c, 1), (r1 - r0) - 1)
+                ts = []
+                for (s0, s1) in ((0, c), (c, r1 - r0)):
+                    ip_s = (ip[s0:s1 + 1] - ip[s0]).contiguous()
+                    l0, l1 = int(ip[s0]), int(ip[s1])
+                    a_s = DeviceCsMat.wrap_torch((s1 - s0, n), ip_s, ix[l0:l1].clone(), dt[l0:l1].clone())
+                    ts.append(time_spmv(a_s, x, y[s0:s1]))
+                    del a_s
+                subs.append(ts)
             del a, ip, ix, dt, y
         biggest = max(rows) * 8
         # direct exchange: the rank with the biggest y block pushes it to G-1 peers over G-1 links
@@ -61,6 +74,12 @@ def main():
                            "rows_per_block": rows, "modelled_allgather_ms": round(gather_s * 1e3, 4),
                            "modelled_step_ms": round(step * 1e3, 4),
                            "modelled_gflops": round(2 * nnz / step / 1e9, 1)}
+        if subs:
+            # nsub = 2: sub-block 0, then its exchange beside sub-block 1, then the exchange of sub-block 1 (half the bytes each)
+            step2 = max(t[0] + max(t[1], gather_s / 2) + gather_s / 2 for t in subs)
+            out["G=%d" % G].update({"nsub2_compute_ms_per_block": [[round(v * 1e3, 4) for v in t] for t in subs],
+                                    "nsub2_modelled_step_ms": round(step2 * 1e3, 4),
+                                    "nsub2_modelled_gflops": round(2 * nnz / step2 / 1e9, 1)})
     print(json.dumps(out))
 
 

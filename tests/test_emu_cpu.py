@@ -51,6 +51,16 @@ def test_gauss_seidel_sweep_in_the_emulator(emu_lib, order):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+def test_spmm_stream_kernel_in_the_emulator(emu_lib):
+    """the entry-stream SpMM kernel (tiles of 256 entries, rows by marks + max-scan, runs per lane group, fix-up of the rows that
+    cross tiles) at its seams, and the reference's golden dense products, on the CPU"""
+    env = dict(os.environ, SPRS_HIP_LIBRARY=emu_lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_spmm_gpu.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "stream_tiles or golden or ragged", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def test_differential_fuzzer_in_the_emulator(emu_lib):
     """scripts/fuzz_parity.py (nine kinds of seeded random cases against the oracle; on the GPU: profiles/r08g, r09c) for
     twenty seconds through the emulated kernels: the script itself stays runnable and the kernels' logic agrees on whatever
