@@ -127,17 +127,23 @@ def case_spmm(rng):
     a = DeviceCsMat.from_host(shape, ip, ix, dt)
     import ctypes as C
     from sprs_amd import _ffi
-    d_rhs, d_out = DeviceVec.from_host(rhs.reshape(-1)), DeviceVec.zeros(rows * k)
-    _ffi.check(_ffi.lib.sprs_hip_spmm_rowmaj_f64(a._h, C.c_void_p(d_rhs.ptr), cols, k, k, C.c_void_p(d_out.ptr), rows, k, 0, None))
+    # the three summation modes: entry stream (default), chunks, lane groups in entry order for rows of <= L entries; the accumulate form
+    mode = int(rng.integers(0, 4))
+    opts = {0: {}, 1: {}, 2: dict(spmm_stream=0), 3: dict(spmm_long_row=int(rng.choice([1, 5, 40, 600])))}[mode]
+    setopt(**opts)
+    acc = bool(rng.integers(0, 2))
+    out0 = rng.standard_normal((rows, k)) if acc else np.zeros((rows, k))
+    d_rhs, d_out = DeviceVec.from_host(rhs.reshape(-1)), DeviceVec.from_host(out0.reshape(-1).copy())
+    _ffi.check(_ffi.lib.sprs_hip_spmm_rowmaj_f64(a._h, C.c_void_p(d_rhs.ptr), cols, k, k, C.c_void_p(d_out.ptr), rows, k, int(acc), None))
     got = d_out.to_host().reshape(rows, k)
     import scipy.sparse as sp
     absm = sp.csr_matrix((np.abs(dt), ix.astype(np.int64), ip.astype(np.int64)), shape=shape)
     ok = True
     for j in range(k):
-        ref = oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, np.ascontiguousarray(rhs[:, j]), np.zeros(rows))
-        mag = absm @ np.abs(rhs[:, j])
+        ref = oracle.mul_acc_mat_vec_csr(shape, ip, ix, dt, np.ascontiguousarray(rhs[:, j]), np.ascontiguousarray(out0[:, j]).copy())
+        mag = absm @ np.abs(rhs[:, j]) + np.abs(out0[:, j])
         ok = ok and not np.any(np.abs(got[:, j] - ref) > 1e-10 * np.abs(ref) + 64 * np.finfo(float).eps * mag)
-    return ok, dict(kind="spmm", rows=rows, cols=cols, k=k, idx=str(np.dtype(idx)), ptr=str(np.dtype(ptr)))
+    return ok, dict(kind="spmm", rows=rows, cols=cols, k=k, idx=str(np.dtype(idx)), ptr=str(np.dtype(ptr)), opts=opts, accumulate=acc)
 
 
 def case_gauss_seidel(rng):
