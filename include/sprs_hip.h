@@ -392,7 +392,7 @@ int32_t sprs_hip_triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const 
  *                          level differences, not reproducible run to run; since round 4 no faster: the order costs nothing
  *                          once a wave instruction's products go out as ONE ds_add_f64, option spgemm_lane_order);
  * name = "gauss_seidel_blocks": workgroups of the Gauss-Seidel sweep kernel (0 = default: one per CU), "gauss_seidel_naps";
- * name = "spgemm_*", "spmm_long_row", "pool", "pool_max_bytes": INTEGRATION.md, "Options".
+ * name = "spgemm_*", "spmm_long_row", "spmm_stream", "pool", "pool_max_bytes": INTEGRATION.md, "Options".
  * The whole table (name, default, range) is SPRS_HIP_OPTIONS in sprs_amd/csrc/common.hpp.  Developer switches — timing
  * experiments with WRONG results (spgemm_debug, spmv_xmask, spmv_band_debug) and the profiling printout spgemm_prof — exist
  * only in libraries built with -DSPRS_HIP_DEVTOOLS; this one rejects them.  get_option("devtools") tells which build it is.
