@@ -695,7 +695,8 @@ def main():
                                              "col0_vs_spmv_max_rel": err, "tolerance": 1e-10, "ok": bool(err <= 1e-10)}
                 del rhs, res
             out["spmm"]["note"] = ("bound: one 128-byte fabric request per stored entry (the rhs row of its column); random 128-byte gathers top out at "
-                                   "57.5 G/s on this part (scripts/probes/hbm_patterns.hip, profiles/r11g_hbm_patterns.jsonl)")
+                                   "57.5 G/s on this part (scripts/probes/hbm_patterns.hip, profiles/r11g_hbm_patterns.jsonl); the rhs is gathered from a "
+                                   "re-laid-out copy (option spmm_relayout: its cost, 2 x cols x k x 8 bytes, is inside kernel_ms_avg)")
             torch.cuda.empty_cache()
         except Exception as e:   # the headline line must not depend on the secondary measurement
             out["spmm"] = {"error": repr(e)[:200]}

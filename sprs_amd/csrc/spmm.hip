@@ -244,13 +244,35 @@ __global__ void tile_rows_kernel(const PTR *__restrict__ indptr, uint64_t rows, 
     tile_row[t] = lo;
 }
 
-template <typename IDX, typename PTR, int KP, bool ACC>
+// Where row c of the rhs sits in the re-laid-out copy (option spmm_relayout): the block of 4096 rows stays, the row's place
+// inside the block is scattered by an odd multiplier (a bijection of 0 .. 4095), rotated from block to block.  The hub
+// columns of a power-law matrix sit at 0, 2^k, 2^j + 2^k ...: their rows of the rhs, 128 bytes apart times such numbers,
+// share a few L2 / fabric channels — the same SpMM call took 5.7 or 7.9 ms depending on where the driver had put the rhs,
+// and 5.7 always once the columns were permuted at random (profiles/r11y).
+constexpr uint32_t RL_BITS = 12, RL_MASK = (1u << RL_BITS) - 1u;
+__device__ __forceinline__ uint32_t relaid_row(uint32_t c) {
+    const uint32_t hi = c >> RL_BITS;
+    return (hi << RL_BITS) | ((c * 0x9E5u + hi * 0x6A7u) & RL_MASK);
+}
+
+// the copy: row c of the rhs (any strides) -> row relaid_row(c) of a row-major array with a pitch of KP doubles (rows never
+// straddle a 128-byte line, whatever k is)
+template <int KP>
+__global__ __launch_bounds__(MM_BLOCK) void spmm_relayout_kernel(const double *__restrict__ rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint64_t rows_rhs,
+                                                                 uint32_t k, double *__restrict__ dst) {
+    const uint32_t j = threadIdx.x % KP;
+    const uint64_t c = ((uint64_t)blockIdx.x * MM_BLOCK + threadIdx.x) / KP;
+    if (c >= rows_rhs || j >= k) return;
+    __builtin_nontemporal_store(rhs[c * ld_rhs + (uint64_t)j * cs_rhs], dst + (uint64_t)relaid_row((uint32_t)c) * KP + j);
+}
+
+template <typename IDX, typename PTR, int KP, bool ACC, bool RELAID>
 __global__ __launch_bounds__(MM_BLOCK) void spmm_stream_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
                                                                const double *__restrict__ data, uint64_t rows, uint64_t nnz,
                                                                const uint64_t *__restrict__ tile_row, uint64_t ntiles,
                                                                const double *__restrict__ rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k,
                                                                double *__restrict__ out, uint64_t ld_out, uint64_t cs_out,
-                                                               double *__restrict__ carry) {
+                                                               double *__restrict__ carry, uint32_t dbg) {
     constexpr int G = WAVE / KP;                         // lane groups = runs of a tile
     constexpr int L = ST_TILE / G;                       // entries of a run
     constexpr int U = L < 16 ? L : 16;                   // rhs rows in flight per lane
@@ -272,8 +294,15 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_stream_kernel(const PTR *__rest
     for (int q = 0; q < ST_Q; ++q) {
         const uint32_t pos = (uint32_t)q * WAVE + lane;
         const uint64_t at = e0 + pos < nnz ? e0 + pos : nnz - 1;
-        ecol[pos] = (uint32_t)__builtin_nontemporal_load(indices + at);      // the entries are used once: the L2s are for the rhs rows
-        eval[pos] = __builtin_nontemporal_load(data + at);
+        uint32_t col;
+        if (DEVTOOLS && (dbg & 1u)) {                     // (developer A/B, option spmm_debug)
+            col = (uint32_t)indices[at];
+            eval[pos] = data[at];
+        } else {
+            col = (uint32_t)__builtin_nontemporal_load(indices + at);            // the entries are used once: the L2s are for the rhs rows
+            eval[pos] = __builtin_nontemporal_load(data + at);
+        }
+        ecol[pos] = RELAID ? relaid_row(col) : col;
         erow[pos] = 0u;
     }
     // rows: every non-empty row that starts inside the tile marks its first entry with its distance from r0.  The walk covers
@@ -317,7 +346,10 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_stream_kernel(const PTR *__rest
         if (__ballot(b < rn) == 0ull) break;             // wave-uniform (the last tile only)
         double x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = rbase[(uint64_t)ecol[rb + b + u] * ld_rhs];
+        for (int u = 0; u < U; ++u) {
+            const double *src = rbase + (uint64_t)ecol[rb + b + u] * ld_rhs;
+            x[u] = DEVTOOLS && (dbg & 4u) ? __builtin_nontemporal_load(src) : *src;
+        }
 #pragma unroll
         for (int u4 = 0; u4 < U; u4 += 4) {              // rows and values of four entries per LDS read
             const Row4 rw4 = *reinterpret_cast<const Row4 *>(erow + rb + b + u4);
@@ -335,8 +367,9 @@ __global__ __launch_bounds__(MM_BLOCK) void spmm_stream_kernel(const PTR *__rest
                         first = false;
                     } else if (col_ok) {
                         double *dst = obase + (uint64_t)cur * ld_out;
-                        if constexpr (ACC) __builtin_nontemporal_store(*dst + acc, dst);
-                        else __builtin_nontemporal_store(acc, dst);
+                        const double val = ACC ? *dst + acc : acc;
+                        if (DEVTOOLS && (dbg & 2u)) *dst = val;
+                        else __builtin_nontemporal_store(val, dst);
                     }
                     cur = rw[e];
                     acc = 0.0;
@@ -514,21 +547,35 @@ int32_t launch_short_rows(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs,
 
 template <typename IDX, typename PTR, int KP>
 int32_t launch_stream(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint64_t cs_rhs, uint32_t k, double *out, uint64_t ld_out,
-                      uint64_t cs_out, bool acc, double *carry, hipStream_t stream) {
+                      uint64_t cs_out, bool acc, double *carry, double *relaid, hipStream_t stream) {
     const SpmmPlan &pl = a->mm;
     const dim3 grid((unsigned)((pl.ntiles + MM_WAVES - 1) / MM_WAVES)), block(MM_BLOCK);
     const dim3 fgrid((unsigned)((pl.ntiles * KP + MM_BLOCK - 1) / MM_BLOCK));
+    const uint32_t dbg = (uint32_t)options().spmm_debug;
+    if (relaid) {
+        // the rhs once through the chip into a compact row-major copy with scattered rows (2 x cols x k x 8 bytes of traffic)
+        hipLaunchKernelGGL((spmm_relayout_kernel<KP>), dim3((unsigned)((a->cols * KP + MM_BLOCK - 1) / MM_BLOCK)), block, 0, stream, rhs, ld_rhs,
+                           cs_rhs, a->cols, k, relaid);
+        rhs = relaid;
+        ld_rhs = KP;
+        cs_rhs = 1;
+    }
+#define SPRS_STREAM(ACCV, RLV)                                                                                                         \
+    hipLaunchKernelGGL((spmm_stream_kernel<IDX, PTR, KP, ACCV, RLV>), grid, block, 0, stream, (const PTR *)a->indptr,                   \
+                       (const IDX *)a->indices, a->data, a->rows, a->nnz, pl.tile_row, pl.ntiles, rhs, ld_rhs, cs_rhs, k, out, ld_out, \
+                       cs_out, carry, dbg)
     if (acc) {
-        hipLaunchKernelGGL((spmm_stream_kernel<IDX, PTR, KP, true>), grid, block, 0, stream, (const PTR *)a->indptr, (const IDX *)a->indices,
-                           a->data, a->rows, a->nnz, pl.tile_row, pl.ntiles, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, carry);
+        if (relaid) SPRS_STREAM(true, true);
+        else SPRS_STREAM(true, false);
         hipLaunchKernelGGL((spmm_stream_fixup_kernel<PTR, KP, true>), fgrid, block, 0, stream, (const PTR *)a->indptr, pl.tile_row, pl.ntiles,
                            carry, k, out, ld_out, cs_out);
     } else {
-        hipLaunchKernelGGL((spmm_stream_kernel<IDX, PTR, KP, false>), grid, block, 0, stream, (const PTR *)a->indptr, (const IDX *)a->indices,
-                           a->data, a->rows, a->nnz, pl.tile_row, pl.ntiles, rhs, ld_rhs, cs_rhs, k, out, ld_out, cs_out, carry);
+        if (relaid) SPRS_STREAM(false, true);
+        else SPRS_STREAM(false, false);
         hipLaunchKernelGGL((spmm_stream_fixup_kernel<PTR, KP, false>), fgrid, block, 0, stream, (const PTR *)a->indptr, pl.tile_row, pl.ntiles,
                            carry, k, out, ld_out, cs_out);
     }
+#undef SPRS_STREAM
     SPRS_TRY_HIP(hipGetLastError());
     return SPRS_HIP_OK;
 }
@@ -568,7 +615,7 @@ int32_t launch_block(sprs_hip_csmat *a, const double *rhs, uint64_t ld_rhs, uint
 template <typename IDX, typename PTR>
 int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_rhs, uint64_t cs_rhs, double *out, uint64_t ld_out,
                   uint64_t cs_out, bool acc, hipStream_t stream) {
-    double *partial = nullptr;
+    double *partial = nullptr, *relaid = nullptr;
     std::lock_guard<std::recursive_mutex> lock(a->mu);   // held until the kernels that read the plan are launched
     const uint64_t want_long = options().spmm_long_row >= 0 ? (uint64_t)options().spmm_long_row : LONG_ROW;
     // the entry stream keeps 32-bit column ids in LDS; the lane-group mode (reference bits for short rows) has its own kernels
@@ -587,6 +634,24 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
             slot.second = need;
         }
         partial = slot.first;
+        // the re-laid-out copy of the rhs (option spmm_relayout; auto: a rhs that is not row-major — a column of it is a separate
+        // line per entry — or one of 256 MiB and more per column block, where the hub rows' channels decide the time)
+        const int64_t rl = options().spmm_relayout;
+        const bool want = stream_mode && (rl == 1 || (rl == 0 && (cs_rhs != 1 || a->cols * kb * sizeof(double) >= (256ull << 20))));
+        if (want) {
+            const uint64_t rows_pad = (a->cols + RL_MASK) & ~(uint64_t)RL_MASK;
+            const uint64_t kp = kb <= 8 ? 8 : kb <= 16 ? 16 : kb <= 32 ? 32 : 64;
+            const uint64_t bytes = rows_pad * kp * sizeof(double);
+            auto &rs = pl.relaid[(void *)stream];
+            if (rs.second < bytes) {
+                if (rs.first) (void)hipFree(rs.first);
+                rs.first = nullptr;
+                rs.second = 0;
+                SPRS_TRY_HIP(hipMalloc((void **)&rs.first, bytes));
+                rs.second = bytes;
+            }
+            relaid = rs.first;
+        }
     }
     if (a->nnz == 0) {
         // nothing stored: the operator form is all zeros (csmat.rs:2004), the accumulate form leaves `out` alone
@@ -604,10 +669,10 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
         double *o = out + j0 * cs_out;
         int32_t st;
         if (stream_mode) {
-            if (kb <= 8) st = launch_stream<IDX, PTR, 8>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
-            else if (kb <= 16) st = launch_stream<IDX, PTR, 16>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
-            else if (kb <= 32) st = launch_stream<IDX, PTR, 32>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
-            else st = launch_stream<IDX, PTR, 64>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
+            if (kb <= 8) st = launch_stream<IDX, PTR, 8>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, relaid, stream);
+            else if (kb <= 16) st = launch_stream<IDX, PTR, 16>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, relaid, stream);
+            else if (kb <= 32) st = launch_stream<IDX, PTR, 32>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, relaid, stream);
+            else st = launch_stream<IDX, PTR, 64>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, relaid, stream);
         } else if (kb <= 8) st = launch_block<IDX, PTR, 8>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
         else if (kb <= 16) st = launch_block<IDX, PTR, 16>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
         else if (kb <= 32) st = launch_block<IDX, PTR, 32>(a, r, ld_rhs, cs_rhs, kb, o, ld_out, cs_out, acc, partial, stream);
@@ -631,6 +696,8 @@ void SpmmPlan::release() {
     ntiles = 0;
     for (auto &kv : partial) drop(kv.second.first);
     partial.clear();
+    for (auto &kv : relaid) drop(kv.second.first);
+    relaid.clear();
     nchunks = n_multi = 0;
     built = false;
 }

@@ -93,16 +93,19 @@ def test_golden_mul_csc_dense(hip, golden):
         assert rel_err(got, ref) <= 1e-10
 
 
-@pytest.fixture(params=[(0, 1), (0, 0), (2048, 1)], ids=["stream", "chunks", "entry-order"])
+@pytest.fixture(params=[(0, 1, 2), (0, 1, 1), (0, 0, 2), (2048, 1, 2)], ids=["stream", "stream-relaid-rhs", "chunks", "entry-order"])
 def long_row(request, hip):
-    """the three summation modes of spmm.hip: tiles of 256 consecutive entries per wave (default), every row by 512-entry
-    chunks (option spmm_stream = 0: the kernel of rounds 1-3), or rows of <= L entries in the reference's own entry order
-    (option spmm_long_row = L: bit-identical to prod.rs:203-210)"""
+    """the summation modes of spmm.hip: tiles of 256 consecutive entries per wave (default) — gathering from the rhs itself or
+    from its re-laid-out copy (option spmm_relayout) —, every row by 512-entry chunks (option spmm_stream = 0: the kernel of
+    rounds 1-3), or rows of <= L entries in the reference's own entry order (option spmm_long_row = L: bit-identical to
+    prod.rs:203-210)"""
     hip.set_option("spmm_long_row", request.param[0])
     hip.set_option("spmm_stream", request.param[1])
+    hip.set_option("spmm_relayout", request.param[2])
     yield request.param[0]
     hip.set_option("spmm_long_row", -1)
     hip.set_option("spmm_stream", 1)
+    hip.set_option("spmm_relayout", 0)
 
 
 @pytest.mark.parametrize("k", [1, 3, 8, 16, 33, 64, 100])
@@ -187,11 +190,20 @@ def test_stream_tiles_and_runs(hip, k, idx, ptr):
     a = DeviceCsMat.from_host((n, m), ip, ix, dt)
     ref = oracle_spmm((n, m), ip, ix, dt, rhs)
     bound = oracle_spmm((n, m), ip, ix, np.abs(dt), np.abs(rhs))
-    for col_major in (False, True):
-        got = (a * prod.DeviceMat.from_host(rhs, col_major=col_major)).to_host()
-        assert np.all(np.abs(got - ref) <= 64 * np.finfo(float).eps * bound)
-        assert np.all(got[lens == 0] == 0.0)
-        assert np.array_equal(got[lens == 1], ref[lens == 1])
+    for relayout in (2, 1):                                       # from the rhs itself, from its re-laid-out copy: the same bits
+        hip.set_option("spmm_relayout", relayout)
+        try:
+            for col_major in (False, True):
+                got = (a * prod.DeviceMat.from_host(rhs, col_major=col_major)).to_host()
+                assert np.all(np.abs(got - ref) <= 64 * np.finfo(float).eps * bound)
+                assert np.all(got[lens == 0] == 0.0)
+                assert np.array_equal(got[lens == 1], ref[lens == 1])
+                if relayout == 2 and not col_major:
+                    plain = got
+                elif not col_major:
+                    assert np.array_equal(got, plain)
+        finally:
+            hip.set_option("spmm_relayout", 0)
     out0 = rng.standard_normal((n, k))
     ref2 = oracle_spmm((n, m), ip, ix, dt, rhs, out0)
     for col_major in (False, True):
