@@ -635,9 +635,11 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
         }
         partial = slot.first;
         // the re-laid-out copy of the rhs (option spmm_relayout; auto: a rhs that is not row-major — a column of it is a separate
-        // line per entry — or one of 256 MiB and more per column block, where the hub rows' channels decide the time)
+        // line per entry — or one of 256 MiB and more per column block with 24 and more gathers per row to pay for the copy:
+        // R-MAT 4M x 32 2.55 -> 2.20 ms at k = 16, 1M x 16 0.32 -> 0.38 ms, profiles/r11zc)
         const int64_t rl = options().spmm_relayout;
-        const bool want = stream_mode && (rl == 1 || (rl == 0 && (cs_rhs != 1 || a->cols * kb * sizeof(double) >= (256ull << 20))));
+        const bool big = a->cols * kb * sizeof(double) >= (256ull << 20) && a->nnz >= 24 * a->cols;
+        const bool want = stream_mode && (rl == 1 || (rl == 0 && (cs_rhs != 1 || big)));
         if (want) {
             const uint64_t rows_pad = (a->cols + RL_MASK) & ~(uint64_t)RL_MASK;
             const uint64_t kp = kb <= 8 ? 8 : kb <= 16 ? 16 : kb <= 32 ? 32 : 64;
