@@ -42,6 +42,23 @@ def main():
         indptr, indices, data = gen.grid_laplacian(g, g, device=dev, idx_dtype=idt, ptr_dtype=torch.int64)
     else:
         indptr, indices, data = gen.rmat_csr(n, k, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)
+    if os.environ.get("SPGEMM_PERMUTE"):
+        # P A P^T with a random P: the same product up to relabelling, the hub rows / columns no longer at 0, 2^k, 2^j + 2^k —
+        # separates what the ADDRESSES of the hub rows' tables and entries cost from what the power law costs
+        g = torch.Generator(device=dev)
+        g.manual_seed(int(os.environ["SPGEMM_PERMUTE"]))
+        perm = torch.randperm(n, device=dev, generator=g)
+        if os.environ["SPGEMM_PERMUTE"] == "0":                  # control: the same code path, nothing moved
+            perm = torch.arange(n, device=dev)
+        rows_of = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
+        key, order = torch.sort((perm[rows_of] << 32) | perm[indices.long()])
+        new_rows = key >> 32
+        indices = (key & 0xFFFFFFFF).to(idt)
+        data = data[order]
+        indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        indptr[1:] = torch.cumsum(torch.bincount(new_rows, minlength=n), 0)
+        del perm, rows_of, key, order, new_rows
+        torch.cuda.empty_cache()
     a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
     # two runs: the first pays the driver's first-touch of the 53 GB result (erratic: 0.03 .. 1 s when a
     # previous process has just released as much); the second is the steady state a caller sees
