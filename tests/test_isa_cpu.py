@@ -73,3 +73,31 @@ def test_row_draw_sits_in_the_loop_header():
     body = src[src.index("void mid_rows_kernel("):src.index("// ranks of the batch's columns")]
     body = re.sub(r"//[^\n]*", "", body)                     # (the comment that tells the story quotes the bad form)
     assert "for (;;)" not in body, "a wave-uniform draw inside `for (;;)` + `break` was mis-compiled once (DESIGN 4.2)"
+
+
+@pytest.fixture(scope="module")
+def spmm_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "spmm.s"
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "--cuda-device-only", "-S",
+                           os.path.join(ROOT, "sprs_amd", "csrc", "spmm.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    kernels = {}
+    for m in re.finditer(r"^(_ZN8sprs_hip\S+):\s*; @\S+\n(.*?)^\s*s_endpgm", text, flags=re.S | re.M):
+        meta = text[text.index(".amdhsa_kernel " + m.group(1)):]
+        kernels[m.group(1)] = (m.group(2), int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1)),
+                               int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", meta).group(1)))
+    return kernels
+
+
+def test_spmm_stream_kernel_keeps_its_gathers_in_flight(spmm_isa):
+    """the entry-stream SpMM kernel: 16 rhs rows in flight per lane behind ONE wait sequence (a gather under a per-lane
+    condition would be a round trip each), no scratch, and few enough registers for 6 waves per SIMD (7 workgroups of 20 KB LDS per CU)"""
+    names = [k for k in spmm_isa if "spmm_stream_kernel" in k]
+    assert len(names) == 4 * 4 * 2 * 2                          # index x pointer widths, KP = 8 .. 64, accumulate, re-laid-out rhs
+    for name in names:
+        body, vgpr, scratch = spmm_isa[name]
+        assert scratch == 0, name
+        assert vgpr <= 84, (name, vgpr)
+        assert longest_load_burst(body) >= 16, name
