@@ -127,9 +127,10 @@ def case_spmm(rng):
     a = DeviceCsMat.from_host(shape, ip, ix, dt)
     import ctypes as C
     from sprs_amd import _ffi
-    # the three summation modes: entry stream (default), chunks, lane groups in entry order for rows of <= L entries; the accumulate form
+    # the summation modes: entry stream (from the rhs itself / from its re-laid-out copy), chunks, lane groups in entry order for rows of
+    # <= L entries; the accumulate form
     mode = int(rng.integers(0, 4))
-    opts = {0: {}, 1: {}, 2: dict(spmm_stream=0), 3: dict(spmm_long_row=int(rng.choice([1, 5, 40, 600])))}[mode]
+    opts = {0: {}, 1: dict(spmm_relayout=1), 2: dict(spmm_stream=0), 3: dict(spmm_long_row=int(rng.choice([1, 5, 40, 600])))}[mode]      # (1: the rhs gathered from its re-laid-out copy)
     setopt(**opts)
     acc = bool(rng.integers(0, 2))
     out0 = rng.standard_normal((rows, k)) if acc else np.zeros((rows, k))
@@ -327,6 +328,7 @@ def case_dense(rng):
         a = DeviceCsMat.from_host(shape, ip, ix, dt)
     rhs = rng.standard_normal((cols, k))
     rcm, ocm = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    setopt(spmm_relayout=int(rng.integers(0, 3)))                 # auto (a column-major rhs of >= 8 columns is re-laid-out) / always / never
     tol = lambda got, ref, mag: np.abs(got - ref) <= 1e-10 * np.maximum(np.abs(ref), 1e-300) + 256 * np.finfo(float).eps * mag
     out = a * prod.DeviceMat.from_host(rhs, col_major=rcm)
     ok = out.col_major == (k < 8) and bool(tol(out.to_host(), m @ rhs, absm @ np.abs(rhs)).all())
