@@ -649,8 +649,12 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
                 if (rs.first) (void)hipFree(rs.first);
                 rs.first = nullptr;
                 rs.second = 0;
-                SPRS_TRY_HIP(hipMalloc((void **)&rs.first, bytes));
-                rs.second = bytes;
+                // (no room for a second copy of the rhs: the kernel gathers from the caller's, as with spmm_relayout = 2)
+                if (hipMalloc((void **)&rs.first, bytes) == hipSuccess) rs.second = bytes;
+                else {
+                    rs.first = nullptr;
+                    (void)hipGetLastError();
+                }
             }
             relaid = rs.first;
         }
