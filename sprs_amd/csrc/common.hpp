@@ -86,7 +86,7 @@ constexpr bool DEVTOOLS = false;
     X(spgemm_midwin, 15, 14, 15, 0)     /* log2 of the column window of the wave-per-row kernel: 14 or 15 (measured equal on config 5; 2^16 — 10 waves per CU — slower: profiles/r10d) */ \
     X(spgemm_mid, 65536, 0, 1ll << 31, 0) /* rows of <= 64 k's and at most this many products run one wave per row (0: none) */   \
     X(spgemm_ordered, 1, 0, 1, 0)       /* 1: products are added in the reference's order (values bit-identical to sprs'); 0: the waves of a large-row workgroup add as they arrive (LDS atomics: same products, rounding-level differences, not reproducible run to run; ~20 % faster kernel) */ \
-    X(spmm_relayout, 0, 0, 2, 0)        /* SpMM stream kernel: gather from a copy of the rhs whose rows are scattered by a multiplicative hash inside blocks of 4096 rows (hub columns sit at 0, 2^k, 2^j + 2^k: their rhs rows would share a few L2 / fabric channels): 0 auto (a rhs of >= 256 MiB per column block under >= 24 entries per column, or one that is not row-major), 1 on, 2 off */ \
+    X(spmm_relayout, 0, 0, 2, 0)        /* SpMM stream kernel: gather from a copy of the rhs whose rows are scattered by a multiplicative hash inside blocks of 4096 rows (hub columns sit at 0, 2^k, 2^j + 2^k: their rhs rows would share a few L2 / fabric channels): 0 auto (a rhs of >= 256 MiB per column block under >= 24 entries per column whose row pitch is a power of two or leaves rows of < 16 columns across lines, or one that is not row-major), 1 on, 2 off */ \
     X(spmm_debug, 0, 0, 7, 1)           /* developer A/B of the stream kernel (right results): 1 plain instead of non-temporal entry loads, 2 plain result stores, 4 non-temporal rhs gathers */ \
     X(spgemm_debug, 0, 0, 15, 1)        /* TIMING EXPERIMENTS ONLY (wrong results): 1 no ordering of the adds, 2 no index emission, 4 no value stores and 8 no adds (wave-per-row kernel) */ \
     X(spgemm_occupancy, 3, 2, 3, 0)     /* workgroups per CU the large-row numeric kernel is compiled for: 3 (80 VGPRs) or 2 (128) */ \

@@ -637,9 +637,13 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
         // the re-laid-out copy of the rhs (option spmm_relayout; auto: a rhs that is not row-major — a column of it is a separate
         // line per entry — or one of 256 MiB and more per column block with 24 and more gathers per row to pay for the copy:
         // R-MAT 4M x 32 2.55 -> 2.20 ms at k = 16, 1M x 16 0.32 -> 0.38 ms, profiles/r11zc)
+        // ... and whose row pitch invites the trouble: a power of two (hub ids 2^j times a pitch of 2^m bytes; a pitch of 192 or 384
+        // bytes — k = 24, 48 — spreads the hub rows by itself: 10.7 ms in place against 15.5 ms at k = 32, and the copy only costs
+        // there, profiles/r12b), or rows of fewer than 16 columns that straddle lines (k = 12: 96-byte rows; the copy's pitch is 128)
         const int64_t rl = options().spmm_relayout;
         const bool big = a->cols * kb * sizeof(double) >= (256ull << 20) && a->nnz >= 24 * a->cols;
-        const bool want = stream_mode && (rl == 1 || (rl == 0 && (cs_rhs != 1 || big)));
+        const bool pitch = (ld_rhs & (ld_rhs - 1)) == 0 || (kb < 16 && (ld_rhs * sizeof(double)) % 128 != 0);
+        const bool want = stream_mode && (rl == 1 || (rl == 0 && (cs_rhs != 1 || (big && pitch))));
         if (want) {
             const uint64_t rows_pad = (a->cols + RL_MASK) & ~(uint64_t)RL_MASK;
             const uint64_t kp = kb <= 8 ? 8 : kb <= 16 ? 16 : kb <= 32 ? 32 : 64;
