@@ -22,6 +22,20 @@ def main():
     n = 1_000_000
     idt = torch.int64 if idx_bytes == 8 else torch.int32
     indptr, indices, data = gen.rmat_csr(n, 8, device=dev, idx_dtype=idt, ptr_dtype=torch.int64, oversample=1.0)
+    if os.environ.get("SPGEMM_PERMUTE"):                      # P A P^T with a random P (0: identity, the control): tests/spgemm_bench.py
+        g = torch.Generator(device=dev)
+        g.manual_seed(int(os.environ["SPGEMM_PERMUTE"]))
+        perm = torch.randperm(n, device=dev, generator=g)
+        if os.environ["SPGEMM_PERMUTE"] == "0":
+            perm = torch.arange(n, device=dev)
+        rows_of = torch.repeat_interleave(torch.arange(n, device=dev), (indptr[1:] - indptr[:-1]).long())
+        key, order = torch.sort((perm[rows_of] << 32) | perm[indices.long()])
+        new_rows = key >> 32
+        indices = (key & 0xFFFFFFFF).to(idt)
+        data = data[order]
+        indptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        indptr[1:] = torch.cumsum(torch.bincount(new_rows, minlength=n), 0)
+        del perm, rows_of, key, order, new_rows
     a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
     torch.cuda.synchronize()
     print("generated: nnz(A) = %d" % indices.numel(), file=sys.stderr, flush=True)
