@@ -18,6 +18,8 @@
 #   spgemm_traffic        FETCH_SIZE / WRITE_SIZE pass over SpGEMM config 5 -> spgemm_traffic.txt (scripts/spgemm_traffic.py)
 #   spmm[:args]           SpMM on R-MAT 10M (scripts/spmm_bench.py [n nnz_per_row k ...]) + its kernel stats
 #   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
+#   pmcsq:<config>        SQ counter passes (instruction mix, busy / wait cycles) over one sweep config, per kernel means -> pmcsq.txt
+#   probe:<name>[:args]   scripts/probes/<name>.out [args] (stand-alone hardware probe, built here with hipcc; JSON lines -> <name>.jsonl)
 TAG=${1:?tag}; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
@@ -65,6 +67,18 @@ for step in "$@"; do
               echo "== group $i: $grp" | tee -a $OUT/spgemm_pmc.txt
               if [ -n "$f" ]; then python3 $ROOT/scripts/rocprof_summary.py "$f" sprs_hip | sed -n '/PMC counters/,$p' | grep -E "rows_kernel|PMC|kernel " | cut -c1-250 | tee -a $OUT/spgemm_pmc.txt; fi
             done ;;
+    pmcsq)  i=0
+            for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" \
+                       "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT" \
+                       "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU"; do
+              i=$((i+1)); rm -rf /tmp/pq_$i
+              ( cd /tmp && timeout -s KILL 200 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pq_$i -o pmc -- python $ROOT/scripts/spmv_sweep.py --steps 3 --warmup 1 "$arg" > /dev/null 2>&1 )
+              f=$(find /tmp/pq_$i -name "*.db" | head -1)
+              echo "== $arg, group $i: $grp" | tee -a $OUT/pmcsq.txt
+              if [ -n "$f" ]; then python3 $ROOT/scripts/rocprof_summary.py "$f" band_ | sed -n '/PMC counters/,$p' | grep -E "band_(hot|cold|reduce)|PMC|kernel " | cut -c1-200 | tee -a $OUT/pmcsq.txt; fi
+            done ;;
+    probe)  pn=${arg%%:*}; pa=""; [ "$arg" != "$pn" ] && pa=${arg#*:}
+            timeout 600 scripts/probes/$pn.out $pa 2>&1 | tee -a $OUT/$pn.jsonl ;;
     spgemm_parity) timeout -s KILL ${PARITY_TIMEOUT:-420} python scripts/spgemm_whole_parity.py $OUT/spgemm5_whole_parity.json ${arg:-20000} 2>&1 | grep -v amdgpu.ids | cut -c1-600 ;;
     spgemm_stats)  # per-kernel times of ONE config-5 product
             ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 150 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spgemm_one.py 2 > $OUT/spgemm_one.json 2>/dev/null; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|^#|sprs_hip" | cut -c1-200 | tee $OUT/spgemm_kernel_stats.txt ;;

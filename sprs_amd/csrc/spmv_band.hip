@@ -294,10 +294,7 @@ struct BandScratch {        // per stream
     // the gather-bound kernels (cold pieces, short rows: L2 -> L1 fills) run beside the HBM-bound hot kernel on a second stream
     hipStream_t aux = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    // the first hot slices are reduced on a third stream while the hot kernel streams the others
-    double *ysum = nullptr;                        // one running sum per long row between the two parts of the reduction
-    hipStream_t aux2 = nullptr;
-    hipEvent_t first_done = nullptr, first_reduced = nullptr;
+    hipEvent_t cold_done = nullptr;                // the cold pieces' partial sums are written (the short rows may still run)
 };
 
 struct BandPlan {
@@ -315,11 +312,9 @@ struct BandPlan {
     Seg *segs = nullptr;                           // hot segments (workgroup by workgroup), then one segment per cold piece, the short piece
     uint32_t *wg_seg = nullptr;                    // hot workgroup b takes segments wg_seg[b] .. wg_seg[b + 1] - 1
     uint32_t nranges = 0, nsegs = 0, hot_wgs = 0, cold_tiles = 4, hot_run = 4;
-    void *spills = nullptr, *spills_first = nullptr;   // Spill records (device): of the first hot slices (below hot_cut), of everything else
-    uint32_t nspills = 0, nspills_first = 0;
+    void *spills = nullptr, *spills_y = nullptr;   // Spill records (device): into the partial sums (hot slices, cold pieces); into y (short rows)
+    uint32_t nspills = 0, nspills_y = 0;
     bool small = false;                            // few tiles per CU: the launches of one SpMV stay on one stream (the fork / join costs more than it hides)
-    uint32_t hot_cut = 0;                          // hot slices [0, hot_cut) are launched (and reduced) first; 0: one launch, one reduction
-    uint32_t hot_wgs_first = 0;                    // workgroups of the first hot launch (the others: hot_wgs - hot_wgs_first)
     ColdGroup *groups = nullptr;
     unsigned long long *wmask = nullptr;           // per (64 long rows, piece): which rows have a partial
     uint32_t *wbase = nullptr;                     //                            and where the first one is
@@ -349,7 +344,7 @@ void band_free(BandPlan *bp) {
     drop(bp->tile_row_all);
     drop(bp->segs);
     drop(bp->spills);
-    drop(bp->spills_first);
+    drop(bp->spills_y);
     drop(bp->wg_seg);
     drop(bp->groups);
     drop(bp->wmask);
@@ -359,10 +354,7 @@ void band_free(BandPlan *bp) {
         drop(kv.second.carry);
         drop(kv.second.xp);
         drop(kv.second.pieces);
-        drop(kv.second.ysum);
-        if (kv.second.first_done) (void)hipEventDestroy(kv.second.first_done);
-        if (kv.second.first_reduced) (void)hipEventDestroy(kv.second.first_reduced);
-        if (kv.second.aux2) (void)hipStreamDestroy(kv.second.aux2);
+        if (kv.second.cold_done) (void)hipEventDestroy(kv.second.cold_done);
         if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
         if (kv.second.join) (void)hipEventDestroy(kv.second.join);
         if (kv.second.aux) (void)hipStreamDestroy(kv.second.aux);
@@ -629,29 +621,20 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         // bound — every wave gets only a few tiles — and does better with more, shorter shares and single-tile ranges
         // (hot kernel 45 against 61 us, profiles/r05p)
         const bool small_hot = hot_tiles < 400ull * (uint64_t)ncu;
-        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : 2;      // (small plans: 4 rounds until round 4; 2 measured better with split 8, profiles/r10u)
+        // (small plans: 4 rounds until round 4; 2 measured better with split 8, profiles/r10u.  Big plans: 2 until round 5; with the
+        // hot kernel no longer waiting for its stores 3 rounds measured 3 - 5 % better on three boxes — 1.046 / 1.049 - 1.089 / 1.059 - 1.098
+        // against 1.081 / 1.114 - 1.117 / 1.080 - 1.116 ms — and 4 rounds 5 % worse, profiles/r13b, r13n, r13o)
+        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : (small_hot ? 2 : 3);
         if (o.spmv_band_hot_run <= 0 && small_hot) bp->hot_run = 1;
         bp->small = small_hot;
-        // Option spmv_band_hot_cut = c: two hot launches, slices [0, c) then [c, nh), and the first slices' carries and their part
-        // of every row's sum on a third stream beside the second launch (the first 64 of 128 slices of R-MAT 10M hold 94 % of
-        // the hot entries and 78 % of the partial sums).  Measured NEGATIVE, so off by default: the reduction then competes
-        // with the gather kernels and the second launch for the same fabric — 1.060 .. 1.090 ms for c = 32 .. 80 against
-        // 1.045 ms in one part (medians of 3, profiles/r05o).  The cut changes the ASSOCIATION of a row's sum (which slices are added
-        // together first): results with and without it agree to rounding (1e-13, tests/test_spmv_band_gpu.py::test_two_part_reduction), not
-        // bit for bit; each setting on its own is deterministic run to run.
-        uint32_t cut = 0;
-        if (o.spmv_band_hot_cut > 0) {
-            cut = (uint32_t)o.spmv_band_hot_cut / RU * RU;
-            if (cut >= nh) cut = 0;
-        }
-        bp->hot_cut = cut;
         auto split = [&](uint32_t k_lo, uint32_t k_hi) {             // equal shares of the tiles of slices [k_lo, k_hi) per workgroup
             uint64_t tiles = 0;
             for (uint32_t k = k_lo; k < k_hi; ++k) tiles += bp->host_pieces[k].ntiles;
             if (!tiles) return;
             uint64_t nwg = (uint64_t)ncu * rounds;
             if (nwg > tiles) nwg = tiles;
-            const uint64_t Q = (tiles + nwg - 1) / nwg;               // wave tiles per workgroup
+            uint64_t Q = (tiles + nwg - 1) / nwg;                     // wave tiles per workgroup
+            if (o.spmv_band_share > 0) Q = (uint64_t)o.spmv_band_share;   // (A/B: the share sets how far apart the workgroups stream)
             uint32_t k = k_lo;
             uint64_t k_first = 0;                                     // number (inside the group) of slice k's first tile
             for (uint64_t b = 0; b * Q < tiles; ++b) {
@@ -666,9 +649,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
                 wg_seg.push_back((uint32_t)segs.size());
             }
         };
-        split(0, cut ? cut : (uint32_t)nh);
-        bp->hot_wgs_first = (uint32_t)(wg_seg.size() - 1);
-        if (cut) split(cut, (uint32_t)nh);
+        split(0, (uint32_t)nh);
         bp->hot_wgs = (uint32_t)(wg_seg.size() - 1);
     }
     {   // cold pieces + short rows: few tiles (R-MAT 1M: 4 600) want one tile per wave, or the launch is a handful of waves per CU
@@ -723,15 +704,15 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         SPRS_TRY_HIP(hipMemcpyAsync(poff_d.p, bp->pair_off.data(), bp->pair_off.size() * 8, hipMemcpyHostToDevice, stream));
         SPRS_TRY_HIP(hipMemsetAsync(cnt_d.p, 0, 8, stream));
         SPRS_TRY_HIP(hipMalloc(&bp->spills, ((uint64_t)nranges + 1) * sizeof(Spill)));     // at most one per range
-        SPRS_TRY_HIP(hipMalloc(&bp->spills_first, ((uint64_t)nranges + 1) * sizeof(Spill)));
+        SPRS_TRY_HIP(hipMalloc(&bp->spills_y, ((uint64_t)nranges + 1) * sizeof(Spill)));
         hipLaunchKernelGGL(bp_spill_kernel, dim3((nranges + 255) / 256), dim3(256), 0, stream, (const Seg *)bp->segs, bp->nsegs, nranges,
                            (const BandPiece *)pcs_d.p, (const uint64_t *)poff_d.p, bp->nh, (const uint16_t *)bp->cid_hot,
-                           (const uint32_t *)bp->cid_cold, bp->hot_cut, (Spill *)bp->spills_first, (Spill *)bp->spills,
+                           (const uint32_t *)bp->cid_cold, (Spill *)bp->spills_y, (Spill *)bp->spills,
                            (unsigned int *)cnt_d.p);
         SPRS_TRY_HIP(hipGetLastError());
         uint32_t counts[2] = {0, 0};
         SPRS_TRY_HIP(hipMemcpy(counts, cnt_d.p, 8, hipMemcpyDeviceToHost));
-        bp->nspills_first = counts[0];
+        bp->nspills_y = counts[0];
         bp->nspills = counts[1];
         bp->bytes += ((uint64_t)counts[0] + counts[1]) * sizeof(Spill);
     }
@@ -768,12 +749,7 @@ int32_t band_scratch(BandPlan *bp, hipStream_t stream, BandScratch **out) {
         SPRS_TRY_HIP(hipStreamCreateWithFlags(&sc.aux, hipStreamNonBlocking));
         SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.fork, hipEventDisableTiming));
         SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.join, hipEventDisableTiming));
-        if (bp->hot_cut) {
-            SPRS_TRY_HIP(hipMalloc((void **)&sc.ysum, ((uint64_t)bp->n_long + 1) * 8));
-            SPRS_TRY_HIP(hipStreamCreateWithFlags(&sc.aux2, hipStreamNonBlocking));
-            SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.first_done, hipEventDisableTiming));
-            SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.first_reduced, hipEventDisableTiming));
-        }
+        SPRS_TRY_HIP(hipEventCreateWithFlags(&sc.cold_done, hipEventDisableTiming));
         it = bp->scratch.emplace((void *)stream, sc).first;
     }
     *out = &it->second;
@@ -792,10 +768,16 @@ int32_t band_build(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
 uint64_t band_plan_bytes(const BandPlan *bp) { return bp ? bp->bytes : 0; }
 
 // One SpMV on a banded plan: the launches, on `stream` and on the scratch's second stream.
-//   stream: gather the hot labels of x -> [fork] -> hot slices ............................... [join] -> carries -> reduce
-//   aux:                                  [fork] -> scatter the rest of x, clear y -> cold pieces + short rows -> [join]
-// The gather-bound launch (cold pieces + short rows: L2 -> L1 line fills) runs beside the HBM-bound hot slices (option
+//   stream: gather the hot labels of x -> [fork] -> hot slices ............ [cold_done] -> carries -> reduce ........ [join]
+//   aux:                                  [fork] -> scatter the rest of x, clear y -> cold pieces -> [cold_done] -> short rows -> their carries -> [join]
+// The gather-bound launches (cold pieces + short rows: L2 -> L1 line fills) run beside the HBM-bound hot slices (option
 // spmv_band_overlap, 2 = off); with the overlap the permutation is split as well (spmv_band_split_permute, 2 = off).
+// The reduction of the long rows needs the hot slices and the cold pieces, NOT the short rows (they write y themselves): it
+// starts when the hot kernel ends and runs beside what is left of the short rows (round 5; until then it waited for the whole
+// second stream; option spmv_band_tail = 2 brings that order back for A/B).  What it is worth is small: concurrent kernels of
+// this SpMV mostly time-share the fabric — the sum of their times alone is 1 190 us, side by side they take 1 040 - 1 080
+// (profiles/r13c, r13d) — and holding part of the short rows back until the hot kernel is done, so that they run beside the
+// reduction, was SLOWER (1.11 - 1.16 against 1.07 ms, profiles/r13d: a small kernel like the carries then waits behind them).
 int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, bool acc, hipStream_t stream) {
     BandScratch *sc = nullptr;
     {
@@ -805,47 +787,18 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     // (a small plan keeps to one stream unless the overlap is asked for: R-MAT 1M 0.092 against 0.096 ms, profiles/r05p)
     const bool overlap = options().spmv_band_overlap != 2 && bp->hot_wgs && bp->cold_blocks && (!bp->small || options().spmv_band_overlap == 1);
     const bool split_permute = overlap && options().spmv_band_split_permute != 2 && bp->hot_labels;
+    const bool early_reduce = overlap && options().spmv_band_tail != 2;
     const uint64_t span = acc ? bp->cols : (bp->cols > a->rows ? bp->cols : a->rows);
     hipStream_t cstream = overlap ? sc->aux : stream;
-    if (split_permute)
-        hipLaunchKernelGGL(band_gather_hot_kernel, dim3((bp->hot_labels + 255) / 256), dim3(256), 0, stream, x,
-                           (const uint32_t *)bp->inv_hot, bp->hot_labels, sc->xp);
-    else
-        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, stream, x,
-                           (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, 0u);
-    SPRS_TRY_HIP(hipGetLastError());
-    if (overlap) {
-        SPRS_TRY_HIP(hipEventRecord(sc->fork, stream));           // the hot labels of xp (or all of it, and the cleared y) are ready
-        SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux, sc->fork, 0));
-    }
-    if (split_permute) {
-        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, cstream, x,
-                           (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, bp->hot_labels);
+    auto launch_carry = [&](const void *spills, uint32_t n, hipStream_t st) -> int32_t {
+        if (!n) return SPRS_HIP_OK;
+        hipLaunchKernelGGL(band_carry_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)spills, n, (const double *)sc->carry,
+                           sc->partial, y);
         SPRS_TRY_HIP(hipGetLastError());
-    }
-    if (bp->cold_blocks) {
-        // two launches: the cold pieces of the long rows (partial sums out), then the short rows (y out)
-        const uint32_t cut = bp->has_short_group ? bp->short_first_block : bp->cold_blocks;
-        for (uint32_t part = 0; part < 2; ++part) {
-            const uint32_t b0 = part ? cut : 0u, nb = part ? bp->cold_blocks - cut : cut;
-            if (!nb) continue;
-#define SPRS_COLD(ACCV, TOYV)                                                                                               \
-    hipLaunchKernelGGL((band_cold_kernel<ACCV, TOYV>), dim3(nb), dim3(CNT), 0, cstream, (const BandPiece *)sc->pieces,          \
-                       (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,                             \
-                       (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, sc->carry, b0, bp->cold_tiles)
-            if (!part) SPRS_COLD(false, false);
-            else if (acc) SPRS_COLD(true, true);
-            else SPRS_COLD(false, true);
-#undef SPRS_COLD
-            SPRS_TRY_HIP(hipGetLastError());
-        }
-    }
-    if (overlap) SPRS_TRY_HIP(hipEventRecord(sc->join, sc->aux));
-    const uint32_t nwb = (bp->n_long + WAVE - 1) / WAVE;
-    const uint32_t per_xcd = (nwb + 7) / 8;
-    const dim3 rg(((per_xcd + 3) / 4) * 8), rb(256);                 // reduction: one wave per block of 64 long rows, XCD by XCD
-    auto launch_hot = [&](uint32_t wg0, uint32_t nwg) -> int32_t {
-        if (!nwg) return SPRS_HIP_OK;
+        return SPRS_HIP_OK;
+    };
+    auto launch_hot = [&]() -> int32_t {
+        if (!bp->hot_wgs) return SPRS_HIP_OK;
         const uint32_t lds = hot_lds_bytes(bp->xt_log2);
 #ifndef SPRS_HIP_EMU
         {   // more than 64 KiB of dynamic LDS has to be asked for, once per kernel and device
@@ -860,55 +813,72 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         }
 #endif
         if (bp->xt_log2 == 13)
-            hipLaunchKernelGGL((band_hot_kernel<13>), dim3(nwg), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
-                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg + wg0,
+            hipLaunchKernelGGL((band_hot_kernel<13>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
+                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg,
                                (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry,
                                (uint32_t)options().spmv_band_debug);
         else
-            hipLaunchKernelGGL((band_hot_kernel<14>), dim3(nwg), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
-                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg + wg0,
+            hipLaunchKernelGGL((band_hot_kernel<14>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
+                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg,
                                (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry,
                                (uint32_t)options().spmv_band_debug);
         SPRS_TRY_HIP(hipGetLastError());
         return SPRS_HIP_OK;
     };
-    auto launch_carry = [&](const void *spills, uint32_t n, hipStream_t st) -> int32_t {
-        if (!n) return SPRS_HIP_OK;
-        hipLaunchKernelGGL(band_carry_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)spills, n, (const double *)sc->carry,
-                           sc->partial, y);
+    // blocks [b0, b0 + nb) of the gather launch: cold pieces (partial sums out) below `cut`, short rows (y out) from there on
+    const uint32_t cut = bp->has_short_group ? bp->short_first_block : bp->cold_blocks;
+    auto launch_gather = [&](uint32_t b0, uint32_t nb) -> int32_t {
+        if (!nb) return SPRS_HIP_OK;
+#define SPRS_COLD(ACCV, TOYV)                                                                                               \
+    hipLaunchKernelGGL((band_cold_kernel<ACCV, TOYV>), dim3(nb), dim3(CNT), 0, cstream, (const BandPiece *)sc->pieces,          \
+                       (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,                             \
+                       (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, sc->carry, b0, bp->cold_tiles)
+        if (b0 < cut) SPRS_COLD(false, false);
+        else if (acc) SPRS_COLD(true, true);
+        else SPRS_COLD(false, true);
+#undef SPRS_COLD
         SPRS_TRY_HIP(hipGetLastError());
         return SPRS_HIP_OK;
     };
-    auto launch_reduce = [&](uint32_t k0, uint32_t k1, const double *init, double *ysum_out, hipStream_t st) -> int32_t {
-        if (acc)
-            hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, st, (const double *)sc->partial, (const unsigned long long *)bp->wmask,
-                               (const uint32_t *)bp->wbase, (const uint32_t *)bp->long_rows, y, init, ysum_out, bp->n_long, bp->np_pad, nwb, k0, k1);
-        else
-            hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, st, (const double *)sc->partial, (const unsigned long long *)bp->wmask,
-                               (const uint32_t *)bp->wbase, (const uint32_t *)bp->long_rows, y, init, ysum_out, bp->n_long, bp->np_pad, nwb, k0, k1);
-        SPRS_TRY_HIP(hipGetLastError());
-        return SPRS_HIP_OK;
-    };
-    const bool two_part = bp->hot_cut != 0 && sc->aux2 != nullptr && options().spmv_band_overlap != 2;
-    SPRS_TRY(launch_hot(0, bp->hot_wgs_first));
-    if (two_part) {
-        // the first slices are complete: their carries and their part of every row's sum on the third stream ...
-        SPRS_TRY_HIP(hipEventRecord(sc->first_done, stream));
-        SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux2, sc->first_done, 0));
-        SPRS_TRY(launch_carry(bp->spills_first, bp->nspills_first, sc->aux2));
-        SPRS_TRY(launch_reduce(0, bp->hot_cut, nullptr, sc->ysum, sc->aux2));
-        SPRS_TRY_HIP(hipEventRecord(sc->first_reduced, sc->aux2));
+
+    if (split_permute)
+        hipLaunchKernelGGL(band_gather_hot_kernel, dim3((bp->hot_labels + 255) / 256), dim3(256), 0, stream, x,
+                           (const uint32_t *)bp->inv_hot, bp->hot_labels, sc->xp);
+    else
+        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, stream, x,
+                           (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, 0u);
+    SPRS_TRY_HIP(hipGetLastError());
+    if (overlap) {
+        SPRS_TRY_HIP(hipEventRecord(sc->fork, stream));           // the hot labels of xp (or all of it, and the cleared y) are ready
+        SPRS_TRY(launch_hot());
+        SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux, sc->fork, 0));
     }
-    SPRS_TRY(launch_hot(bp->hot_wgs_first, bp->hot_wgs - bp->hot_wgs_first));     // ... while the other slices stream
-    if (overlap) SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->join, 0));
-    if (!two_part) SPRS_TRY(launch_carry(bp->spills_first, bp->nspills_first, stream));
+    if (split_permute) {
+        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, cstream, x,
+                           (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, bp->hot_labels);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    SPRS_TRY(launch_gather(0, cut));
+    if (early_reduce) SPRS_TRY_HIP(hipEventRecord(sc->cold_done, sc->aux));
+    SPRS_TRY(launch_gather(cut, bp->cold_blocks - cut));
+    // the short rows' own carries follow them on their stream
+    if (early_reduce) SPRS_TRY(launch_carry(bp->spills_y, bp->nspills_y, sc->aux));
+    if (overlap) SPRS_TRY_HIP(hipEventRecord(sc->join, sc->aux));
+    else SPRS_TRY(launch_hot());
+    if (overlap) SPRS_TRY_HIP(hipStreamWaitEvent(stream, early_reduce ? sc->cold_done : sc->join, 0));
+    if (!early_reduce) SPRS_TRY(launch_carry(bp->spills_y, bp->nspills_y, stream));
     SPRS_TRY(launch_carry(bp->spills, bp->nspills, stream));
-    if (two_part) {
-        SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->first_reduced, 0));
-        SPRS_TRY(launch_reduce(bp->hot_cut, bp->np_pad, sc->ysum, nullptr, stream));
-    } else {
-        SPRS_TRY(launch_reduce(0, bp->np_pad, nullptr, nullptr, stream));
-    }
+    const uint32_t nwb = (bp->n_long + WAVE - 1) / WAVE;
+    const uint32_t per_xcd = (nwb + 7) / 8;
+    const dim3 rg(((per_xcd + 3) / 4) * 8), rb(256);                 // reduction: one wave per block of 64 long rows, XCD by XCD
+    if (acc)
+        hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, stream, (const double *)sc->partial, (const unsigned long long *)bp->wmask,
+                           (const uint32_t *)bp->wbase, (const uint32_t *)bp->long_rows, y, bp->n_long, bp->np_pad, nwb);
+    else
+        hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, stream, (const double *)sc->partial, (const unsigned long long *)bp->wmask,
+                           (const uint32_t *)bp->wbase, (const uint32_t *)bp->long_rows, y, bp->n_long, bp->np_pad, nwb);
+    SPRS_TRY_HIP(hipGetLastError());
+    if (early_reduce) SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->join, 0));   // the short rows and their carries
     return SPRS_HIP_OK;
 }
 

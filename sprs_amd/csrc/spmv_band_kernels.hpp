@@ -344,7 +344,15 @@ __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kern
 #pragma unroll                                                           // turn an infinite x[first label] into a NaN
                 for (int q = 0; q < EPL; ++q) pr[q] = lane * EPL + q < cnt ? pr[q] : 0.0;
             }
-            const uint32_t R0 = R0n;
+            // tile_row[w] is the LAST load of the tile's request: taken here, in front of the flush, so that its wait covers only
+            // loads issued a whole tile ago.  (Until round 5 the compiler sank this copy behind the flush's stores, and on gfx950
+            // loads and stores count on ONE in-order vmcnt: the wave then waited for the acknowledgement of its stores with no
+            // load in flight, once per tile — `s_waitcnt vmcnt(0)` between the flush and the next request in the ISA; the probe
+            // scripts/probes/stream_store.hip prices such a drain at 1.0 - 2.3 us per tile.)
+            uint32_t R0 = R0n;
+#ifndef SPRS_HIP_EMU
+            asm volatile("" : "+v"(R0)::"memory");
+#endif
             // the tile after this one: the next of the range, or the first of the wave's next range
             const uint32_t rend = (r + 1) * run < n ? (r + 1) * run : n;
             const bool range_ends = t + 1 >= rend;
@@ -508,8 +516,8 @@ struct Spill {
 __global__ __launch_bounds__(256) void bp_spill_kernel(const Seg *__restrict__ segs, uint32_t nsegs, uint32_t nranges,
                                                        const BandPiece *__restrict__ pieces, const uint64_t *__restrict__ pair_off,
                                                        uint32_t nhot, const uint16_t *__restrict__ cid_hot,
-                                                       const uint32_t *__restrict__ cid_cold, uint32_t first_cut,
-                                                       Spill *__restrict__ spills_first, Spill *__restrict__ spills_rest,
+                                                       const uint32_t *__restrict__ cid_cold,
+                                                       Spill *__restrict__ spills_y, Spill *__restrict__ spills_partial,
                                                        unsigned int *__restrict__ count) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nranges) return;
@@ -530,10 +538,11 @@ __global__ __launch_bounds__(256) void bp_spill_kernel(const Seg *__restrict__ s
         if (!nj.valid || nj.piece != rg.piece || d.tile_row[nj.tile0] - 1 != row || !range_has_head(d, nj.piece, nj.tile0, cid_hot, cid_cold, nhot))
             break;
     }
-    // two lists: the hot slices below first_cut (reduced first, while the hot kernel still streams the others) and the rest
-    const bool first = rg.piece < first_cut;
+    // two lists: the short rows' (into y, applied behind them on their stream) and the long rows' (into the partial sums, in
+    // front of the reduction)
+    const bool first = d.to_y != 0;
     const unsigned int slot = atomicAdd(count + (first ? 0 : 1), 1u);
-    (first ? spills_first : spills_rest)[slot] = Spill{d.to_y ? (uint64_t)d.rowidx[row] : pair_off[rg.piece] + row, i, n, d.to_y, 0u};
+    (first ? spills_y : spills_partial)[slot] = Spill{d.to_y ? (uint64_t)d.rowidx[row] : pair_off[rg.piece] + row, i, n, d.to_y, 0u};
 }
 
 // per SpMV: the heads of a record's ranges are added to the row's sum in range order
@@ -616,16 +625,16 @@ __device__ __forceinline__ uint32_t band_mask_rank(uint32_t m_lo, uint32_t m_hi,
 #endif
 }
 
-// The pieces [k_begin, k_end) of every row (both multiples of RU).  The reduction may run in two parts — the first hot
-// slices while the hot kernel still streams the others, band_spmv — that continue ONE chain of additions: the first part
-// leaves its sums in ysum (one per long row), the second starts from them: the same bits as a single pass.
-//   init: sums to start from (null: 0.0);  ysum_out: where the sums go (null: they are final, y[long_rows[j]] (+)= sum)
+// All pieces of every row, in ascending order.
+// (Round 5 tried the transposed form — lane = PARTIAL: a wave owns 128 / 256 long rows with one LDS accumulator each, the
+// partials of the block inside a piece are a contiguous run cut into chunks of 64, loaded with every lane busy together with
+// one byte per pair that names the row, added with ds_add_f64 — 4 x fewer, full load instructions: 126 - 134 us against
+// 122 us, and 99 us even with the partial array read front to back and neither adds nor stores (profiles/r13h ... r13k).  The
+// reduction is not bound by its instruction count or its access pattern; the form with the smaller tables stayed.)
 template <bool ACC>
 __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restrict__ partial, const unsigned long long *__restrict__ wmask,
                                                           const uint32_t *__restrict__ wbase, const uint32_t *__restrict__ long_rows,
-                                                          double *__restrict__ y, const double *__restrict__ init,
-                                                          double *__restrict__ ysum_out, uint32_t n_long, uint32_t np_pad, uint32_t nwb,
-                                                          uint32_t k_begin, uint32_t k_end) {
+                                                          double *__restrict__ y, uint32_t n_long, uint32_t np_pad, uint32_t nwb) {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     // wave -> row block: block b runs on XCD b % 8 (observed; only speed depends on it): every XCD gets a CONTIGUOUS range
     // of row blocks (neighbouring row blocks read neighbouring partials of every piece, often the same 128-byte line)
@@ -637,18 +646,18 @@ __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restri
         if (wb >= nwb) break;
         const uint64_t j = (uint64_t)wb * WAVE + lane;
         const uint64_t jc = j < n_long ? j : n_long - 1;
-        const uint32_t r = ysum_out ? 0u : long_rows[jc];               // (requested early: needed only at the very end)
-        double s = init ? init[jc] : 0.0;
+        const uint32_t r = long_rows[jc];                               // (requested early: needed only at the very end)
+        double s = 0.0;
         const unsigned long long *mrow = wmask + (uint64_t)wb * np_pad;
         const uint32_t *brow = wbase + (uint64_t)wb * np_pad;
-        for (uint32_t k0 = k_begin; k0 < k_end; k0 += WAVE) {
-            const bool in = k0 + lane < k_end;
+        for (uint32_t k0 = 0; k0 < np_pad; k0 += WAVE) {
+            const bool in = k0 + lane < np_pad;
             const unsigned long long mk = in ? mrow[k0 + lane] : 0ull;   // lane l: the table row of piece k0 + l
             const uint32_t bs = in ? brow[k0 + lane] : 0u;
             const uint32_t mk_lo = (uint32_t)mk, mk_hi = (uint32_t)(mk >> 32);
 #pragma unroll
             for (int kk = 0; kk < WAVE; kk += RU) {
-                if (k0 + kk >= k_end) break;                             // wave-uniform
+                if (k0 + kk >= np_pad) break;                            // wave-uniform
                 double v[RU];
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
@@ -662,8 +671,7 @@ __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restri
             }
         }
         if (j < n_long) {
-            if (ysum_out) ysum_out[j] = s;
-            else if constexpr (ACC) y[r] = y[r] + s;
+            if constexpr (ACC) y[r] = y[r] + s;
             else y[r] = s;
         }
     }

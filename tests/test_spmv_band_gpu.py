@@ -26,10 +26,10 @@ def hip():
 
 
 class band_options:
-    def __init__(self, hip, hot, phases, rounds=0, split=0, tile=0, cold_tiles=0, hot_run=0, hot_cut=0):
+    def __init__(self, hip, hot, phases, rounds=0, split=0, tile=0, cold_tiles=0, hot_run=0, overlap=0, tail=0):
         self.hip, self.vals = hip, dict(spmv_band=1, spmv_band_hot=hot, spmv_band_phases=phases, spmv_band_rounds=rounds,
                                         spmv_band_split=split, spmv_band_tile=tile, spmv_band_cold_tiles=cold_tiles,
-                                        spmv_band_hot_run=hot_run, spmv_band_hot_cut=hot_cut)
+                                        spmv_band_hot_run=hot_run, spmv_band_overlap=overlap, spmv_band_tail=tail)
 
     def __enter__(self):
         for k, v in self.vals.items():
@@ -93,27 +93,30 @@ def test_hub_rows_and_many_segments(hip):
             check_band(hip, shape, ip, ix, dt, seed=rounds)
 
 
-def test_two_part_reduction(hip):
-    """many hot slices, the first 16 / 32 of them launched and reduced FIRST (their carries and their part of every row's
-    sum on a third stream while the second hot launch runs), the rest continuing the same chain of additions: the result
-    must equal the one-part run to rounding, and the oracle within tolerance"""
+def test_reduction_beside_the_short_rows(hip):
+    """the two streams forced on a small matrix: the reduction of the long rows starts when the hot slices and the cold
+    pieces are done and runs beside the short rows (whose carries follow them on the second stream) — the same additions in
+    the same order as with the whole second stream joined first (spmv_band_tail = 2) and as on one stream: bit-identical"""
     from sprs_amd.device import DeviceCsMat, DeviceVec
     rng = np.random.default_rng(21)
-    rows, cols = 1500, 300000
-    lens = rng.integers(30, 400, size=rows)
-    lens[::97] = 5000                                          # a few hub rows: runs that span ranges in the early slices
+    rows, cols = 6000, 300000
+    lens = rng.integers(1, 60, size=rows)
+    lens[::97] = 5000                                          # hub rows: runs that span ranges in the early slices
+    lens[5::7] = 2500                                          # short rows (below the split) that span several cold tiles: carries into y
     lens[3::50] = 0
     shape, ip, ix, dt = ragged_csr(list(lens), cols, seed=22)
     x = rng.random(cols) + 0.5
     out = {}
-    for cut in (-1, 16, 32):
-        with band_options(hip, 36, 1, tile=8192, hot_cut=cut, rounds=3, hot_run=2):
-            y = check_band(hip, shape, ip, ix, dt, seed=4)
+    for overlap, tail in ((2, 0), (1, 0), (1, 2)):
+        with band_options(hip, 12, 1, tile=8192, rounds=3, hot_run=2, split=3000, cold_tiles=1, overlap=overlap, tail=tail):
+            check_band(hip, shape, ip, ix, dt, seed=4)
             a = DeviceCsMat.from_host(shape, ip, ix, dt)
-            out[cut] = (a * DeviceVec.from_host(x)).to_host()
-    # (the two launches cut the slices into ranges of their own, so a row's sum inside a slice may be associated
-    # differently: equal to rounding, not bit for bit)
-    assert rel_err(out[16], out[-1]) <= 1e-13 and rel_err(out[32], out[-1]) <= 1e-13
+            xv = DeviceVec.from_host(x)
+            out[(overlap, tail)] = [(a * xv).to_host() for _ in range(3)]
+    first = out[(2, 0)][0]
+    for ys in out.values():
+        for y in ys:
+            assert np.array_equal(y, first)
 
 
 def test_split_and_empty_pieces(hip):
