@@ -527,16 +527,26 @@ int32_t sprs_hip_csmat_download_outer(const sprs_hip_csmat *m, uint64_t start, u
     return SPRS_HIP_OK;
 }
 
+// Everything a handle derives from its arrays: the SpMV / SpMM / Gauss-Seidel plans (they copy values), the copy in the other
+// storage order and the transpose view kept for dense . sparse products.  Called whenever the values (or the arrays) change:
+// refresh, free and BOTH numeric SpGEMM entries, which rewrite C's values in place (a stale CSC copy of C
+// would otherwise serve later products).
+static void invalidate_caches(sprs_hip_csmat *m) {
+    m->plan.release();
+    m->mm.release();
+    m->gs.release();
+    if (m->t_view) (void)sprs_hip_csmat_free(m->t_view);
+    m->t_view = nullptr;
+    if (m->as_other) (void)sprs_hip_csmat_free(m->as_other);
+    m->as_other = nullptr;
+}
+
 int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m) {
     clear_error();
     if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
     SPRS_TRY_HIP(hipDeviceSynchronize());     // nothing in flight may still read the plan copies
     std::lock_guard<std::recursive_mutex> lock(m->mu);
-    m->plan.release();
-    m->mm.release();
-    m->gs.release();
-    if (m->as_other) (void)sprs_hip_csmat_free(m->as_other);
-    m->as_other = nullptr;
+    invalidate_caches(m);
     return SPRS_HIP_OK;
 }
 
@@ -590,11 +600,7 @@ int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **
 int32_t sprs_hip_csmat_free(sprs_hip_csmat *m) {
     clear_error();
     if (!m) return SPRS_HIP_OK;
-    m->plan.release();
-    m->mm.release();
-    m->gs.release();
-    if (m->as_other) (void)sprs_hip_csmat_free(m->as_other);
-    m->as_other = nullptr;
+    invalidate_caches(m);
     if (m->owns) {
         if (m->indptr) (void)hipFree(m->indptr);
         pool_free(m->indices, m->cap_indices, m->device);
@@ -695,9 +701,8 @@ int32_t sprs_hip_spgemm_numeric(const sprs_hip_csmat *a, const sprs_hip_csmat *b
     SPRS_TRY(spgemm_contract(a, b));
     SPRS_TRY(numeric_target_ok(a, b, c));
     std::lock_guard<std::recursive_mutex> lock(c->mu);
-    c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
-    c->mm.release();
-    c->gs.release();                        // (the level order reads the structure only, but "has a diagonal" may change with it)
+    SPRS_TRY_HIP(hipDeviceSynchronize());   // nothing in flight may still read the copies that go away
+    invalidate_caches(c);                   // values are about to change: plans copy them, and so does the copy in the other storage order
     return spgemm_numeric(a, b, c);
 }
 
@@ -740,9 +745,8 @@ int32_t sprs_hip_spgemm_plan_numeric(sprs_hip_spgemm_plan *plan, const sprs_hip_
     if (!plan || !a || !b || !c) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
     SPRS_TRY(numeric_target_ok(a, b, c));
     std::lock_guard<std::recursive_mutex> lock(c->mu);
-    c->plan.release();                      // values are about to change: cached SpMV / SpMM plans copy them
-    c->mm.release();
-    c->gs.release();                        // (the level order reads the structure only, but "has a diagonal" may change with it)
+    SPRS_TRY_HIP(hipDeviceSynchronize());   // nothing in flight may still read the copies that go away
+    invalidate_caches(c);                   // values are about to change: plans copy them, and so does the copy in the other storage order
     return spgemm_plan_numeric(plan, a, b, c);
 }
 
@@ -960,6 +964,11 @@ int32_t sprs_hip_csmat_mulacc_dense_f64(const sprs_hip_csmat *lhs, const double 
     if (ld_rhs < (rhs_layout == SPRS_HIP_ROW_MAJOR ? k : rhs_rows) || ld_out < (out_layout == SPRS_HIP_ROW_MAJOR ? k : out_rows))
         SPRS_FAIL(SPRS_HIP_INVALID_ARG, "leading dimension smaller than the extent it strides over");
     if (k && ((rhs_rows && !rhs_dev) || (out_rows && !out_dev))) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL matrix");
+    if (k && rhs_rows && out_rows) {   // the spans the two operands stride over must not meet (as vec_args_ok for the vectors)
+        const uint64_t span_r = (rhs_layout == SPRS_HIP_ROW_MAJOR ? rhs_rows - 1 : k - 1) * ld_rhs + (rhs_layout == SPRS_HIP_ROW_MAJOR ? k : rhs_rows);
+        const uint64_t span_o = (out_layout == SPRS_HIP_ROW_MAJOR ? out_rows - 1 : k - 1) * ld_out + (out_layout == SPRS_HIP_ROW_MAJOR ? k : out_rows);
+        if (rhs_dev < out_dev + span_o && out_dev < rhs_dev + span_r) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "the result matrix overlaps the right-hand side");
+    }
     sprs_hip_csmat *csr = nullptr;
     SPRS_TRY(csr_form(lhs, &csr));
     hipStream_t st = (hipStream_t)stream;
@@ -999,18 +1008,18 @@ int32_t sprs_hip_dense_dot_csmat_f64(const double *lhs_dev, uint64_t lhs_rows, u
         SPRS_TRY(other_form(rhs, &csc));
         src = csc;
     }
+    // the view stays in the rhs handle (beside as_other): its tile / band plans are built once, not per call
     sprs_hip_csmat *rt = nullptr;
-    SPRS_TRY(sprs_hip_csmat_transpose_view(src, &rt));
+    {
+        sprs_hip_csmat *owner = const_cast<sprs_hip_csmat *>(rhs);
+        std::lock_guard<std::recursive_mutex> lock(owner->mu);
+        if (!owner->t_view) SPRS_TRY(sprs_hip_csmat_transpose_view(src, &owner->t_view));
+        rt = owner->t_view;
+    }
     int32_t lay_t = 0;
     // lhs^T: lhs_cols x lhs_rows, the other layout over the same memory
     const int32_t st = sprs_hip_csmat_mul_dense_f64(rt, lhs_dev, lhs_cols, lhs_rows, lhs_layout == SPRS_HIP_ROW_MAJOR ? SPRS_HIP_COL_MAJOR : SPRS_HIP_ROW_MAJOR,
                                                     ld_lhs, out_dev, &lay_t, stream);
-    if (st == SPRS_HIP_OK) {
-        // the kernels read the chunk plan cached in the view: wait before the view goes
-        const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
-        if (e != hipSuccess) { (void)sprs_hip_csmat_free(rt); return fail_hip(e, "dense . sparse"); }
-    }
-    (void)sprs_hip_csmat_free(rt);
     if (st != SPRS_HIP_OK) return st;
     *out_layout = lay_t == SPRS_HIP_ROW_MAJOR ? SPRS_HIP_COL_MAJOR : SPRS_HIP_ROW_MAJOR;     // reversed_axes()
     return SPRS_HIP_OK;

@@ -204,6 +204,7 @@ struct sprs_hip_csmat {
     sprs_hip::SpmvPlan plan;
     sprs_hip::SpmmPlan mm;
     sprs_hip::GsPlan gs;
+    sprs_hip_csmat *t_view = nullptr;    // transpose view (of the CSC form) kept for dense . sparse products (sprs_hip_dense_dot_csmat_f64): its SpMM / SpMV plans live as long as the values do; dropped with as_other
     sprs_hip_csmat *as_other = nullptr;  // the handle in the OTHER storage order (to_other_storage, csmat.rs:1405-1426): made by the first product that needs it (a CSC operand of a dense product / SpMV runs on its CSR form), dropped by refresh / free
 
     uint64_t outer() const { return storage == SPRS_HIP_CSR ? rows : cols; }

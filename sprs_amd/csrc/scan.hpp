@@ -63,14 +63,21 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
     }
     return v;
 #else
-    int x = (int)v;
-    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));     // row_shr:1 (zeros shifted in)
-    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));     // row_shr:2
-    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));     // row_shr:4
-    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));     // row_shr:8
-    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));    // row_bcast:15 into rows 1 and 3
-    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));    // row_bcast:31 into rows 2 and 3
-    return (uint32_t)x;
+    // UNSIGNED max (v_max_u32): a mark of 2^31 or more — a gap of that many rows inside one SpMM tile — stays the largest
+    uint32_t x = v;
+#define SPRS_MAX_STEP(CTRL, MASK, BOUND)                                                                  \
+    {                                                                                                     \
+        const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, MASK, 0xf, BOUND);     \
+        x = o_ > x ? o_ : x;                                                                              \
+    }
+    SPRS_MAX_STEP(0x111, 0xf, true)      // row_shr:1 (zeros shifted in)
+    SPRS_MAX_STEP(0x112, 0xf, true)      // row_shr:2
+    SPRS_MAX_STEP(0x114, 0xf, true)      // row_shr:4
+    SPRS_MAX_STEP(0x118, 0xf, true)      // row_shr:8
+    SPRS_MAX_STEP(0x142, 0xa, false)     // row_bcast:15 into rows 1 and 3
+    SPRS_MAX_STEP(0x143, 0xc, false)     // row_bcast:31 into rows 2 and 3
+#undef SPRS_MAX_STEP
+    return x;
 #endif
 }
 

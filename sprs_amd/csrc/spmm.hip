@@ -619,7 +619,18 @@ int32_t spmm_impl(sprs_hip_csmat *a, const double *rhs, uint64_t k, uint64_t ld_
     std::lock_guard<std::recursive_mutex> lock(a->mu);   // held until the kernels that read the plan are launched
     const uint64_t want_long = options().spmm_long_row >= 0 ? (uint64_t)options().spmm_long_row : LONG_ROW;
     // the entry stream keeps 32-bit column ids in LDS; the lane-group mode (reference bits for short rows) has its own kernels
-    const bool stream_mode = options().spmm_stream != 0 && want_long == 0 && a->cols <= 0xffffffffull && a->nnz != 0;
+    // (and 32-bit row distances inside a tile)
+    const bool stream_mode = options().spmm_stream != 0 && want_long == 0 && a->cols <= 0xffffffffull && a->rows <= 0xffffffffull && a->nnz != 0;
+    // a hypersparse matrix in the operator form: the tile that meets a run of empty rows zeroes them one wave per run, column by
+    // column — with many more rows than entries that is a cliff.  The result is cleared in one piece instead and
+    // the accumulate kernels run on it: +0.0 + products, the same bits as starting from zero.
+    if (!acc && stream_mode && a->rows > 4 * a->nnz + 4096 && k && (cs_out == 1 || ld_out == 1)) {
+        if (cs_out == 1 && ld_out == k) SPRS_TRY_HIP(hipMemsetAsync(out, 0, a->rows * k * sizeof(double), stream));
+        else if (ld_out == 1 && cs_out == a->rows) SPRS_TRY_HIP(hipMemsetAsync(out, 0, a->rows * k * sizeof(double), stream));
+        else if (cs_out == 1) SPRS_TRY_HIP(hipMemset2DAsync(out, ld_out * sizeof(double), 0, k * sizeof(double), a->rows, stream));
+        else SPRS_TRY_HIP(hipMemset2DAsync(out, cs_out * sizeof(double), 0, a->rows * sizeof(double), k, stream));
+        acc = true;
+    }
     {
         if (!a->mm.built || a->mm.long_row != want_long || a->mm.stream != stream_mode) SPRS_TRY(build_spmm_plan<PTR>(a, stream_mode, stream));
         SpmmPlan &pl = a->mm;

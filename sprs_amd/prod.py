@@ -57,9 +57,14 @@ class DeviceMat:
         return self.rows if self.col_major else self.cols
 
 
+def _dims(lhs, rhs, out):
+    """the three dimension asserts of the four dense kernels come FIRST, the storage assert last (prod.rs:199-202, 228-231,
+    256-259, 284-288): with both wrong every mirror reports the dimensions"""
+    if rhs.cols != out.cols or lhs.cols() != rhs.rows or lhs.rows() != out.rows:
+        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
+
+
 def _mulacc_dense(lhs, rhs, out, stream):
-    if rhs.cols != out.cols:
-        raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")          # prod.rs:201, 230, 259, 287
     check(lib.sprs_hip_csmat_mulacc_dense_f64(lhs._h, C.c_void_p(rhs.vec.ptr), rhs.rows, rhs.cols, rhs.layout, rhs.ld,
                                               C.c_void_p(out.vec.ptr), out.rows, out.layout, out.ld, 1, _stream_ptr(stream)))
 
@@ -71,6 +76,7 @@ def _storage(lhs, want_csr):
 
 def csr_mulacc_dense_rowmaj(lhs, rhs, out, stream=None):
     """prod::csr_mulacc_dense_rowmaj (prod.rs:189-214): out += lhs * rhs."""
+    _dims(lhs, rhs, out)
     _storage(lhs, True)
     _mulacc_dense(lhs, rhs, out, stream)
 
@@ -79,13 +85,15 @@ def csr_mulacc_dense_colmaj(lhs, rhs, out, stream=None):
     """prod::csr_mulacc_dense_colmaj (prod.rs:274-298): out += lhs * rhs (the reference walks the rhs column by column; the
     device entry is told by the operands' layouts how to address them).  rhs / out: DeviceMat, or two equally long lists of
     column vectors (out[:, j] += lhs * rhs[:, j])."""
-    _storage(lhs, True)
     if isinstance(rhs, (list, tuple)):
-        if len(rhs) != len(out):
+        if len(rhs) != len(out) or any(lhs.cols() != r.n or lhs.rows() != o.n for r, o in zip(rhs, out)):
             raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")
+        _storage(lhs, True)
         for r, o in zip(rhs, out):
             mul_acc_mat_vec_csr(lhs, r, o, stream)
         return
+    _dims(lhs, rhs, out)
+    _storage(lhs, True)
     _mulacc_dense(lhs, rhs, out, stream)
 
 
@@ -93,19 +101,22 @@ def csc_mulacc_dense_rowmaj(lhs, rhs, out, stream=None):
     """prod::csc_mulacc_dense_rowmaj (prod.rs:219-241): out += lhs * rhs for a CSC lhs.  The reference walks the columns of
     lhs in order and adds `lval * rhs[col, :]` into out[row, :], so every out[i, j] receives its products by ascending column —
     the order the CSR kernel uses on the converted matrix (cached in the handle, below the C ABI)."""
+    _dims(lhs, rhs, out)
     _storage(lhs, False)
     _mulacc_dense(lhs, rhs, out, stream)
 
 
 def csc_mulacc_dense_colmaj(lhs, rhs, out, stream=None):
     """prod::csc_mulacc_dense_colmaj (prod.rs:246-270); rhs / out as in csr_mulacc_dense_colmaj."""
-    _storage(lhs, False)
     if isinstance(rhs, (list, tuple)):
-        if len(rhs) != len(out):
-            raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")      # prod.rs:257
+        if len(rhs) != len(out) or any(lhs.cols() != r.n or lhs.rows() != o.n for r, o in zip(rhs, out)):
+            raise _ffi.SprsHipError(_ffi.DIM_MISMATCH, "Dimension mismatch")      # prod.rs:256-257
+        _storage(lhs, False)
         for r, o in zip(rhs, out):
             mul_acc_mat_vec_csc(lhs, r, o, stream)
         return
+    _dims(lhs, rhs, out)
+    _storage(lhs, False)
     _mulacc_dense(lhs, rhs, out, stream)
 
 

@@ -36,6 +36,94 @@ def test_rust_sys_crate_declares_the_same_symbols():
         assert used in rs, used
 
 
+# ---- type-level drift guard: the Rust crates are never compiled here, so the only "compiler" their
+# extern block ever sees is this comparison with the C header, argument by argument -------------------------------------------
+_C_SCALARS = {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "double": "f64", "float": "f32",
+              "char": "c_char", "void": "c_void", "int": "i32", "size_t": "usize", "uint8_t": "u8", "uint16_t": "u16"}
+
+
+def _canon_c(decl):
+    """'const sprs_hip_csmat *a' / 'uint64_t n' / 'sprs_hip_csmat **out' -> the Rust spelling of the type (name dropped)"""
+    decl = decl.strip()
+    stars = decl.count("*")
+    words = [w for w in re.sub(r"[*]", " ", decl).split() if w not in ("struct",)]
+    const = "const" in words
+    words = [w for w in words if w != "const"]
+    base = words[0]
+    base = _C_SCALARS.get(base, base)                                 # opaque handles and info structs keep their names
+    t = base
+    for level in range(stars):
+        # `const T *`: pointer to const; deeper levels (T **out) are *mut *mut in the crate: only the innermost level of a
+        # const-qualified base is const
+        t = ("*const " if (const and level == 0) else "*mut ") + t
+    return t
+
+
+def c_prototypes():
+    src = open(os.path.join(ROOT, "include", "sprs_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][A-Za-z0-9_ ]*?[ *]+)\b(sprs_hip_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        args = args.strip()
+        alist = [] if args in ("", "void") else [_canon_c(a) for a in args.split(",")]
+        protos[name] = (_canon_c(ret + " r") if ret.strip() != "void" else "()", alist)
+    return protos
+
+
+def rust_prototypes():
+    rs = open(os.path.join(ROOT, "rust", "sprs-hip-sys", "src", "lib.rs")).read()
+    rs = re.sub(r"//[^\n]*", "", rs)
+    protos = {}
+    for name, args, ret in re.findall(r"pub fn (sprs_hip_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", rs):
+        alist = []
+        for a in [x.strip() for x in args.split(",") if x.strip()]:
+            alist.append(re.sub(r"\s+", " ", a.split(":", 1)[1].strip()))
+        protos[name] = (re.sub(r"\s+", " ", ret.strip()) if ret else "()", alist)
+    return protos
+
+
+def test_rust_sys_crate_matches_the_header_type_by_type():
+    c, r = c_prototypes(), rust_prototypes()
+    assert sorted(c) == declared_symbols() and sorted(r) == sorted(c)
+    for name in sorted(c):
+        assert len(c[name][1]) == len(r[name][1]), "%s: %d arguments in the header, %d in rust/sprs-hip-sys" % (name, len(c[name][1]), len(r[name][1]))
+        assert c[name][0] == r[name][0], "%s: returns %s in the header, %s in the crate" % (name, c[name][0], r[name][0])
+        for i, (ct, rt) in enumerate(zip(c[name][1], r[name][1])):
+            assert ct == rt, "%s, argument %d: header says %s, crate says %s" % (name, i, ct, rt)
+
+
+def test_ctypes_binding_matches_the_header_type_by_type():
+    """the same for sprs_amd/_ffi.py: arity, integer / float widths, pointer-ness (ctypes has one void pointer for every handle)"""
+    from sprs_amd import _ffi
+    c = c_prototypes()
+
+    def klass(t):
+        if t.startswith("*"):
+            return "ptr"
+        return {"c_char": "i8"}.get(t, t)
+
+    def klass_ct(t):
+        if t is None:
+            return "()"
+        if t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or (hasattr(t, "_type_") and not isinstance(t._type_, str)):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_uint32: "u32", C.c_int64: "i64", C.c_uint64: "u64", C.c_double: "f64"}[t]
+
+    for name, (res, args) in _ffi.SIGNATURES.items():
+        assert len(args) == len(c[name][1]), "%s: %d arguments in the header, %d in _ffi.py" % (name, len(c[name][1]), len(args))
+        assert klass(c[name][0]) == klass_ct(res), name
+        for i, (ct, at) in enumerate(zip(c[name][1], args)):
+            assert klass(ct) == klass_ct(at), "%s, argument %d: header says %s, _ffi.py says %s" % (name, i, ct, at)
+
+
+def test_type_guard_catches_a_wrong_width():
+    """the guard itself: a u32 where the header says uint64_t, a *mut where it says const, a missing argument"""
+    assert _canon_c("const double *x_dev") == "*const f64" and _canon_c("sprs_hip_csmat **out") == "*mut *mut sprs_hip_csmat"
+    assert _canon_c("uint64_t n") == "u64" and _canon_c("void *stream") == "*mut c_void" and _canon_c("const void *p") == "*const c_void"
+    assert _canon_c("const sprs_hip_csmat *a") == "*const sprs_hip_csmat" and _canon_c("const char *name") == "*const c_char"
+
+
 def test_status_codes_match_header():
     from sprs_amd import _ffi
     src = open(os.path.join(ROOT, "include", "sprs_hip.h")).read()

@@ -578,6 +578,44 @@ def test_kept_plan_symbolic_numeric_split(hip, idx, ptr):
     assert e.value.status == hip._ffi.BAD_STRUCTURE
 
 
+def test_numeric_drops_every_cached_copy_of_c(hip):
+    """sprs_hip_spgemm_numeric / _plan_numeric rewrite C's values in place.  A dense . sparse product had left
+    a CSC copy of C (and a transpose view with its plans) in the handle: after the numeric call those must be rebuilt from the
+    new values, for both entries, and the repeated dense . sparse product reuses ONE view."""
+    from sprs_amd import gen, prod, smmp
+    from sprs_amd.device import DeviceCsMat
+    from sprs_amd.prod import DeviceMat
+    n, k = 3000, 5
+    indptr, indices, data = gen.rmat_csr(n, 6, seed=31)
+    ip, ix, dt = indptr.numpy().astype(np.uint64), indices.numpy().astype(np.uint64), data.numpy()
+    a = DeviceCsMat.from_host((n, n), ip, ix, dt)
+    a2 = DeviceCsMat.from_host((n, n), ip, ix, dt * 2.0 + 0.25)
+    rng = np.random.default_rng(5)
+    lhs = rng.random((k, n)) + 0.5
+    dl = DeviceMat.from_host(lhs)
+
+    def dense_of(c):
+        sh, cip, cix, cdt = c.to_host()
+        m = np.zeros(sh)
+        for r in range(sh[0]):
+            m[r, cix[cip[r]:cip[r + 1]].astype(np.int64)] = cdt[cip[r]:cip[r + 1]]
+        return m
+
+    c = a * a
+    first = prod.dense_dot_csmat(dl, c).to_host()
+    assert np.allclose(first, lhs @ dense_of(c), rtol=1e-10, atol=0)
+    again = prod.dense_dot_csmat(dl, c).to_host()                # the kept view and its plans
+    assert np.array_equal(first, again)
+    smmp.numeric(a2, a2, c)                                      # same structure, new values, in place
+    want = lhs @ dense_of(c)
+    got = prod.dense_dot_csmat(dl, c).to_host()
+    assert np.allclose(got, want, rtol=1e-10, atol=0) and not np.allclose(got, first, rtol=1e-6, atol=0)
+    plan = smmp.SpgemmPlan(a, a)
+    plan.numeric(c)                                              # back to the first values through the kept plan
+    back = prod.dense_dot_csmat(dl, c).to_host()
+    assert np.array_equal(back, first)
+
+
 def plan_for_other(hip, plan, a2, c):
     import ctypes as C
     from sprs_amd._ffi import check, lib

@@ -242,6 +242,42 @@ def test_ragged_and_contract(hip, golden):
     csc = DeviceCsMat.from_host(shape, ip, ix, dt, storage=_ffi.CSC)
     with pytest.raises(SprsHipError, match="Storage mismatch"):             # prod.rs:202
         prod.csr_mulacc_dense_rowmaj(csc, prod.DeviceMat(5, 2), prod.DeviceMat(5, 2))
+    # both wrong: the reference asserts the dimensions first and the storage last (prod.rs:199-202), and so does every mirror
+    with pytest.raises(SprsHipError, match="Dimension mismatch"):
+        prod.csr_mulacc_dense_rowmaj(csc, prod.DeviceMat(4, 2), prod.DeviceMat(5, 2))
+    with pytest.raises(SprsHipError, match="Dimension mismatch"):
+        prod.csc_mulacc_dense_colmaj(m, prod.DeviceMat(3, 2), prod.DeviceMat(5, 2))
+    # a result that lies inside the right-hand side is refused (as for the vectors of the SpMV entries)
+    sq = DeviceCsMat.eye(6)
+    buf = prod.DeviceMat(6, 4)
+    with pytest.raises(SprsHipError) as e:
+        prod.csr_mulacc_dense_rowmaj(sq, buf, buf)
+    assert e.value.status == _ffi.INVALID_ARG
+
+
+def test_hypersparse_operator_form(hip):
+    """many more rows than entries: the operator form clears the result in one piece and runs the accumulate
+    kernels on it — same values, every empty row +0.0 — for both result layouts (row-major from 8 columns, `.f()` below), a
+    row-major and a column-major rhs, and rows at both ends of the matrix empty"""
+    from sprs_amd import prod
+    from sprs_amd.device import DeviceCsMat
+    rng = np.random.default_rng(41)
+    rows, cols, nnz = 300000, 5000, 700
+    r = np.sort(rng.choice(np.arange(100, rows - 100), size=nnz // 2, replace=False))
+    lens = np.zeros(rows, dtype=np.int64)
+    lens[r] = rng.integers(1, 4, size=r.size)
+    ip = np.zeros(rows + 1, dtype=np.uint64)
+    ip[1:] = np.cumsum(lens)
+    ix = np.concatenate([np.sort(rng.choice(cols, size=l, replace=False)) for l in lens[r]]).astype(np.uint64)
+    dt = rng.standard_normal(ix.size)
+    a = DeviceCsMat.from_host((rows, cols), ip, ix, dt)
+    for k in (3, 16):
+        rhs = rng.standard_normal((cols, k))
+        ref = oracle_spmm((rows, cols), ip, ix, dt, rhs)
+        for col_major in (False, True):
+            out = (a * prod.DeviceMat.from_host(rhs, col_major=col_major)).to_host()
+            assert rel_err(out, ref) <= TOL
+            assert not out[lens == 0].any() and not np.signbit(out[lens == 0]).any()
 
 
 def test_dense_dispatch_below_the_abi(hip):
