@@ -232,6 +232,13 @@ def main():
                     help="N > 1: all-gather-v of y inside the library (sprs_hip_dist_*: sub-block pipeline, RCCL loaded by the "
                          "library itself; default, what `value` times) or through torch.distributed (grouped send/recv on RCCL); "
                          "the other route and the multiply without any exchange are timed after the K steps and reported beside it")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="N > 1: torch.distributed backend.  nccl = RCCL over xGMI (the product path).  gloo: the y blocks are staged "
+                         "through host memory — for running the N > 1 code path (self-launch, partition, RowShardedSpMV on the HIP "
+                         "kernels, route agreement, JSON keys) where RCCL cannot come up, e.g. N ranks on ONE GPU with --devices 0,0; the "
+                         "library's own RCCL route is not attempted then and the line says so")
+    ap.add_argument("--devices", default="",
+                    help="N > 1: comma-separated device of every local rank (default: rank i on device i); ranks may share a device with --backend gloo")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the short spgemm5 object")
     ap.add_argument("--permute-cols", type=int, default=0,
                     help="experiment: relabel the columns by a random permutation (seed given) before the run")
@@ -266,12 +273,25 @@ def main():
     args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank
+    if args.devices:
+        devs = [int(v) for v in args.devices.split(",")]
+        if len(devs) != world:
+            sys.exit("--devices names %d devices for %d ranks" % (len(devs), world))
+        if len(set(devs)) != len(devs) and args.backend == "nccl":
+            sys.exit("ranks sharing a device need --backend gloo (RCCL refuses duplicate devices)")
+        dev_index = devs[local_rank]
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # small control tensors of the collectives: on the device for RCCL, on the host for gloo
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import sprs_amd
     from sprs_amd import gen, prod
@@ -279,7 +299,7 @@ def main():
     from sprs_amd.dist import RowShardedSpMV
     from sprs_amd import _ffi
     import ctypes as C
-    _ffi.check(_ffi.lib.sprs_hip_set_device(local_rank))
+    _ffi.check(_ffi.lib.sprs_hip_set_device(dev_index))
     for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_relabel", args.relabel), ("spmv_lds_pad", args.ldspad), ("spmv_band", args.band)):
         if val is not None:
             sprs_amd.set_option(opt, val)
@@ -379,7 +399,11 @@ def main():
         return sh.y
 
     step = torch_step
-    if world > 1:
+    if world > 1 and args.backend != "nccl":
+        if args.exchange == "lib" and rank == 0:
+            print("bench.py: --backend gloo: the library's RCCL exchange is not attempted; timing the torch.distributed route "
+                  "(y blocks staged through host memory)", file=sys.stderr)
+    elif world > 1:
         try:
             from sprs_amd.dist import DistSpMV
             rb = sh.block
@@ -401,7 +425,7 @@ def main():
         # gives what one step through torch.distributed gives (the two exchanges move the same blocks; the multiply is the same
         # kernel) — otherwise all ranks time the torch route together and the line says so
         import torch.distributed as dist
-        flag = torch.tensor([1.0 if libdist is not None else 0.0], dtype=torch.float64, device=dev)
+        flag = torch.tensor([1.0 if libdist is not None else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if float(flag.item()) < 0.5:
             libdist = None
@@ -432,11 +456,18 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    # plan policy (include/sprs_hip.h, sprs_hip_csmat_prepare): the FIRST multiply of a handle runs on the plain tile index over its own
+    # arrays, the re-laid-out copy (banded plan) is built by the SECOND — both are timed here, outside the timed region
     torch.cuda.synchronize()
     t_plan = time.perf_counter()
-    step(x)                                             # the first multiply builds the plan cached in the handle
+    step(x)
     torch.cuda.synchronize()
     first_step_s = time.perf_counter() - t_plan
+    first_plan = handles[id(sh.block)].spmv_plan_info() if handles else (0, 0)
+    t_plan = time.perf_counter()
+    step(x)                                             # the second multiply builds the copy plan cached in the handle
+    torch.cuda.synchronize()
+    second_step_s = time.perf_counter() - t_plan
     for _ in range(args.warmup):
         step(x)
     torch.cuda.synchronize()
@@ -464,7 +495,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([t_total], dtype=torch.float64, device=dev)
+        tt = torch.tensor([t_total], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_total = float(tt.item())
     kern_ms = [a.elapsed_time(b) for a, b in ev]
@@ -483,11 +514,12 @@ def main():
                 fn(x)
             torch.cuda.synchronize()
             barrier()
-            tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+            tt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return round(float(tt.item()) * 1e3 / k, 5)
         k2 = max(3, args.steps // 2)
-        exchange_times = {"timed_route": "lib" if use_lib else "torch", "steps_each": k2}
+        exchange_times = {"timed_route": "lib" if use_lib else "torch", "steps_each": k2, "backend": args.backend,
+                          "devices": args.devices or ",".join(str(i) for i in range(world))}
         if libdist is not None:
             try:
                 exchange_times["rccl_comm_ranks"] = libdist.comm_count()     # what the communicator itself says (ncclCommCount)
@@ -546,11 +578,16 @@ def main():
             "rows": n, "cols": n, "nnz": nnz_total,
             "index_bytes": args.idx_bytes, "indptr_bytes": args.idx_bytes,
             "partition": ("cost-balanced (nnz + 8/row) contiguous row blocks x%d, direct all-gather-v of y (%s)" %
-                          (world, "sprs_hip_dist_*, RCCL inside the library" if use_lib else "torch.distributed grouped send/recv on RCCL"))
+                          (world, "sprs_hip_dist_*, RCCL inside the library" if use_lib else
+                           "torch.distributed grouped send/recv on RCCL" if args.backend == "nccl" else "torch.distributed send/recv on gloo, staged through host memory"))
                          if world > 1 else "single GPU",
             "generate_s": round(gen_s, 2),
             # once per handle, never part of `value`: the first multiply (plan build + one SpMV) minus a steady-state step
-            "plan_build_s": round(max(0.0, first_step_s - ms_per_step * 1e-3), 4),
+            "plan_build_s": round(max(0.0, second_step_s - ms_per_step * 1e-3), 4),
+            # the handle's FIRST multiply (plain tile index over the handle's own arrays + one SpMV on it): what a caller that
+            # multiplies once pays instead of plan_build_s
+            "first_spmv_ms": round(first_step_s * 1e3, 3),
+            "first_spmv_plan": {0: "none", 1: "nnz tiles", 2: "xcd-sliced copy", 3: "banded copy"}.get(first_plan[0], "?"),
         },
         "roofline": {
             "bound": "hbm",
@@ -574,6 +611,37 @@ def main():
         if routes_check is not None:
             exchange_times["routes_agree"] = routes_check
         out["exchange"] = exchange_times
+
+    # ---- N > 1: parity of the distributed result (every rank checks ITS row block against the oracle on that block, and that the
+    # gathered y is the same vector on every rank) — the checker only, after the timed region ------------------------------------
+    if world > 1 and not args.no_cpu_baseline:
+        import torch.distributed as dist
+        try:
+            from oracle import oracle   # test infrastructure: the checker, never the product
+            npdt = np.uint64 if args.idx_bytes == 8 else np.uint32
+            step(x)
+            torch.cuda.synchronize()
+            y_all = sh.y.cpu().numpy()
+            yb = np.zeros(sh.block[0])
+            oracle.mul_acc_mat_vec_csr((sh.block[0], n), sh.block[2].cpu().numpy().view(npdt), sh.block[3].cpu().numpy().view(npdt),
+                                       sh.block[4].cpu().numpy(), x.cpu().numpy(), yb)
+            got = y_all[sh.r0:sh.r1]
+            den = np.maximum(np.abs(yb), np.abs(got))
+            rel = float(np.max(np.where(den > 0, np.abs(got - yb) / np.where(den > 0, den, 1.0), 0.0))) if den.size else 0.0
+            chk = float(np.sum(y_all * (1.0 + (np.arange(n) % 7))))        # position-weighted checksum of the gathered vector
+        except Exception as e:
+            if rank == 0:
+                print("bench.py: parity of the distributed result failed to run (%s)" % repr(e)[:200], file=sys.stderr)
+            rel, chk = float("inf"), float(rank)
+        t_rel = torch.tensor([rel], dtype=torch.float64, device=cdev)
+        t_lo, t_hi = torch.tensor([chk], dtype=torch.float64, device=cdev), torch.tensor([chk], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t_rel, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(t_hi, op=dist.ReduceOp.MAX)
+        same = bool(float(t_lo.item()) == float(t_hi.item()))
+        out["parity"] = {"max_rel_err_vs_oracle": float(t_rel.item()), "tolerance": 1e-10, "what": "every rank: its row block of y against the oracle on "
+                         "that block (max over ranks); gathered_y_identical: the position-weighted checksum of the whole y is the same double on every rank",
+                         "gathered_y_identical": same, "ok": bool(float(t_rel.item()) <= 1e-10 and same)}
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on the host cores -------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -653,7 +721,11 @@ def main():
             out["spmv_u32"] = {"workload": name + ", u32 indices and indptr", "nnz": nnz4, "steps": k4, "kernel_ms_avg": round(ms4, 5),
                                "gflops": round(2.0 * nnz4 / (ms4 * 1e-3) / 1e9, 2), "algorithmic_bytes_per_launch": b4,
                                "achieved_GBs": round(b4 / (ms4 * 1e-3) / 1e9, 2), "frac": round(b4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "plan_bytes": pb4}
+                               "plan_bytes": pb4,
+                               "note": "the banded plan stores its own 16-bit / 32-bit ids whatever the handle's index width, so a u32 handle streams "
+                                       "the SAME %.2f GB plan as the usize handle and takes the same time; `frac` here prices that time against the "
+                                       "smaller 12 B/entry CSR formula, which is why it reads lower than the headline — the narrower indices save "
+                                       "device memory for the handle (1.3 GB) and upload time, not SpMV time" % (pb4 / 1e9)}
             del a4, ip4, ix4, dt4, y4
             torch.cuda.empty_cache()
         except Exception as e:   # the headline line must not depend on the secondary measurement
@@ -688,7 +760,25 @@ def main():
                 prod.csmat_mul_vec(a8, DeviceVec.borrow(x0), out=DeviceVec.borrow(y0), stream=stream)
                 torch.cuda.synchronize()
                 err = float(((res.view(n, kk)[:, 0] - y0).abs() / y0.abs().clamp_min(1e-300)).max())
-                out["spmm"]["k"][str(kk)] = {"kernel_ms_avg": round(msk, 4), "gflops": round(2.0 * nnz_total * kk / (msk * 1e-3) / 1e9, 1),
+                # ... and a row sample of TWO columns against the oracle itself (the checker; SpMM == SpMV per rhs column, prod.rs:274-298)
+                orc = None
+                if not args.no_cpu_baseline and "ip_h" in locals():
+                    from oracle import oracle   # test infrastructure: the checker, never the product
+                    worst, checked = 0.0, 0
+                    for r_lo in (0, n // 2, n - 60000):
+                        r_hi = r_lo + 60000
+                        lo_, hi_ = int(ip_h[r_lo]), int(ip_h[r_hi])
+                        ipb = (ip_h[r_lo:r_hi + 1] - ip_h[r_lo]).astype(ip_h.dtype)
+                        for col in (0, kk - 1):
+                            xc = rhs.view(n, kk)[:, col].contiguous().cpu().numpy()
+                            yb = np.zeros(r_hi - r_lo)
+                            oracle.mul_acc_mat_vec_csr((r_hi - r_lo, n), ipb, ix_h[lo_:hi_], dt_h[lo_:hi_], xc, yb)
+                            got = res.view(n, kk)[r_lo:r_hi, col].cpu().numpy()
+                            den = np.maximum(np.abs(yb), np.abs(got))
+                            worst = max(worst, float(np.max(np.where(den > 0, np.abs(got - yb) / np.where(den > 0, den, 1.0), 0.0))))
+                        checked += r_hi - r_lo
+                    orc = {"rows_checked": checked, "columns_checked": [0, kk - 1], "max_rel_err": worst, "tolerance": 1e-10, "ok": bool(worst <= 1e-10)}
+                out["spmm"]["k"][str(kk)] = {"vs_oracle": orc,"kernel_ms_avg": round(msk, 4), "gflops": round(2.0 * nnz_total * kk / (msk * 1e-3) / 1e9, 1),
                                              "algorithmic_bytes_per_launch": algk, "achieved_GBs": round(algk / (msk * 1e-3) / 1e9, 1),
                                              "frac": round(algk / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                              "rhs_rows_gathered_per_s": round(nnz_total / (msk * 1e-3) / 1e9, 1),

@@ -134,6 +134,14 @@ int32_t sprs_hip_csmat_slice_outer(const sprs_hip_csmat *m, uint64_t start, uint
  * modifying the arrays of a WRAPPED handle in place (sprs_hip_csmat_wrap_device), call this to drop
  * the cached plans; they are rebuilt by the next multiply. */
 int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m);
+/* PLAN POLICY.  A handle's FIRST SpMV runs on the plain tile index over its own arrays (built in microseconds); the plans
+ * that re-lay the matrix out — the banded copy with the hot columns served from LDS, the XCD-sliced copy: ~0.1 s to build
+ * for a 3e8-entry matrix, i.e. about 80 SpMVs, and 0.7 x the matrix in extra HBM — are built by the SECOND SpMV of the
+ * handle, so a handle that multiplies once (`&a * &x` on a temporary) never pays for them.  A caller that knows it will
+ * iterate (a solver) calls this once after the upload: the full plan is built now, on `stream`, and the first SpMV already
+ * runs at the steady-state rate.  Idempotent; option spmv_plan_defer = 0 brings back "build at the first multiply".
+ * No counterpart in the reference (its CsMat has no derived state). */
+int32_t sprs_hip_csmat_prepare(sprs_hip_csmat *m, void *stream);
 /* What the SpMV plan cached in the handle looks like (after the first multiply; kind 0 before):
  * kind 1 = nnz tiles over the handle's own arrays, 2 = XCD-sliced copy (spmv.hip), 3 = banded copy
  * with the hot columns served from LDS (spmv_band.hip); plan_bytes = HBM the plan holds besides the

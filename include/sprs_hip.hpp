@@ -100,6 +100,8 @@ public:
     uint64_t nnz() const { return info().nnz; }
     bool is_csr() const { return info().storage == SPRS_HIP_CSR; }
     const sprs_hip_csmat *handle() const { return h_; }
+    // build the full SpMV plan now instead of at the handle's second multiply (sprs_hip_csmat_prepare): for callers that iterate
+    void prepare(void *stream = nullptr) { check(sprs_hip_csmat_prepare(h_, stream)); }
 
     // into_raw_storage (csmat.rs:946-954) for 8-byte handles
     void to_host(std::vector<uint64_t> &indptr, std::vector<uint64_t> &indices, std::vector<double> &data) const {

@@ -98,6 +98,7 @@ extern "C" {
     ) -> i32;
     pub fn sprs_hip_csmat_slice_outer(m: *const sprs_hip_csmat, start: u64, end: u64, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_csmat_refresh(m: *mut sprs_hip_csmat) -> i32;
+    pub fn sprs_hip_csmat_prepare(m: *mut sprs_hip_csmat, stream: *mut c_void) -> i32;
     pub fn sprs_hip_csmat_spmv_plan_info(m: *const sprs_hip_csmat, kind: *mut i32, plan_bytes: *mut u64) -> i32;
     pub fn sprs_hip_csmat_transpose_view(m: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_csmat_free(m: *mut sprs_hip_csmat) -> i32;

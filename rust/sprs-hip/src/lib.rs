@@ -92,6 +92,12 @@ impl DeviceCsMat {
         Self { h }
     }
 
+    /// Build the full SpMV plan now instead of at the handle's second multiply (`sprs_hip_csmat_prepare`): for callers that
+    /// iterate (a solver); a handle that multiplies once never pays for the re-laid-out copy.
+    pub fn prepare(&mut self) {
+        unsafe { check(sys::sprs_hip_csmat_prepare(self.h, std::ptr::null_mut())) };
+    }
+
     pub fn shape(&self) -> (usize, usize) {
         let (mut r, mut c) = (0u64, 0u64);
         unsafe { check(sys::sprs_hip_csmat_info(self.h, &mut r, &mut c, std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut(), std::ptr::null_mut())) };

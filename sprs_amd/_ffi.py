@@ -66,6 +66,7 @@ SIGNATURES = {
     "sprs_hip_csmat_download_outer": (i32, [vp, u64, u64, vp, vp, vp, P(u64)]),
     "sprs_hip_csmat_slice_outer": (i32, [vp, u64, u64, P(vp)]),
     "sprs_hip_csmat_refresh": (i32, [vp]),
+    "sprs_hip_csmat_prepare": (i32, [vp, vp]),
     "sprs_hip_csmat_spmv_plan_info": (i32, [vp, P(i32), P(u64)]),
     "sprs_hip_csmat_transpose_view": (i32, [vp, P(vp)]),
     "sprs_hip_csmat_free": (i32, [vp]),

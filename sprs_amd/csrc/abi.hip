@@ -919,6 +919,14 @@ static int32_t csr_form(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
     return other_form(m, out);
 }
 
+int32_t sprs_hip_csmat_prepare(sprs_hip_csmat *m, void *stream) {
+    clear_error();
+    if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    sprs_hip_csmat *csr = nullptr;
+    SPRS_TRY(csr_form(m, &csr));               // a CSC handle multiplies through its CSR copy: that is the handle to prepare
+    return spmv_prepare(csr, (hipStream_t)stream);
+}
+
 static int32_t vec_args_ok(const double *x_dev, uint64_t x_len, double *y_dev, uint64_t y_len) {
     if ((x_len && !x_dev) || (y_len && !y_dev)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL vector");
     if (x_len && y_len && x_dev < y_dev + y_len && y_dev < x_dev + x_len)

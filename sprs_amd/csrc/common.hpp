@@ -58,6 +58,7 @@ constexpr bool DEVTOOLS = false;
     X(spmv_tile, 0, 0, 4096, 0)         /* nnz per workgroup tile: 0 auto, 2048 or 4096 */                                        \
     X(spmv_lds_pad, 0, 0, 100000, 0)    /* extra dynamic LDS bytes per workgroup: caps workgroups per CU (tuning) */              \
     X(spmv_xmask, -1, INT64_MIN, INT64_MAX, 1) /* TIMING EXPERIMENTS ONLY: gather x[col & mask] (wrong results unless -1) */      \
+    X(spmv_plan_defer, 1, 0, 1, 0)      /* 1: a handle's FIRST multiply runs on the plain tile index; the re-laid-out copy plans (banded, XCD-sliced: ~0.1 s to build on a 3e8-entry matrix = 80 SpMVs) are built at the second one, or by sprs_hip_csmat_prepare; 0: at the first (rounds 1-4).  Forced plans (spmv_band = 1, spmv_xcs = 1) are never deferred */ \
     X(spmv_band, 0, 0, 2, 0)            /* banded plan (hot columns from LDS, spmv_band.hip): 0 auto (on), 1 on, 2 off */          \
     X(spmv_band_hot, 0, 0, 384, 0)      /* hot slices (0 = default 128) */                                                        \
     X(spmv_band_tile, 0, 0, 16384, 0)   /* labels per hot slice = doubles of the x tile in LDS: 8192 or 16384 (0 = default 16384) */ \
@@ -135,6 +136,7 @@ struct BandPlan;                   // spmv_band.hip
 
 struct SpmvPlan {
     bool built = false;
+    bool light = false;            // built as the plain tile index although a copy plan would apply (first multiply of the handle): rebuilt at the next one
     bool xcs = false;
     BandPlan *band = nullptr;      // banded plan: when set, nothing else below is used
     uint64_t opt_sig = 0;          // hash of the option values the plan was built with (plan_signature, spmv.hip)
@@ -197,6 +199,8 @@ struct sprs_hip_csmat {
     void *indices = nullptr;   // device, nnz entries
     double *data = nullptr;    // device, nnz entries
     bool owns = false;
+    uint64_t spmv_calls = 0;   // multiplies so far: the re-laid-out plan copies (banded / XCD-sliced) are built at the SECOND one (or by sprs_hip_csmat_prepare)
+    bool prepared = false;     // sprs_hip_csmat_prepare was called: the copy plans may be built at once
     bool one_shot = false;     // the handle multiplies once (sprs_hip_spmv_f64_host): plain plan, no copies of the matrix
     uint64_t cap_indices = 0, cap_data = 0;   // bytes of the owned blocks (>= what nnz needs: blocks come from the pool)
     int device = 0;
@@ -225,6 +229,7 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
 void band_free(BandPlan *bp);
 uint64_t band_plan_bytes(const BandPlan *bp);
 // spmv.hip
+int32_t spmv_prepare(sprs_hip_csmat *a, hipStream_t stream);   // builds the full SpMV plan now (sprs_hip_csmat_prepare)
 int32_t spmv_f64(sprs_hip_csmat *a, const double *x, double *y, bool accumulate, hipStream_t stream);
 // spgemm.hip
 int32_t spgemm_f64(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_csmat **c);

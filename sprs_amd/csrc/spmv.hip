@@ -580,13 +580,17 @@ static uint64_t plan_signature(const Options &o) {
     return h | 1ull;
 }
 
+// light: the handle's first multiply — a plan that COPIES the matrix (banded, XCD-sliced) is not built yet unless the options
+// force it; pl.light then says that the next multiply should come back here.  A handle that multiplies once (`&a * &x` on a
+// temporary) never pays the ~0.1 s of a copy plan; one that iterates pays it at its second multiply.
 template <typename IDX, typename PTR>
-static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
+static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream, bool light = false) {
     SpmvPlan &pl = a->plan;
     const Options &o = options();
     pl.release();
     pl.opt_sig = plan_signature(o);
     pl.idx_bytes = (int)sizeof(IDX);
+    pl.light = false;
     const uint64_t rows = a->rows, nnz = a->nnz;
     const PTR *ip = (const PTR *)a->indptr;
 
@@ -594,7 +598,13 @@ static int32_t build_plan(sprs_hip_csmat *a, hipStream_t stream) {
     bool want = !a->one_shot && (o.spmv_xcs == 1 || (o.spmv_xcs == 0 && a->cols * 8 >= (16ull << 20) && nnz >= (1ull << 22)));
     // the banded plan (spmv_band.hip) takes such matrices when it applies (its own test of the row lengths)
     // (it pays from smaller x on than the XCD-sliced plan: R-MAT 1M, x = 8 MB, cold caches: 0.101 vs 0.156 ms, profiles/r02p)
-    const bool want_band = !a->one_shot && (o.spmv_band == 1 || (o.spmv_band == 0 && o.spmv_xcs != 2 && a->cols * 8 >= (4ull << 20) && nnz >= (1ull << 22)));
+    bool want_band = !a->one_shot && (o.spmv_band == 1 || (o.spmv_band == 0 && o.spmv_xcs != 2 && a->cols * 8 >= (4ull << 20) && nnz >= (1ull << 22)));
+    if (light) {
+        const bool auto_band = want_band && o.spmv_band != 1, auto_xcs = want && o.spmv_xcs != 1;
+        pl.light = auto_band || auto_xcs;
+        if (auto_band) want_band = false;
+        if (auto_xcs) want = false;
+    }
     if (want_band) {
         const int32_t st = band_build(a, stream, &pl.band);
         // auto mode: a matrix the banded plan cannot be built for (its temporaries did not fit) keeps the plans below;
@@ -746,8 +756,10 @@ static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool 
     std::lock_guard<std::recursive_mutex> lock(a->mu);
     {
         SpmvPlan &pl = a->plan;
-        if (!pl.built || pl.opt_sig != plan_signature(o))
-            SPRS_TRY((build_plan<IDX, PTR>(a, stream)));
+        const bool defer = o.spmv_plan_defer != 0 && a->spmv_calls == 0 && !a->prepared;
+        if (!pl.built || pl.opt_sig != plan_signature(o) || (pl.light && !defer))
+            SPRS_TRY((build_plan<IDX, PTR>(a, stream, defer)));
+        ++a->spmv_calls;
         if (!pl.band) SPRS_TRY(get_scratch(pl, stream, &sc));
     }
     const SpmvPlan &pl = a->plan;
@@ -780,6 +792,17 @@ template <typename IDX, typename PTR>
 static int32_t dispatch(sprs_hip_csmat *a, const double *x, double *y, bool acc, hipStream_t stream) {
     if (options().spmv_kernel == 2) return launch_rowwave<IDX, PTR>(a, x, y, acc, stream);
     return launch_tiled<IDX, PTR>(a, x, y, acc, stream);
+}
+
+int32_t spmv_prepare(sprs_hip_csmat *a, hipStream_t stream) {
+    std::lock_guard<std::recursive_mutex> lock(a->mu);
+    a->prepared = true;
+    if (a->rows == 0 || a->nnz == 0 || options().spmv_kernel == 2) return SPRS_HIP_OK;
+    if (a->plan.built && !a->plan.light && a->plan.opt_sig == plan_signature(options())) return SPRS_HIP_OK;
+    if (a->idx_bytes == 8 && a->iptr_bytes == 8) return build_plan<uint64_t, uint64_t>(a, stream);
+    if (a->idx_bytes == 4 && a->iptr_bytes == 8) return build_plan<uint32_t, uint64_t>(a, stream);
+    if (a->idx_bytes == 8 && a->iptr_bytes == 4) return build_plan<uint64_t, uint32_t>(a, stream);
+    return build_plan<uint32_t, uint32_t>(a, stream);
 }
 
 int32_t spmv_f64(sprs_hip_csmat *a, const double *x, double *y, bool accumulate, hipStream_t stream) {

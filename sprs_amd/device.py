@@ -166,6 +166,13 @@ class DeviceCsMat:
         """Drop the cached multiply plans after the wrapped device arrays were modified in place."""
         check(lib.sprs_hip_csmat_refresh(self._h))
 
+    def prepare(self, stream=None):
+        """Build the full SpMV plan now (sprs_hip_csmat_prepare): without it the re-laid-out copy plans come with the SECOND
+        multiply of the handle — the first one runs on the plain tile index."""
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None and hasattr(stream, "cuda_stream") else C.c_void_p(stream or 0)
+        check(lib.sprs_hip_csmat_prepare(self._h, sp))
+        return self
+
     def spmv_plan_info(self):
         """-> (kind, plan_bytes): 0 none yet, 1 nnz tiles, 2 XCD-sliced copy, 3 banded copy (hot columns from LDS)."""
         kind, nbytes = C.c_int32(), C.c_uint64()

@@ -82,7 +82,34 @@ class RowShardedSpMV:
             self.mode = "allgather"
             self._exchange_allgather()
 
+    def _exchange_staged(self):
+        """The same direct exchange for a backend without device-side P2P (gloo with the vectors on a GPU): the own block goes
+        to pinned host memory once, the peers' blocks arrive there and are copied into y.  For running the N > 1 path where
+        RCCL cannot come up (several ranks on one GPU); never the measured route of a real multi-GPU run."""
+        if not hasattr(self, "_host"):
+            self._host = torch.empty(self.rows, dtype=torch.float64).pin_memory() if torch.cuda.is_available() else torch.empty(self.rows, dtype=torch.float64)
+        h = self._host
+        h[self.r0:self.r1].copy_(self.y[self.r0:self.r1])          # (synchronises with the stream that wrote the block)
+        ops = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            a, b = self.cuts[peer], self.cuts[peer + 1]
+            if self.r1 > self.r0:
+                ops.append(dist.P2POp(dist.isend, h[self.r0:self.r1], peer, self.group))
+            if b > a:
+                ops.append(dist.P2POp(dist.irecv, h[a:b], peer, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for peer in range(self.world):
+            if peer != self.rank:
+                a, b = self.cuts[peer], self.cuts[peer + 1]
+                self.y[a:b].copy_(h[a:b], non_blocking=True)
+
     def _exchange_direct(self):
+        if self.y.is_cuda and dist.get_backend(self.group) == "gloo":
+            return self._exchange_staged()
         mine = self.y[self.r0:self.r1]
         ops = []
         for peer in range(self.world):

@@ -442,6 +442,58 @@ def test_config2_full_size_whole_vector(hip):
         _whole_vector_vs_oracle(indptr, indices, data, x, y, n)
 
 
+def test_plan_policy_call_count_rule(hip):
+    """a handle's first SpMV must not pay for a plan that copies the matrix.  Auto mode, a matrix the
+    banded plan applies to: multiply 1 -> plain tile index (kind 1, a few hundred KB), multiply 2 -> the banded copy (kind 3);
+    option spmv_plan_defer = 0 and sprs_hip_csmat_prepare build it at once; a forced plan (spmv_band = 1) is never deferred; the
+    one-shot host entry never builds a copy; every result is the oracle's within the tolerance."""
+    import torch
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    dev = torch.device("cuda", 0)
+    n = 700_000
+    indptr, indices, data = gen.rmat_csr(n, 24, device=dev)
+    x = gen.dense_vector(n, seed=3, device=dev)
+
+    def mul(a):
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+        prod.csmat_mul_vec(a, DeviceVec.borrow(x), out=DeviceVec.borrow(y))
+        torch.cuda.synchronize()
+        return y
+
+    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    assert a.spmv_plan_info() == (0, 0)
+    y1 = mul(a)
+    kind1, bytes1 = a.spmv_plan_info()
+    assert kind1 == 1 and bytes1 < indices.numel() // 16           # the tile index: 8 bytes per 2 - 4 K entries
+    y2 = mul(a)
+    kind2, bytes2 = a.spmv_plan_info()
+    assert kind2 == 3 and bytes2 > indices.numel() * 8              # the banded copy
+    assert torch.equal(mul(a), y2)                                  # from here on the same plan, the same bits
+    _whole_vector_vs_oracle(indptr, indices, data, x, y1, n)
+    _whole_vector_vs_oracle(indptr, indices, data, x, y2, n)
+    a.refresh()                                                     # values changed: the handle has multiplied before, the full plan comes back at once
+    mul(a)
+    assert a.spmv_plan_info()[0] == 3
+    b = DeviceCsMat.wrap_torch((n, n), indptr, indices, data).prepare()
+    assert b.spmv_plan_info()[0] == 3 and torch.equal(mul(b), y2)
+    b.prepare()                                                     # idempotent
+    assert b.spmv_plan_info()[0] == 3
+    hip.set_option("spmv_plan_defer", 0)
+    try:
+        c = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+        assert torch.equal(mul(c), y2) and c.spmv_plan_info()[0] == 3
+    finally:
+        hip.set_option("spmv_plan_defer", 1)
+    hip.set_option("spmv_band", 1)
+    try:
+        d = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+        mul(d)
+        assert d.spmv_plan_info()[0] == 3
+    finally:
+        hip.set_option("spmv_band", 0)
+
+
 def test_config3_full_size_whole_vector(hip):
     """BASELINE config 3 (5-point Laplacian of a 4096 x 4096 grid, heat.rs:45-80) at full size: every component
     within the componentwise bound |dy_i| <= 1e-10 (|A||x|)_i (mixed signs), Dirichlet rows exact."""
@@ -474,6 +526,11 @@ def test_config4_full_size_whole_vector_and_determinism(hip):
     indptr, indices, data = gen.rmat_csr(n, 32, device=dev)
     x = gen.dense_vector(n, seed=3, device=dev)
     a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    # plan policy: the FIRST multiply of a handle runs on the plain tile index, the banded copy comes with the second one ...
+    y_first = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    prod.csmat_mul_vec(a, DeviceVec.borrow(x), out=DeviceVec.borrow(y_first))
+    torch.cuda.synchronize()
+    assert a.spmv_plan_info()[0] == 1
     ys = []
     for _ in range(5):
         y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
@@ -481,6 +538,16 @@ def test_config4_full_size_whole_vector_and_determinism(hip):
         torch.cuda.synchronize()
         ys.append(y)
     assert a.spmv_plan_info()[0] == 3
+    # ... both within the tolerance of the oracle (the two plans group a row's products differently: equal to rounding)
+    _whole_vector_vs_oracle(indptr, indices, data, x, y_first, n)
+    # ... and sprs_hip_csmat_prepare builds it before the first multiply of a fresh handle
+    b = DeviceCsMat.wrap_torch((n, n), indptr, indices, data).prepare()
+    assert b.spmv_plan_info()[0] == 3
+    yb = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    prod.csmat_mul_vec(b, DeviceVec.borrow(x), out=DeviceVec.borrow(yb))
+    torch.cuda.synchronize()
+    assert torch.equal(yb, ys[0])
+    del b, yb, y_first
     for y in ys[1:]:
         assert torch.equal(y, ys[0])
     ref = _whole_vector_vs_oracle(indptr, indices, data, x, ys[0], n)
