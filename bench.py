@@ -577,8 +577,8 @@ def main():
             "workload": name,
             "rows": n, "cols": n, "nnz": nnz_total,
             "index_bytes": args.idx_bytes, "indptr_bytes": args.idx_bytes,
-            "partition": ("cost-balanced (nnz + 8/row) contiguous row blocks x%d, direct all-gather-v of y (%s)" %
-                          (world, "sprs_hip_dist_*, RCCL inside the library" if use_lib else
+            "partition": ("cost-balanced (nnz + %g/row) contiguous row blocks x%d, direct all-gather-v of y (%s)" %
+                          (sh.row_weight, world, "sprs_hip_dist_*, RCCL inside the library" if use_lib else
                            "torch.distributed grouped send/recv on RCCL" if args.backend == "nccl" else "torch.distributed send/recv on gloo, staged through host memory"))
                          if world > 1 else "single GPU",
             "generate_s": round(gen_s, 2),

@@ -40,6 +40,29 @@ def main():
     x = gen.dense_vector(n, device=dev)
     nnz = indices.numel()
     out = {"n": n, "nnz": nnz, "row_weight": RW, "model": "per-block kernel time measured on ONE MI355X; exchange modelled"}
+    # ROW_WEIGHTS="8,16,32": the cost function nnz + w * rows of the partition swept (choose it to minimise
+    # max(compute) + max(y block) / one xGMI link) — one JSON line per weight, G = 4 and 8 only
+    if os.environ.get("ROW_WEIGHTS"):
+        for w in [float(v) for v in os.environ["ROW_WEIGHTS"].split(",")]:
+            rec = {"row_weight": w}
+            for G in (4, 8):
+                cuts = gen.balanced_row_blocks(indptr, G, row_weight=w)
+                times, rows, nz = [], [], []
+                for g in range(G):
+                    r0, r1 = cuts[g], cuts[g + 1]
+                    lo, hi = int(indptr[r0]), int(indptr[r1])
+                    a = DeviceCsMat.wrap_torch((r1 - r0, n), (indptr[r0:r1 + 1] - indptr[r0]).contiguous(), indices[lo:hi].clone(), data[lo:hi].clone())
+                    y = torch.empty(r1 - r0, dtype=torch.float64, device=dev)
+                    times.append(time_spmv(a, x, y))
+                    rows.append(r1 - r0)
+                    nz.append(hi - lo)
+                    del a, y
+                gather_s = max(rows) * 8 / (LINK_GBS * 1e9)
+                rec["G=%d" % G] = {"compute_ms": [round(t * 1e3, 4) for t in times], "rows": rows, "nnz": nz,
+                                   "modelled_allgather_ms": round(gather_s * 1e3, 4), "modelled_step_ms": round((max(times) + gather_s) * 1e3, 4),
+                                   "modelled_gflops": round(2 * nnz / (max(times) + gather_s) / 1e9, 1)}
+            print(json.dumps(rec), flush=True)
+        return
     for G in (1, 2, 4, 8):
         cuts = gen.balanced_row_blocks(indptr, G, row_weight=RW)
         times, rows, subs = [], [], []

@@ -32,14 +32,21 @@ class RowShardedSpMV:
     block = (rows, cols, indptr, indices, data) with a zero-based indptr.
     """
 
-    def __init__(self, shape, indptr, indices, data, local_spmv, group=None, row_weight=8.0, exchange="direct"):
+    def __init__(self, shape, indptr, indices, data, local_spmv, group=None, row_weight=None, exchange="direct"):
         assert exchange in ("direct", "allgather")
         self.mode = exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rows, self.cols = shape
-        # blocks of equal cost nnz + row_weight * rows (a row costs ~5 entries of compute on MI355X; 8 also evens out the y blocks of the exchange)
+        # blocks of equal cost nnz + row_weight * rows.  A row costs ~5 entries of compute on MI355X; a larger weight evens out the y
+        # blocks of the exchange (R-MAT keeps its long rows in front: the last blocks have the most rows) at the price of uneven
+        # multiplies.  Chosen on the one-GPU model max(block multiply) + max(y block) / one xGMI link (scripts/virtual_ranks.py,
+        # profiles/r13t_virtual_ranks_row_weight_sweep.jsonl): 8 is best up to 4 ranks (0.562 ms against 0.582 at 16), 16 - 24 at 8
+        # ranks (0.358 against 0.378 at 8) — a model, not a multi-GPU measurement.
+        if row_weight is None:
+            row_weight = 8.0 if self.world <= 4 else 16.0
+        self.row_weight = row_weight
         self.cuts = gen.balanced_row_blocks(indptr, self.world, row_weight=row_weight)
         r0, r1 = self.cuts[self.rank], self.cuts[self.rank + 1]
         lo, hi = int(indptr[r0]), int(indptr[r1])
