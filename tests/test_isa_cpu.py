@@ -101,3 +101,39 @@ def test_spmm_stream_kernel_keeps_its_gathers_in_flight(spmm_isa):
         assert scratch == 0, name
         assert vgpr <= 84, (name, vgpr)
         assert longest_load_burst(body) >= 16, name
+
+
+@pytest.fixture(scope="module")
+def band_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = tmp_path_factory.mktemp("isa") / "spmv_band.s"
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "--cuda-device-only", "-S",
+                           os.path.join(ROOT, "sprs_amd", "csrc", "spmv_band.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    kernels = {}
+    for m in re.finditer(r"^(_ZN8sprs_hip\S+):\s*; @\S+\n(.*?)^\s*s_endpgm", text, flags=re.S | re.M):
+        kernels[m.group(1)] = m.group(2)
+    return kernels, text
+
+
+def test_hot_kernel_does_not_drain_its_stores_before_the_next_request(band_isa):
+    """gfx950 counts loads and stores on ONE in-order vmcnt.  Until round 5 the compiler sank the use of the tile's last load
+    (tile_row[w]) behind the flush of the previous tile's sums: `global_store ... ; s_waitcnt vmcnt(0) ; v_mov ; global_load ...` —
+    every wave waited for the acknowledgement of its stores with nothing in flight, once per tile (hot kernel alone 736 us; 658 us
+    with the wait in front of the flush, profiles/r13c).  Guard: in the loop of band_hot_kernel no full drain sits between the
+    non-temporal store of the flush and the next non-temporal tile loads; and the kernel keeps its 96 VGPRs (two 64-register
+    gather waves fit beside each of its waves) without scratch."""
+    kernels, text = band_isa
+    for name in pick(kernels, "band_hot_kernelILi14E"):
+        lines = [ln.strip() for ln in kernels[name].splitlines()]
+        stores = [i for i, ln in enumerate(lines) if ln.startswith("global_store_dwordx2") and ln.endswith(" nt")]
+        assert stores, name
+        first = stores[0]                                    # the deferred flush of the previous tile: the first nt store of the loop
+        nxt = next(i for i in range(first, len(lines)) if lines[i].startswith("global_load_dwordx4") and lines[i].endswith(" nt"))
+        between = lines[first:nxt]
+        assert not any(ln.startswith("s_waitcnt") and "vmcnt(0)" in ln for ln in between), \
+            "%s: the flush's stores are drained before the next tile is requested:\n%s" % (name, "\n".join(between))
+        tail = text[text.index(name + ":"):]
+        m = re.search(r"; NumVgprs: (\d+).*?; ScratchSize: (\d+)", tail, flags=re.S)
+        assert m and int(m.group(1)) <= 96 and int(m.group(2)) == 0, (name, m and m.groups())
