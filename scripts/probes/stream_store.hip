@@ -9,6 +9,7 @@
 //   4 whole 128-byte lines only: the sums are parked and written when 16-aligned groups are complete (8-byte nt)
 //   5 as 4 with 16-byte stores   6 8-byte sc1 (write-through) stores
 // ring_MB: the output offsets wrap around a window of that many MB (0: every sum has its own address).
+//   9 as 1, but the sums of a whole range of 4 tiles parked in LDS and written in one burst at its end (C <= 128)
 //   7 as 1 and 8 as 6, but as exactly two predicated store instructions per tile (C <= 128): counted by the compiler's waits
 // ORDER 0: the stores of a step in front of its request (default), 1: behind it.
 // usage: stream_store.out [GiB of stream, default 3]     one JSON line per (mode, order, depth, C): best of 4 runs
@@ -96,6 +97,26 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 5)))
                     if (MODE == 1) __builtin_nontemporal_store(s + j, out + o + j);
                     else if (MODE == 2) out[o + j] = s + j;
                     else __hip_atomic_store(out + o + j, s + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else if (MODE == 9) {
+                // the sums of a whole RANGE (RUN tiles) parked in LDS and written in ONE burst when the range ends: the same bytes in
+                // RUN times fewer, longer bursts
+                const bool first = ((i + d) % RUN) == 0, last = ((i + d) % RUN) == RUN - 1;
+                double *big = lds + wave * 512;
+                if (first) {
+                    parked = 0;
+                    parked_at = o;
+                }
+                for (uint32_t j = lane; j < C; j += WAVE) big[(parked + j) & 511u] = s + j;
+                parked += C;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (last) {
+                    for (uint32_t j = lane; j < parked; j += WAVE) __builtin_nontemporal_store(big[j & 511u], out + parked_at + j);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             } else if (MODE == 7 || MODE == 8) {
                 // exactly two store instructions per tile, no loop: the compiler can count them, and a wait for the loads of
@@ -194,17 +215,12 @@ int main(int argc, char **argv) {
     for (int rounds : {2}) {
         run<0, 1>(vals, ids, ntiles, 0, out, ncu, rounds);
         run<0, 2>(vals, ids, ntiles, 0, out, ncu, rounds);
-        for (uint32_t C : {24u, 72u}) {
+        for (uint32_t C : {6u, 24u, 72u}) {
             run<1, 1>(vals, ids, ntiles, C, out, ncu, rounds);
-            run<7, 2>(vals, ids, ntiles, C, out, ncu, rounds);
-            run<7, 2, 1>(vals, ids, ntiles, C, out, ncu, rounds);
-            run<7, 3, 1>(vals, ids, ntiles, C, out, ncu, rounds);
-            // the same sums written into a window that is used over and over: does a cache level absorb them?
-            for (uint64_t mb : {4ull, 16ull, 64ull, 128ull, 512ull}) {
-                run<1, 1>(vals, ids, ntiles, C, out, ncu, rounds, mb);
-                run<2, 1>(vals, ids, ntiles, C, out, ncu, rounds, mb);
-                run<6, 1>(vals, ids, ntiles, C, out, ncu, rounds, mb);
-            }
+            run<1, 2>(vals, ids, ntiles, C, out, ncu, rounds);
+            run<9, 1>(vals, ids, ntiles, C, out, ncu, rounds);
+            run<9, 2>(vals, ids, ntiles, C, out, ncu, rounds);
+            run<4, 1>(vals, ids, ntiles, C, out, ncu, rounds);
         }
     }
     return 0;

@@ -792,8 +792,12 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     hipStream_t cstream = overlap ? sc->aux : stream;
     auto launch_carry = [&](const void *spills, uint32_t n, hipStream_t st) -> int32_t {
         if (!n) return SPRS_HIP_OK;
-        hipLaunchKernelGGL(band_carry_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)spills, n, (const double *)sc->carry,
-                           sc->partial, y);
+        if (spills == bp->spills_y)
+            hipLaunchKernelGGL(band_carry_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)spills, n, (const double *)sc->carry,
+                               sc->partial, y);
+        else
+            hipLaunchKernelGGL(band_carry_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)spills, n, (const double *)sc->carry,
+                               sc->partial, y);
         SPRS_TRY_HIP(hipGetLastError());
         return SPRS_HIP_OK;
     };

@@ -545,13 +545,15 @@ __global__ __launch_bounds__(256) void bp_spill_kernel(const Seg *__restrict__ s
     (first ? spills_y : spills_partial)[slot] = Spill{d.to_y ? (uint64_t)d.rowidx[row] : pair_off[rg.piece] + row, i, n, d.to_y, 0u};
 }
 
-// per SpMV: the heads of a record's ranges are added to the row's sum in range order
+// per SpMV: the heads of a record's ranges are added to the row's sum in range order.  Two launches: the short rows' records
+// (TO_Y: into y, behind the short rows on their stream) and the long rows' (into the partial sums, in front of the reduction).
+template <bool TO_Y>
 __global__ __launch_bounds__(256) void band_carry_kernel(const Spill *__restrict__ spills, uint32_t nspills, const double *__restrict__ carry,
                                                          double *__restrict__ partial, double *__restrict__ y) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nspills) return;
     const Spill sp = spills[i];
-    double *dst = (sp.to_y ? y : partial) + sp.dst;
+    double *dst = (TO_Y ? y : partial) + sp.dst;
     double acc = *dst;
     for (uint32_t k = 0; k < sp.n; ++k) acc += carry[sp.first + k];
     *dst = acc;
