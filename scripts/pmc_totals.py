@@ -21,6 +21,9 @@ PER_SPMV = ("spmv_tile_kernel", "spmv_sliced_kernel", "spmv_carry_kernel", "spmv
 def main():
     tot = {}
     per_kernel = {}
+    # plan policy (round 5): a handle's first multiply runs on the plain tile index, so a profile of a banded-plan workload holds ONE
+    # dispatch of spmv_tile_kernel / spmv_carry_kernel per handle beside the band_* kernels of the steady state: not part of "one SpMV"
+    banded = any(line.startswith("sprs_hip::") and "band_hot_kernel" in line for line in open(sys.argv[1]))
     for line in open(sys.argv[1]):
         if not line.startswith("sprs_hip::"):
             continue
@@ -29,6 +32,8 @@ def main():
         full = line.replace("sprs_hip::", "").replace("(anonymous namespace)::", "")
         kern = re.sub(r"[<(].*", "", full.split()[0])
         if kern not in PER_SPMV:
+            continue
+        if banded and not kern.startswith("band_"):
             continue
         counter, n, mean = parts[-5], int(parts[-4]), float(parts[-3])
         inst = re.sub(r"\(.*", "", full).strip()          # with template arguments: band_cold_kernel<false, false> and <false, true> are two launches
