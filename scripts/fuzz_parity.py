@@ -79,7 +79,9 @@ def case_spmv(rng):
         opts = dict(spmv_band=1, spmv_band_tile=tile, spmv_band_hot=int(rng.integers(1, max(2, cols // tile + 2))),
                     spmv_band_split=int(rng.choice([2, 8, 24, 40])), spmv_band_rounds=int(rng.integers(1, 5)),
                     spmv_band_hot_run=int(rng.integers(1, 5)), spmv_band_cold_tiles=int(rng.integers(1, 5)),
-                    spmv_band_phases=int(rng.integers(1, 3)))
+                    spmv_band_phases=int(rng.integers(1, 3)),
+                    # round 5: one stream / two streams, the reduction behind hot slices + cold pieces or behind the whole second stream
+                    spmv_band_overlap=int(rng.choice([0, 1, 2])), spmv_band_tail=int(rng.choice([0, 2])))
     elif plan == 3:
         opts = dict(spmv_band=2, spmv_xcs=2, spmv_kernel=int(rng.choice([1, 2])), spmv_tile=int(rng.choice([0, 2048, 4096])))
     setopt(**opts)
