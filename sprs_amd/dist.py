@@ -33,7 +33,7 @@ class RowShardedSpMV:
     """
 
     def __init__(self, shape, indptr, indices, data, local_spmv, group=None, row_weight=None, exchange="direct"):
-        assert exchange in ("direct", "allgather")
+        assert exchange in ("direct", "allgather", "staged")   # staged: the direct exchange through host memory (what a GPU run under gloo takes)
         self.mode = exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -80,6 +80,8 @@ class RowShardedSpMV:
             return
         if self.mode == "allgather":
             return self._exchange_allgather()
+        if self.mode == "staged":
+            return self._exchange_staged()
         try:
             self._exchange_direct()
         except RuntimeError as e:                     # e.g. a backend without grouped P2P on this topology
@@ -94,7 +96,9 @@ class RowShardedSpMV:
         to pinned host memory once, the peers' blocks arrive there and are copied into y.  For running the N > 1 path where
         RCCL cannot come up (several ranks on one GPU); never the measured route of a real multi-GPU run."""
         if not hasattr(self, "_host"):
-            self._host = torch.empty(self.rows, dtype=torch.float64).pin_memory() if torch.cuda.is_available() else torch.empty(self.rows, dtype=torch.float64)
+            self._host = torch.empty(self.rows, dtype=torch.float64)
+            if self.y.is_cuda:
+                self._host = self._host.pin_memory()
         h = self._host
         h[self.r0:self.r1].copy_(self.y[self.r0:self.r1])          # (synchronises with the stream that wrote the block)
         ops = []

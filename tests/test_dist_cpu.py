@@ -69,6 +69,16 @@ def test_row_sharded_spmv_gloo_allgather_fallback():
 
 
 @pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_spmv_gloo_host_staged_exchange(world):
+    """the exchange a GPU run takes under gloo (bench.py --backend gloo: several ranks on ONE GPU): own block -> host buffer,
+    grouped send / recv of host slices, peers' blocks copied into y — here with y itself on the host"""
+    n = 5000
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, 2, ret, "staged"), nprocs=world, join=True)
+    assert len(ret) == world and all(ret[r][0] for r in range(world))
+
+
+@pytest.mark.parametrize("world", [2, 3])
 def test_row_sharded_spmv_gloo(world):
     mgr = mp.Manager()
     ret = mgr.dict()
