@@ -12,6 +12,8 @@ resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 Workload selection (for parity-sized runs, never for the headline):
   --workload rmat10m (default) | rmat1m | laplace4096 | rmat:<n>:<nnz_per_row>
+  --workload spgemm_uniform   the reference's own bench shape (sprs-benches/src/main.rs:148-163): uniform density, 2.5M x 2.5M,
+                        4 entries per row, oracle at Fixed(1) and Automatic, whole-product parity; also an object of the default line
   --workload spgemm5    BASELINE config 5: C = A * A, R-MAT 1M x 1M ~8 nnz/row (smmp::mul_csr_csr twin); a step is one
                         whole product; prints its own JSON line (seconds per product, compulsory-bytes roofline,
                         CPU baseline = the oracle's mul_csr_csr with sprs' chunking at T = 1 and Automatic on sampled
@@ -220,6 +222,133 @@ def spgemm5(dev, idx_bytes, steps, warmup, check_rows, cpu_blocks, cpu_block_row
     return out
 
 
+def spmv_config(dev, wl, steps=30, warmup=4, with_oracle=True):
+    """One SpMV configuration of BASELINE.json beside the headline (configs 2 and 3: `rmat1m`, `laplace4096`), timed like the
+    headline (HIP events around every SpMV on the launch stream, matrix / x / y resident in HBM, handle prepared) — WARM
+    (steps back to back: whatever fits stays in L2 / the 256 MiB Infinity Cache) and COLD (a 1 GiB read-modify-write
+    between the steps, outside the events: matrix and x come from HBM) — with the WHOLE result vector checked against
+    the oracle.  usize indices and indptr (the sprs default), like the headline."""
+    from sprs_amd import gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    if wl == "rmat1m":
+        n = 1_000_000
+        indptr, indices, data = gen.rmat_csr(n, 16, device=dev)
+        name = "BASELINE config 2: R-MAT 1M x 1M, ~16 nnz/row"
+    elif wl == "laplace4096":
+        n = 4096 * 4096
+        indptr, indices, data = gen.grid_laplacian(4096, 4096, device=dev)
+        name = "BASELINE config 3: 5-pt Laplacian 4096^2 grid"
+    else:
+        raise ValueError(wl)
+    nnz = int(indices.numel())
+    a = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    x = gen.dense_vector(n, seed=3, device=dev)
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    xv, yv = DeviceVec.borrow(x), DeviceVec.borrow(y)
+    stream = torch.cuda.current_stream()
+    a.prepare(stream=stream)
+    for _ in range(warmup):
+        prod.csmat_mul_vec(a, xv, out=yv, stream=stream)
+    torch.cuda.synchronize()
+    alg = algorithmic_bytes(n, n, nnz, 8, 8)
+    plan_kind, plan_bytes = a.spmv_plan_info()
+    res = {"workload": name, "rows": n, "nnz": nnz, "index_bytes": 8, "algorithmic_bytes_per_launch": alg, "steps": steps,
+           "plan": {1: "nnz tiles", 2: "xcd-sliced copy", 3: "banded copy (hot columns from LDS)"}.get(plan_kind, "none"),
+           "plan_bytes": plan_bytes}
+    flush = torch.empty(1 << 27, dtype=torch.float64, device=dev)       # 1 GiB
+    for label, cold in (("warm", False), ("cold", True)):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for p_, q_ in ev:
+            if cold:
+                flush.add_(1.0)
+            p_.record(stream)
+            prod.csmat_mul_vec(a, xv, out=yv, stream=stream)
+            q_.record(stream)
+        torch.cuda.synchronize()
+        ms = [p_.elapsed_time(q_) for p_, q_ in ev]
+        avg = float(np.mean(ms))
+        res[label] = {"kernel_ms_avg": round(avg, 5), "kernel_ms_min": round(float(np.min(ms)), 5),
+                      "gflops": round(2.0 * nnz / (avg * 1e-3) / 1e9, 2), "achieved_GBs": round(alg / (avg * 1e-3) / 1e9, 1),
+                      "frac": round(alg / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del flush
+    if with_oracle:
+        from oracle import oracle   # test infrastructure: the checker, never the product
+        y_h = np.zeros(n)
+        oracle.mul_acc_mat_vec_csr((n, n), indptr.cpu().numpy().view(np.uint64), indices.cpu().numpy().view(np.uint64),
+                                   data.cpu().numpy(), x.cpu().numpy(), y_h)
+        y_g = y.cpu().numpy()
+        den = np.maximum(np.abs(y_h), np.abs(y_g))
+        rel = np.where(den > 0, np.abs(y_g - y_h) / np.where(den > 0, den, 1.0), 0.0)
+        if wl == "laplace4096":
+            # the stencil rows cancel (1 + 1 - 4 + 1 + 1): the bound is componentwise against (|A| |x|)_i, as the GPU tests use
+            ax = np.zeros(n)
+            oracle.mul_acc_mat_vec_csr((n, n), indptr.cpu().numpy().view(np.uint64), indices.cpu().numpy().view(np.uint64),
+                                       np.abs(data.cpu().numpy()), np.abs(x.cpu().numpy()), ax)
+            rel = np.where(ax > 0, np.abs(y_g - y_h) / np.where(ax > 0, ax, 1.0), np.abs(y_g - y_h))
+        res["parity"] = {"rows_checked": n, "max_rel_err_vs_oracle": float(rel.max()), "tolerance": 1e-10,
+                         "bound": "|dy_i| <= tol (|A||x|)_i" if wl == "laplace4096" else "|dy_i| <= tol max(|y_i|, |ref_i|)",
+                         "ok": bool(rel.max() <= 1e-10)}
+    return res
+
+
+def spgemm_uniform(dev, n=2_500_000, nnz_over_rows=4, steps=3, with_cpu=True):
+    """The largest product of the reference's own bench (sprs-benches/src/main.rs:148-163, 178-186, 211-260): m1 (n x n) *
+    m2 (n x n), both from the uniform generator at density nnz_over_rows / n (sprs-rand `rand_csr`, here gen.uniform_csr),
+    timed at ThreadingStrategy::Fixed(1) and ::Automatic on the CPU (the C restatement of smmp::mul_csr_csr; the reference
+    also times 2 and 4 threads).  Every row of the product has ~16 multiply-adds: the whole product runs through the
+    one-wave-per-row LDS-hash kernel (small_rows_kernel).  The WHOLE product is compared with the oracle's, structure and
+    value bits."""
+    from sprs_amd import gen, smmp
+    from sprs_amd.device import DeviceCsMat
+    dens = float(nnz_over_rows) / n
+    a_ip, a_ix, a_dt = gen.uniform_csr((n, n), dens, seed=11, value_seed=12, device=dev)
+    b_ip, b_ix, b_dt = gen.uniform_csr((n, n), dens, seed=21, value_seed=22, device=dev)
+    a = DeviceCsMat.wrap_torch((n, n), a_ip, a_ix, a_dt)
+    b = DeviceCsMat.wrap_torch((n, n), b_ip, b_ix, b_dt)
+    stream = torch.cuda.current_stream()
+    c = smmp.mul_csr_csr(a, b)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for p_, q_ in ev:
+        c = None
+        p_.record(stream)
+        c = smmp.mul_csr_csr(a, b)
+        q_.record(stream)
+    torch.cuda.synchronize()
+    ms = [p_.elapsed_time(q_) for p_, q_ in ev]
+    sec = float(np.mean(ms)) * 1e-3
+    nnz_a, nnz_b, nnz_c = int(a_ix.numel()), int(b_ix.numel()), int(c.nnz())
+    b_len = (b_ip[1:] - b_ip[:-1]).to(torch.float64)
+    products = float(b_len[a_ix.long()].sum().item())
+    comp = (nnz_a + nnz_b + nnz_c) * 16 + 3 * (n + 1) * 8
+    out = {"workload": "sprs-benches shape bench, largest shape: (%d x %d) * (%d x %d), uniform density %d / cols, values N(0,1), usize indices"
+                       % (n, n, n, n, nnz_over_rows),
+           "seconds_per_product": round(sec, 6), "kernel_ms_min": round(float(np.min(ms)), 3), "steps": steps,
+           "nnz_a": nnz_a, "nnz_b": nnz_b, "nnz_c": nnz_c, "products": products, "gflops": round(2 * products / sec / 1e9, 2),
+           "compulsory_bytes": comp, "achieved_GBs": round(comp / sec / 1e9, 1), "roofline_frac": round(comp / sec / 1e9 / HBM_PEAK_GBS, 4)}
+    if with_cpu:
+        from oracle import oracle   # test infrastructure: the checker + the timed CPU port, never the product
+        h = lambda t: t.cpu().numpy().view(np.uint64)
+        args = ((n, n), h(a_ip), h(a_ix), a_dt.cpu().numpy(), (n, n), h(b_ip), h(b_ix), b_dt.cpu().numpy())
+        t = time.perf_counter()
+        _, r_ip, r_ix, r_dt = oracle.mul_csr_csr(*args, threads=1)
+        t1 = time.perf_counter() - t
+        t = time.perf_counter()
+        res = oracle.mul_csr_csr(*args, threads=0, return_threads=True)
+        tauto = time.perf_counter() - t
+        _, g_ip, g_ix, g_dt = c.to_host()
+        same = bool(np.array_equal(g_ip, r_ip) and np.array_equal(g_ix, r_ix))
+        bits = bool(same and np.array_equal(g_dt.view(np.uint64), r_dt.view(np.uint64)))
+        same_auto = bool(np.array_equal(res[1], r_ip) and np.array_equal(res[2], r_ix) and np.array_equal(res[3].view(np.uint64), r_dt.view(np.uint64)))
+        out["parity"] = {"entries_checked": nnz_c, "structure_bit_exact": same, "values_bit_exact": bits,
+                         "oracle_auto_equals_fixed1": same_auto,          # the reference's own assert_eq!(prod, prod_) (main.rs:228, 242, 256)
+                         "tolerance": 1e-10, "ok": bool(same and bits)}
+        out["cpu_baseline"] = {"fixed1_seconds": round(t1, 3), "automatic_seconds": round(tauto, 3), "automatic_threads": int(res[-1]),
+                               "kind": "port", "host_cores": oracle.num_procs(),
+                               "sample": "the whole product, once per strategy (C restatement of smmp::mul_csr_csr; rustc is not available here)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,6 +433,14 @@ def main():
         if val is not None:
             sprs_amd.set_option(opt, val)
 
+    if args.workload == "spgemm_uniform":
+        if world != 1:
+            sys.exit("spgemm_uniform is single-GPU (north star: SpGEMM stays on one GPU)")
+        out = spgemm_uniform(dev, steps=args.steps if args.steps != 50 else 5, with_cpu=not args.no_cpu_baseline)
+        out.update({"metric": "CSR x CSR SpGEMM seconds per product (sprs-benches shape)", "value": out["seconds_per_product"], "unit": "s",
+                    "higher_is_better": False, "n_gpus": 1, "scaling": "replicas only", "vs_baseline": None, "dtype": "f64", "data": "synthetic"})
+        print(json.dumps(out))
+        return
     if args.workload == "spgemm5":
         if world != 1:
             sys.exit("spgemm5 is single-GPU (north star: SpGEMM stays on one GPU)")
@@ -377,12 +514,21 @@ def main():
     stream = torch.cuda.current_stream()
 
     handles = {}
+    prep_s = [0.0]
 
     def local_spmv(block, xv, y_block):
         key = id(block)
         if key not in handles:
             rows_b, cols_b, ip, ix, dt = block
             handles[key] = DeviceCsMat.wrap_torch((rows_b, cols_b), ip, ix, dt)
+            if world > 1:
+                # N > 1: every route's handle gets its final plan up front (plan policy, sprs_hip.h) — the routes cross-check and the
+                # secondary timings call a handle once or twice outside any warm-up, and a deferred plan build must not land in them
+                torch.cuda.synchronize()
+                t_prep = time.perf_counter()
+                handles[key].prepare(stream=stream)
+                torch.cuda.synchronize()
+                prep_s[0] += time.perf_counter() - t_prep
         out = DeviceVec.borrow(y_block)
         prod.csmat_mul_vec(handles[key], DeviceVec.borrow(xv), out=out, stream=stream)
 
@@ -507,6 +653,7 @@ def main():
         import torch.distributed as dist
 
         def timed_ms(fn, k):
+            fn(x)                                       # one untimed call: no first-use cost of a route inside its timing
             torch.cuda.synchronize()
             barrier()
             t = time.perf_counter()
@@ -583,7 +730,8 @@ def main():
                          if world > 1 else "single GPU",
             "generate_s": round(gen_s, 2),
             # once per handle, never part of `value`: the first multiply (plan build + one SpMV) minus a steady-state step
-            "plan_build_s": round(max(0.0, second_step_s - ms_per_step * 1e-3), 4),
+            # (N > 1: every handle is prepared when it is made — the time of that sprs_hip_csmat_prepare call)
+            "plan_build_s": round(max(0.0, second_step_s - ms_per_step * 1e-3), 4) if world == 1 else round(prep_s[0], 4),
             # the handle's FIRST multiply (plain tile index over the handle's own arrays + one SpMV on it): what a caller that
             # multiplies once pays instead of plan_build_s
             "first_spmv_ms": round(first_step_s * 1e3, 3),
@@ -790,6 +938,22 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:   # the headline line must not depend on the secondary measurement
             out["spmm"] = {"error": repr(e)[:200]}
+
+    # ---- BASELINE configs 2 and 3 beside the headline (the driver's line must carry them) and the reference's own
+    # bench shape for the SpGEMM (sprs-benches: uniform density, 2.5M x 2.5M, 4 entries per row) ------------------------------------
+    if rank == 0 and world == 1 and wl == "rmat10m" and args.idx_bytes == 8 and not args.no_secondary:
+        out["configs"] = {}
+        for cfg in ("rmat1m", "laplace4096"):
+            try:
+                out["configs"][cfg] = spmv_config(dev, cfg, with_oracle=not args.no_cpu_baseline)
+            except Exception as e:   # the headline line must not depend on a secondary measurement
+                out["configs"][cfg] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+        try:
+            out["spgemm_uniform"] = spgemm_uniform(dev, with_cpu=not args.no_cpu_baseline)
+        except Exception as e:
+            out["spgemm_uniform"] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
 
     # ---- BASELINE config 5 beside the headline (rank 0, N = 1, default workload): a short SpGEMM object -----------
     if rank == 0 and world == 1 and wl == "rmat10m" and not args.no_secondary and not args.no_cpu_baseline:

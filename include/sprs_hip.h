@@ -140,6 +140,13 @@ int32_t sprs_hip_csmat_refresh(sprs_hip_csmat *m);
  * handle, so a handle that multiplies once (`&a * &x` on a temporary) never pays for them.  A caller that knows it will
  * iterate (a solver) calls this once after the upload: the full plan is built now, on `stream`, and the first SpMV already
  * runs at the steady-state rate.  Idempotent; option spmv_plan_defer = 0 brings back "build at the first multiply".
+ * What a caller that does NOT prepare must know: (i) multiply #1 and multiply #2 of one handle run on different plans and so
+ * add the products of a row in different (each deterministic) orders — both within 1e-10 of the reference, but not
+ * bit-identical to each other; from multiply #2 on every result has the same bits.  A solver whose first iteration must
+ * reproduce later ones prepares the handle.  (ii) Multiply #2 allocates, builds and synchronises (the plan build): it must
+ * not sit inside a timed or a CAPTURED region — an SpMV on a stream that is being captured into a hipGraph fails with
+ * SPRS_HIP_INVALID_ARG unless the handle's final plan already exists.  The flag and the multiply count belong to the handle the
+ * caller holds: a CSC handle hands them to its cached CSR copy, also to the one rebuilt after sprs_hip_csmat_refresh.
  * No counterpart in the reference (its CsMat has no derived state). */
 int32_t sprs_hip_csmat_prepare(sprs_hip_csmat *m, void *stream);
 /* What the SpMV plan cached in the handle looks like (after the first multiply; kind 0 before):

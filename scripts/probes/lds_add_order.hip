@@ -34,6 +34,37 @@ __global__ __launch_bounds__(64) void probe_kernel(const double *__restrict__ v,
     if ((int)lane < nslots) out[t * 64 + lane] = acc[lane];
 }
 
+// The same question UNDER CONTENTION: 8 waves per workgroup, several workgroups per CU, every wave
+// running its trials back to back with no barrier between the waves, all accumulators in one LDS array whose per-wave
+// regions cover every bank — the ds_add_f64 instructions of up to 16 - 32 waves of a CU queue up at one LDS at the same time.
+// Every wave still adds into its own 64 doubles (as the library's wave kernels do; the workgroup kernel hands a token on).
+template <int WITH_RETURN>
+__global__ __launch_bounds__(512) void probe_contended_kernel(const double *__restrict__ v, const uint32_t *__restrict__ slot,
+                                                            const unsigned long long *__restrict__ active, double *__restrict__ out,
+                                                            int nslots, int reps) {
+    __shared__ double acc_s[8][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    double *acc = acc_s[wave];
+    for (int r = 0; r < reps; ++r) {
+        const size_t t = ((size_t)blockIdx.x * 8 + wave) * (size_t)reps + (size_t)r;
+        acc[lane] = 0.0;
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const bool on = (active[t] >> lane) & 1ull;
+        const double x = v[t * 64 + lane];
+        const uint32_t s = slot[t * 64 + lane];
+        double rr = 0.0;
+        if (on) {
+            if constexpr (WITH_RETURN) rr = atomicAdd(&acc[s], x);
+            else atomicAdd(&acc[s], x);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (WITH_RETURN && rr == 12345.678) out[0] = rr;
+        if ((int)lane < nslots) out[t * 64 + lane] = acc[lane];
+    }
+}
+
 static uint64_t sm64(uint64_t &s) {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -42,7 +73,10 @@ static uint64_t sm64(uint64_t &s) {
 }
 
 int main(int argc, char **argv) {
-    const size_t trials = argc > 1 ? strtoull(argv[1], nullptr, 10) : 200000;
+    size_t trials = argc > 1 ? strtoull(argv[1], nullptr, 10) : 200000;
+    const bool contended = argc > 2 && atoi(argv[2]) != 0;      // second argument 1: the 8-waves-per-workgroup form
+    const int reps = 64;
+    if (contended) trials = (trials + 8 * reps - 1) / (8 * reps) * (8 * reps);
     for (int with_return = 0; with_return < 2; ++with_return)
     for (int nslots : {1, 2, 3, 8, 33, 64}) {
         std::vector<double> v(trials * 64), ref_up(trials * 64), ref_dn(trials * 64), got(trials * 64);
@@ -75,7 +109,11 @@ int main(int argc, char **argv) {
         hipMemcpy(dslot, slot.data(), slot.size() * 4, hipMemcpyHostToDevice);
         hipMemcpy(dact, act.data(), act.size() * 8, hipMemcpyHostToDevice);
         hipMemset(dout, 0, v.size() * 8);
-        if (with_return) hipLaunchKernelGGL(probe_kernel<1>, dim3((unsigned)trials), dim3(64), 0, nullptr, dv, dslot, dact, dout, nslots);
+        if (contended) {
+            const unsigned nb = (unsigned)(trials / (8 * reps));
+            if (with_return) hipLaunchKernelGGL(probe_contended_kernel<1>, dim3(nb), dim3(512), 0, nullptr, dv, dslot, dact, dout, nslots, reps);
+            else hipLaunchKernelGGL(probe_contended_kernel<0>, dim3(nb), dim3(512), 0, nullptr, dv, dslot, dact, dout, nslots, reps);
+        } else if (with_return) hipLaunchKernelGGL(probe_kernel<1>, dim3((unsigned)trials), dim3(64), 0, nullptr, dv, dslot, dact, dout, nslots);
         else hipLaunchKernelGGL(probe_kernel<0>, dim3((unsigned)trials), dim3(64), 0, nullptr, dv, dslot, dact, dout, nslots);
         if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
         hipMemcpy(got.data(), dout, v.size() * 8, hipMemcpyDeviceToHost);
@@ -88,8 +126,8 @@ int main(int argc, char **argv) {
                 if (memcmp(&got[i], &ref_up[i], 8)) ++bad_up;
                 if (memcmp(&got[i], &ref_dn[i], 8)) ++bad_dn;
             }
-        printf("{\"probe\": \"lds_add_f64_lane_order\", \"returning\": %d, \"slots\": %d, \"sums\": %zu, \"order_sensitive\": %zu, "
-               "\"differ_from_ascending\": %zu, \"differ_from_descending\": %zu}\n", with_return, nslots, n, sens, bad_up, bad_dn);
+        printf("{\"probe\": \"lds_add_f64_lane_order\", \"waves_per_workgroup\": %d, \"returning\": %d, \"slots\": %d, \"sums\": %zu, \"order_sensitive\": %zu, "
+               "\"differ_from_ascending\": %zu, \"differ_from_descending\": %zu}\n", contended ? 8 : 1, with_return, nslots, n, sens, bad_up, bad_dn);
         hipFree(dv); hipFree(dout); hipFree(dslot); hipFree(dact);
     }
     return 0;

@@ -600,6 +600,9 @@ int32_t sprs_hip_csmat_transpose_view(const sprs_hip_csmat *m, sprs_hip_csmat **
 int32_t sprs_hip_csmat_free(sprs_hip_csmat *m) {
     clear_error();
     if (!m) return SPRS_HIP_OK;
+    // a kernel launched through a cached copy (as_other, t_view) or a plan copy may still be reading it: a handle that holds
+    // any of them waits for the device before they go (refresh does the same; a bare handle frees at once)
+    if (m->t_view || m->as_other || m->plan.built) (void)hipDeviceSynchronize();
     invalidate_caches(m);
     if (m->owns) {
         if (m->indptr) (void)hipFree(m->indptr);
@@ -907,7 +910,12 @@ int32_t sprs_hip_dist_spmv_f64(sprs_hip_dist *d, const double *x_dev, uint64_t x
 static int32_t other_form(const sprs_hip_csmat *m, sprs_hip_csmat **out) {
     auto *mm = const_cast<sprs_hip_csmat *>(m);
     std::lock_guard<std::recursive_mutex> lock(mm->mu);
-    if (!mm->as_other) SPRS_TRY(to_other_storage(m, &mm->as_other));
+    if (!mm->as_other) {
+        SPRS_TRY(to_other_storage(m, &mm->as_other));
+        // the plan policy (prepare flag, multiplies so far) is the OWNER's: a copy rebuilt after a refresh keeps it
+        mm->as_other->prepared = mm->prepared;
+        mm->as_other->spmv_calls = mm->spmv_calls;
+    }
     *out = mm->as_other;
     return SPRS_HIP_OK;
 }
@@ -923,6 +931,10 @@ int32_t sprs_hip_csmat_prepare(sprs_hip_csmat *m, void *stream) {
     clear_error();
     if (!m) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
     sprs_hip_csmat *csr = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lock(m->mu);
+        m->prepared = true;                    // kept on the handle the caller holds: survives a refresh of a CSC handle's CSR copy
+    }
     SPRS_TRY(csr_form(m, &csr));               // a CSC handle multiplies through its CSR copy: that is the handle to prepare
     return spmv_prepare(csr, (hipStream_t)stream);
 }
@@ -944,7 +956,9 @@ int32_t sprs_hip_mul_acc_mat_vec_csc_f64(const sprs_hip_csmat *a, const double *
     SPRS_TRY(vec_args_ok(x_dev, x_len, y_dev, y_len));
     sprs_hip_csmat *csr = nullptr;
     SPRS_TRY(csr_form(a, &csr));
-    return spmv_f64(csr, x_dev, y_dev, true, (hipStream_t)stream);
+    const int32_t st = spmv_f64(csr, x_dev, y_dev, true, (hipStream_t)stream);
+    if (csr != a) const_cast<sprs_hip_csmat *>(a)->spmv_calls = csr->spmv_calls;
+    return st;
 }
 
 int32_t sprs_hip_csmat_mul_vec_f64(const sprs_hip_csmat *a, const double *x_dev, uint64_t x_len, double *y_dev, uint64_t y_len,
@@ -956,7 +970,9 @@ int32_t sprs_hip_csmat_mul_vec_f64(const sprs_hip_csmat *a, const double *x_dev,
     SPRS_TRY(vec_args_ok(x_dev, x_len, y_dev, y_len));
     sprs_hip_csmat *csr = nullptr;
     SPRS_TRY(csr_form(a, &csr));
-    return spmv_f64(csr, x_dev, y_dev, false, (hipStream_t)stream);
+    const int32_t st = spmv_f64(csr, x_dev, y_dev, false, (hipStream_t)stream);
+    if (csr != a) const_cast<sprs_hip_csmat *>(a)->spmv_calls = csr->spmv_calls;
+    return st;
 }
 
 int32_t sprs_hip_csmat_mulacc_dense_f64(const sprs_hip_csmat *lhs, const double *rhs_dev, uint64_t rhs_rows, uint64_t k,
@@ -972,10 +988,22 @@ int32_t sprs_hip_csmat_mulacc_dense_f64(const sprs_hip_csmat *lhs, const double 
     if (ld_rhs < (rhs_layout == SPRS_HIP_ROW_MAJOR ? k : rhs_rows) || ld_out < (out_layout == SPRS_HIP_ROW_MAJOR ? k : out_rows))
         SPRS_FAIL(SPRS_HIP_INVALID_ARG, "leading dimension smaller than the extent it strides over");
     if (k && ((rhs_rows && !rhs_dev) || (out_rows && !out_dev))) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL matrix");
-    if (k && rhs_rows && out_rows) {   // the spans the two operands stride over must not meet (as vec_args_ok for the vectors)
+    if (k && rhs_rows && out_rows) {   // the two operands must not share an ELEMENT (as vec_args_ok for the vectors)
         const uint64_t span_r = (rhs_layout == SPRS_HIP_ROW_MAJOR ? rhs_rows - 1 : k - 1) * ld_rhs + (rhs_layout == SPRS_HIP_ROW_MAJOR ? k : rhs_rows);
         const uint64_t span_o = (out_layout == SPRS_HIP_ROW_MAJOR ? out_rows - 1 : k - 1) * ld_out + (out_layout == SPRS_HIP_ROW_MAJOR ? k : out_rows);
-        if (rhs_dev < out_dev + span_o && out_dev < rhs_dev + span_r) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "the result matrix overlaps the right-hand side");
+        if (rhs_dev < out_dev + span_o && out_dev < rhs_dev + span_r) {
+            // the strided spans meet.  Two views of ONE buffer with the same layout and pitch — rhs = buf[:, 0:k], out = buf[:, k:2k],
+            // or the same as column blocks; ndarray views the reference accepts — are still element-disjoint when the lines of one
+            // fall into the gaps of the other: the offset between them, modulo the pitch, leaves both line extents apart.
+            bool disjoint = false;
+            if (rhs_layout == out_layout && ld_rhs == ld_out) {
+                const uint64_t w_r = rhs_layout == SPRS_HIP_ROW_MAJOR ? k : rhs_rows, w_o = out_layout == SPRS_HIP_ROW_MAJOR ? k : out_rows;
+                const uint64_t d = rhs_dev <= out_dev ? (uint64_t)(out_dev - rhs_dev) % ld_rhs : (ld_rhs - (uint64_t)(rhs_dev - out_dev) % ld_rhs) % ld_rhs;
+                // inside one pitch: rhs lines occupy [0, w_r), out lines [d, d + w_o)
+                disjoint = d >= w_r && d + w_o <= ld_rhs;
+            }
+            if (!disjoint) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "the result matrix overlaps the right-hand side");
+        }
     }
     sprs_hip_csmat *csr = nullptr;
     SPRS_TRY(csr_form(lhs, &csr));
@@ -1017,13 +1045,12 @@ int32_t sprs_hip_dense_dot_csmat_f64(const double *lhs_dev, uint64_t lhs_rows, u
         src = csc;
     }
     // the view stays in the rhs handle (beside as_other): its tile / band plans are built once, not per call
-    sprs_hip_csmat *rt = nullptr;
-    {
-        sprs_hip_csmat *owner = const_cast<sprs_hip_csmat *>(rhs);
-        std::lock_guard<std::recursive_mutex> lock(owner->mu);
-        if (!owner->t_view) SPRS_TRY(sprs_hip_csmat_transpose_view(src, &owner->t_view));
-        rt = owner->t_view;
-    }
+    // The owner's lock is held until the product's kernels are launched: a concurrent refresh / numeric SpGEMM on rhs frees the
+    // view in invalidate_caches (behind a device synchronise), and must not do so between the look-up and the launches.
+    sprs_hip_csmat *owner = const_cast<sprs_hip_csmat *>(rhs);
+    std::lock_guard<std::recursive_mutex> lock(owner->mu);
+    if (!owner->t_view) SPRS_TRY(sprs_hip_csmat_transpose_view(src, &owner->t_view));
+    sprs_hip_csmat *rt = owner->t_view;
     int32_t lay_t = 0;
     // lhs^T: lhs_cols x lhs_rows, the other layout over the same memory
     const int32_t st = sprs_hip_csmat_mul_dense_f64(rt, lhs_dev, lhs_cols, lhs_rows, lhs_layout == SPRS_HIP_ROW_MAJOR ? SPRS_HIP_COL_MAJOR : SPRS_HIP_ROW_MAJOR,

@@ -207,6 +207,9 @@ int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world
         sprs_hip_csmat *m = nullptr;
         SPRS_TRY(slice_outer(local_block, cuts[s], cuts[s + 1], &m));
         d->sub.push_back(m);
+        // an iterative caller by construction: the final plan is built now, so that the first collective multiply already runs
+        // on it (and multiply #1 and #2 of a solver give the same bits; plan policy, sprs_hip.h)
+        if (m->rows && m->nnz) SPRS_TRY(spmv_prepare(m, nullptr));
         d->sub_starts.push_back(r0 + cuts[s]);
     }
     d->sub_starts.push_back(r0 + lrows);

@@ -757,8 +757,17 @@ static int32_t launch_tiled(sprs_hip_csmat *a, const double *x, double *y, bool 
     {
         SpmvPlan &pl = a->plan;
         const bool defer = o.spmv_plan_defer != 0 && a->spmv_calls == 0 && !a->prepared;
-        if (!pl.built || pl.opt_sig != plan_signature(o) || (pl.light && !defer))
+        if (!pl.built || pl.opt_sig != plan_signature(o) || (pl.light && !defer)) {
+#ifndef SPRS_HIP_EMU
+            // a plan build allocates, copies to the host and synchronises: none of that may happen on a stream that is being
+            // captured into a hipGraph (the graph would replay the build, or the capture would be invalidated half-way)
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+                SPRS_FAIL(SPRS_HIP_INVALID_ARG, "SpMV on a capturing stream needs the handle's plan to exist: call sprs_hip_csmat_prepare first");
+            (void)hipGetLastError();
+#endif
             SPRS_TRY((build_plan<IDX, PTR>(a, stream, defer)));
+        }
         ++a->spmv_calls;
         if (!pl.band) SPRS_TRY(get_scratch(pl, stream, &sc));
     }

@@ -43,7 +43,8 @@ class RowShardedSpMV:
         # blocks of the exchange (R-MAT keeps its long rows in front: the last blocks have the most rows) at the price of uneven
         # multiplies.  Chosen on the one-GPU model max(block multiply) + max(y block) / one xGMI link (scripts/virtual_ranks.py,
         # profiles/r13t_virtual_ranks_row_weight_sweep.jsonl): 8 is best up to 4 ranks (0.562 ms against 0.582 at 16), 16 - 24 at 8
-        # ranks (0.358 against 0.378 at 8) — a model, not a multi-GPU measurement.
+        # ranks (0.358 against 0.378 at 8) — a model, not a multi-GPU measurement.  NOTE: the default therefore depends on the world
+        # size (8 up to 4 ranks, 16 above): a caller that must keep one partition across world sizes passes row_weight itself.
         if row_weight is None:
             row_weight = 8.0 if self.world <= 4 else 16.0
         self.row_weight = row_weight
@@ -100,7 +101,15 @@ class RowShardedSpMV:
             if self.y.is_cuda:
                 self._host = self._host.pin_memory()
         h = self._host
-        h[self.r0:self.r1].copy_(self.y[self.r0:self.r1])          # (synchronises with the stream that wrote the block)
+        if self.y.is_cuda:
+            # the previous exchange ended with non-blocking H2D copies out of `h`: they must be done before gloo writes into it
+            # again (the blocking D2H copy below is no such guarantee: it is skipped for an empty block and orders only the
+            # stream it runs on)
+            ev = getattr(self, "_h2d_done", None)
+            if ev is not None:
+                ev.synchronize()
+            torch.cuda.current_stream(self.y.device).synchronize()      # ... and the multiply that wrote the own block
+        h[self.r0:self.r1].copy_(self.y[self.r0:self.r1])
         ops = []
         for peer in range(self.world):
             if peer == self.rank:
@@ -117,6 +126,10 @@ class RowShardedSpMV:
             if peer != self.rank:
                 a, b = self.cuts[peer], self.cuts[peer + 1]
                 self.y[a:b].copy_(h[a:b], non_blocking=True)
+        if self.y.is_cuda:
+            if getattr(self, "_h2d_done", None) is None:
+                self._h2d_done = torch.cuda.Event()
+            self._h2d_done.record(torch.cuda.current_stream(self.y.device))
 
     def _exchange_direct(self):
         if self.y.is_cuda and dist.get_backend(self.group) == "gloo":

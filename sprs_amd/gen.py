@@ -15,6 +15,12 @@ Definitions:
              Each level consumes 16 bits of a SplitMix64 word
              (thresholds round(p * 65536)).
   Laplacian  grid_laplacian of sprs/examples/heat.rs:45-80.
+  uniform    the matrices of the reference's own benches (sprs-rand `rand_csr`,
+             sprs-rand/src/lib.rs:24-88; shapes of sprs-benches/src/main.rs:102-164):
+             ceil(density * rows * cols) entries, the row of each drawn uniformly,
+             the columns of a row drawn uniformly WITHOUT repetition and sorted,
+             values standard normal.  Same distribution as the reference's generator,
+             not the same stream (its rng is Pcg64Mcg seeded from the OS).
 """
 import math
 
@@ -108,6 +114,49 @@ def rmat_csr(n, nnz_per_row, seed=1, value_seed=2, oversample=None, device="cpu"
     nnz = indices.numel()
     data = uniform_05_15(torch.arange(nnz, dtype=torch.int64, device=device), value_seed)
     return indptr.to(ptr_dtype), indices, data
+
+
+def standard_normal(counter, seed):
+    """N(0,1) doubles: Box-Muller on two hashed uniforms (deterministic, device-independent up to libm rounding)."""
+    u1 = (_lsr(splitmix64(counter * 2, seed), 11).to(torch.float64) + 1.0) * (1.0 / (1 << 53))     # (0, 1]
+    u2 = _lsr(splitmix64(counter * 2 + 1, seed), 11).to(torch.float64) * (1.0 / (1 << 53))
+    return torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2.0 * math.pi * u2)
+
+
+def uniform_csr(shape, density, seed=11, value_seed=12, device="cpu", idx_dtype=torch.int64, ptr_dtype=torch.int64):
+    """The role of sprs-rand's rand_csr (sprs-rand/src/lib.rs:24-88): exp_nnz = ceil(density * rows * cols) stored
+    entries; every entry draws its ROW uniformly (rows end up multinomially filled, lib.rs:44-63), then every row draws
+    that many DISTINCT columns uniformly (the reference redraws a column that is already present, lib.rs:68-77 — here all
+    clashes of a round are redrawn together until none is left) and sorts them; values ~ N(0,1) (rand_csr_std).
+    Returns (indptr, indices, data) torch tensors on `device`."""
+    rows, cols = int(shape[0]), int(shape[1])
+    assert 0.0 <= density <= 1.0
+    nnz = int(math.ceil(density * rows * cols))
+    indptr = torch.zeros(rows + 1, dtype=torch.int64, device=device)
+    if nnz == 0 or rows == 0 or cols == 0:
+        return indptr.to(ptr_dtype), torch.zeros(0, dtype=idx_dtype, device=device), torch.zeros(0, dtype=torch.float64, device=device)
+    e = torch.arange(nnz, dtype=torch.int64, device=device)
+    row = _lsr(splitmix64(e, seed), 1) % rows
+    row, _ = torch.sort(row)
+    counts = torch.bincount(row, minlength=rows)
+    if int(counts.max()) > cols:
+        raise ValueError("a row drew more entries than there are columns (density too high for this generator)")
+    torch.cumsum(counts, 0, out=indptr[1:])
+    col = _lsr(splitmix64(e, seed + 1), 1) % cols
+    rnd = 0
+    while True:
+        key, order = torch.sort((row << 32) | col)          # rows are sorted already: this sorts the columns inside each row
+        col = key & 0xFFFFFFFF
+        dup = torch.zeros(nnz, dtype=torch.bool, device=device)
+        dup[1:] = key[1:] == key[:-1]
+        ndup = int(dup.sum())
+        if ndup == 0:
+            break
+        rnd += 1
+        idx = torch.nonzero(dup).flatten()
+        col[idx] = _lsr(splitmix64(idx + nnz * rnd, seed + 1), 1) % cols
+    data = standard_normal(e, value_seed)
+    return indptr.to(ptr_dtype), col.to(idx_dtype), data
 
 
 def grid_laplacian(rows, cols, device="cpu", idx_dtype=torch.int64, ptr_dtype=torch.int64):

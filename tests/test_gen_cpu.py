@@ -47,3 +47,27 @@ def test_balanced_row_blocks():
         assert sum(nnz) == ix.numel()
         longest = int(np.diff(ip.numpy()).max())
         assert max(nnz) <= ix.numel() / parts + longest
+
+
+def test_uniform_csr_is_the_reference_generators_distribution():
+    # sprs-rand/src/lib.rs:24-88 (rand_csr) and its own test random_csr (lib.rs:105-113): density within 0.25 .. 0.35
+    ip, ix, dt = gen.uniform_csr((100, 70), 0.3)
+    assert ix.numel() == int(np.ceil(0.3 * 100 * 70))                    # exactly exp_nnz entries (lib.rs:37-38, 64)
+    oracle.check_structure(70, 100, ip.numpy().astype(np.uint64), ix.numpy().astype(np.uint64))   # rows strictly increasing: no repeated column
+    assert 0.25 < ix.numel() / 7000.0 < 0.35
+    ip0, ix0, dt0 = gen.uniform_csr((0, 0), 0.3)                         # lib.rs:98-103 empty_random_mat
+    assert ix0.numel() == 0 and ip0.numel() == 1
+    # the bench shape rule: nnz_over_rows = 4 -> density 4 / cols (sprs-benches/src/main.rs:178-186)
+    n = 20000
+    ip, ix, dt = gen.uniform_csr((n, n), 4.0 / n, seed=5)
+    lens = np.diff(ip.numpy())
+    assert ix.numel() == 4 * n and abs(lens.mean() - 4.0) < 1e-9 and lens.max() < 20          # multinomial rows, no power law
+    assert abs(float(dt.mean())) < 0.02 and abs(float(dt.std()) - 1.0) < 0.02                  # N(0, 1) values
+    cols = np.bincount(ix.numpy(), minlength=n)
+    assert cols.max() < 25                                                                     # uniform columns
+    ip2, ix2, dt2 = gen.uniform_csr((n, n), 4.0 / n, seed=5)
+    assert torch.equal(ip, ip2) and torch.equal(ix, ix2) and torch.equal(dt, dt2)
+    # a dense-ish small case forces the redraw rounds
+    ip, ix, dt = gen.uniform_csr((50, 24), 0.3, seed=9)
+    oracle.check_structure(24, 50, ip.numpy().astype(np.uint64), ix.numpy().astype(np.uint64))
+    assert ix.numel() == 360

@@ -253,6 +253,31 @@ def test_ragged_and_contract(hip, golden):
     with pytest.raises(SprsHipError) as e:
         prod.csr_mulacc_dense_rowmaj(sq, buf, buf)
     assert e.value.status == _ffi.INVALID_ARG
+    # ... but two element-disjoint views of ONE buffer are legal, as ndarray views are for the reference:
+    # rhs = buf[:, 0:k], out = buf[:, k:2k] with pitch 2k (row-major), and the same as column blocks (column-major)
+    import ctypes as C
+    from sprs_amd.device import DeviceVec
+    sq2 = DeviceCsMat.from_host((6, 6), np.arange(7, dtype=np.uint64), np.array([5, 4, 3, 2, 1, 0], dtype=np.uint64),
+                                np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0]))          # a scaled row reversal
+    for layout, ld in ((_ffi.ROW_MAJOR, 8), (_ffi.COL_MAJOR, 12)):
+        host = rng.standard_normal(48)
+        both = DeviceVec.from_host(host)
+        off = 4 if layout == _ffi.ROW_MAJOR else 6                     # row-major: columns 4..7 of every 8-wide row; column-major: rows 6..11 of every 12-high column
+        _ffi.check(_ffi.lib.sprs_hip_csmat_mulacc_dense_f64(sq2._h, C.c_void_p(both.ptr), 6, 4, layout, ld, C.c_void_p(both.ptr + off * 8), 6, layout, ld, 0, None))
+        got = both.to_host()
+        if layout == _ffi.ROW_MAJOR:
+            v = got.reshape(6, 8)
+            src, dst = host.reshape(6, 8)[:, :4], v[:, 4:]
+            assert np.array_equal(v[:, :4], src)
+        else:
+            v = got.reshape(4, 12).T                                   # 12 x 4, column-major storage
+            src, dst = host.reshape(4, 12).T[:6, :], v[6:, :]
+            assert np.array_equal(v[:6, :], src)
+        assert np.array_equal(dst, np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])[:, None] * src[::-1, :])
+        # the same pitch with views that DO share elements is still refused
+        with pytest.raises(SprsHipError) as e:
+            _ffi.check(_ffi.lib.sprs_hip_csmat_mulacc_dense_f64(sq2._h, C.c_void_p(both.ptr), 6, 4, layout, ld, C.c_void_p(both.ptr + (off - 1) * 8), 6, layout, ld, 0, None))
+        assert e.value.status == _ffi.INVALID_ARG
 
 
 def test_hypersparse_operator_form(hip):
