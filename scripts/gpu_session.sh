@@ -7,6 +7,7 @@
 #   gate:<expr>           pytest -m gpu -k "<expr>" under a short timeout; a failure or a hang ENDS the session (first run of a new kernel)
 #   tests:<expr>          pytest -m gpu -k "<expr>"
 #   bench[:args]          bench.py [args]  (default workload R-MAT 10M SpMV; e.g. bench:--workload\ spgemm5)
+#   (SWEEP_ARGS="--workload rmat1m" / "--row-block 3/8" in the environment: the matrix of the sweep / trace steps)
 #   sweep:<configs>       scripts/spmv_sweep.py on R-MAT 10M; configs separated by '|', each name:opt=val,opt=val
 #   trace:<config>        rocprofv3 --kernel-trace of one sweep config, per-kernel means and the dispatch sequence
 #   stats[:args]          rocprofv3 --kernel-trace --stats of bench.py [args]
@@ -38,8 +39,8 @@ for step in "$@"; do
     gate)   timeout 300 python -m pytest tests -m gpu -x -q -k "$arg" 2>&1 | tail -6
             if [ "${PIPESTATUS[0]}" != 0 ]; then echo "gate failed: session ends here"; exit 1; fi ;;
     bench)  timeout 900 python bench.py $arg 2>/dev/null | tee -a $OUT/bench.jsonl ;;
-    sweep)  IFS='|' read -ra CFG <<< "$arg"; timeout 900 python scripts/spmv_sweep.py --steps 30 --oracle "${CFG[@]}" 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tee -a $OUT/sweep.jsonl ;;
-    trace)  ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace -d /tmp/st -o s -- python $ROOT/scripts/spmv_sweep.py --steps 10 "$arg" > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_seq.py $(prof_db /tmp/st) band_ spmv_ ) 2>&1 | cut -c1-200 | tee -a $OUT/kernel_seq.txt ;;
+    sweep)  IFS='|' read -ra CFG <<< "$arg"; timeout 900 python scripts/spmv_sweep.py --steps 30 --oracle $SWEEP_ARGS "${CFG[@]}" 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tee -a $OUT/sweep.jsonl ;;
+    trace)  ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace -d /tmp/st -o s -- python $ROOT/scripts/spmv_sweep.py --steps 10 $SWEEP_ARGS "$arg" > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_seq.py $(prof_db /tmp/st) band_ spmv_ ) 2>&1 | cut -c1-200 | tee -a $OUT/kernel_seq.txt ;;
     stats)  ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/bench.py --no-cpu-baseline $arg > $OUT/stats_bench.json 2>/dev/null; f=$(prof_db /tmp/st); python3 $ROOT/scripts/rocprof_summary.py $f sprs_hip | grep -E "^kernel|^#|sprs_hip" | cut -c1-190; python3 $ROOT/scripts/rocprof_seq.py $f band_ | cut -c1-200 ) 2>&1 | tee -a $OUT/kernel_stats.txt ;;
     pmc)    PMC_GROUPS=${PMC_GROUPS:-3} bash scripts/gpu_pmc.sh $TAG/pmc $arg > /dev/null 2>&1; grep -E "csrc_sha16|band_|spmv_" $OUT/pmc/pmc_summary.txt | cut -c1-200 ;;
     spgemm) timeout 600 python tests/spgemm_bench.py 1000000 8 8 100 2>&1 | grep -E "seconds" | tee -a $OUT/spgemm.jsonl

@@ -75,7 +75,41 @@ __global__ void bp_classify_kernel(const PTR *__restrict__ indptr, uint64_t rows
     long_flag[r] = is_long ? 1 : 0;
 }
 
-// short rows -> their compact CSR piece (labels instead of columns); long rows -> long_rows
+// short rows -> their compact CSR piece (labels instead of columns); long rows -> long_rows.
+// BUCKETS (round 6): a range of the short piece is `R` entries (cold_tiles wave tiles) walked by one wave; a row that runs on
+// from one range into the next needs a fix-up launch behind the short rows (band_carry_kernel<true>).  Short rows have
+// fewer than `split` entries, so the piece is laid out with gaps instead: the rows whose position d in the gap-free
+// concatenation lies in [k R', (k + 1) R'), R' = R - (split - 1), go to range k, packed from its first entry on — they hold
+// at most R' + split - 1 = R entries — and the rest of the range is padding (value 0, label `cols`: xp[cols] is always 0.0).
+// Every range then begins with a row start: no heads, no records, no launch; the price is (split - 1) / R of the piece
+// (R-MAT 1M: 7 / 512 of 0.9 M entries).  bucket0[k] = position of the first row of bucket k in the gap-free concatenation.
+struct ShortBuckets {
+    const uint64_t *bucket0;     // null: the gap-free layout (rows long enough to make the gaps expensive)
+    uint64_t Rp, R;
+};
+
+__device__ __forceinline__ uint64_t short_place(const ShortBuckets &sb, uint64_t d) {
+    if (!sb.bucket0) return d;
+    const uint64_t k = d / sb.Rp;
+    return k * sb.R + (d - sb.bucket0[k]);
+}
+
+__global__ void bp_bucket_starts_kernel(const uint64_t *__restrict__ short_ptr, uint64_t rows, uint64_t Rp, uint64_t nb,
+                                        uint64_t *__restrict__ bucket0) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    const uint64_t target = k * Rp;
+    uint64_t lo = 0, hi = rows;                       // first row r with short_ptr[r] >= target (short_ptr[rows] = all short entries > target)
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (short_ptr[mid] < target) lo = mid + 1;
+        else hi = mid;
+    }
+    bucket0[k] = short_ptr[lo];
+}
+
+// mode 0: the row lists (s_rowidx, long_rows); mode 1: the entries in the wave-tile layout of band_cold_kernel and the
+// compact rows' positions (s_ptr), both in the layout `sb` describes
 template <typename IDX, typename PTR>
 __global__ void bp_fill_short_kernel(const PTR *__restrict__ indptr, const IDX *__restrict__ indices,
                                      const double *__restrict__ data, uint64_t rows,
@@ -83,27 +117,27 @@ __global__ void bp_fill_short_kernel(const PTR *__restrict__ indptr, const IDX *
                                      const uint64_t *__restrict__ long_pos, const uint32_t *__restrict__ perm,
                                      uint32_t *__restrict__ s_rowidx, uint32_t *__restrict__ s_ptr,
                                      uint32_t *__restrict__ s_cid, double *__restrict__ s_val,
-                                     uint32_t *__restrict__ long_rows, uint64_t split) {
+                                     uint32_t *__restrict__ long_rows, uint64_t split, int mode, ShortBuckets sb, uint64_t padded_total) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > rows) return;
     if (r == rows) {
-        if (!s_cid) s_ptr[short_pos[rows]] = (uint32_t)short_ptr[rows];
+        if (mode == 1) s_ptr[short_pos[rows]] = (uint32_t)padded_total;
         return;
     }
     const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
     if (e == s) return;
     if (e - s >= split) {
-        long_rows[long_pos[r]] = (uint32_t)r;
+        if (mode == 0) long_rows[long_pos[r]] = (uint32_t)r;
         return;
     }
     const uint64_t i = short_pos[r];
-    uint64_t d = short_ptr[r];
-    if (!s_cid) {                 // first call: the row lists
+    if (mode == 0) {
         s_rowidx[i] = (uint32_t)r;
-        s_ptr[i] = (uint32_t)d;
         return;
     }
-    for (uint64_t p = s; p < e; ++p, ++d) {       // second call: the entries, in the wave-tile layout of band_cold_kernel
+    uint64_t d = short_place(sb, short_ptr[r]);
+    s_ptr[i] = (uint32_t)d;
+    for (uint64_t p = s; p < e; ++p, ++d) {
         const uint64_t tile = d / WT;
         const uint32_t t = (uint32_t)(d % WT);
         const uint32_t ll = t / EPL, q = t % EPL;
@@ -312,7 +346,9 @@ struct BandPlan {
     Seg *segs = nullptr;                           // hot segments (workgroup by workgroup), then one segment per cold piece, the short piece
     uint32_t *wg_seg = nullptr;                    // hot workgroup b takes segments wg_seg[b] .. wg_seg[b + 1] - 1
     uint32_t nranges = 0, nsegs = 0, hot_wgs = 0, cold_tiles = 4, hot_run = 4;
-    void *spills = nullptr, *spills_y = nullptr;   // Spill records (device): into the partial sums (hot slices, cold pieces); into y (short rows)
+    void *spills_y = nullptr;                      // Spill records (device) of the short rows: into y, by band_carry_kernel
+    void *rspills = nullptr;                       // RSpill records (device) of the long rows, sorted by row: read by the reduction
+    uint32_t *rsp_off = nullptr;                   // per block of 64 long rows: its first record (+ the end)
     uint32_t nspills = 0, nspills_y = 0;
     bool small = false;                            // few tiles per CU: the launches of one SpMV stay on one stream (the fork / join costs more than it hides)
     ColdGroup *groups = nullptr;
@@ -343,7 +379,8 @@ void band_free(BandPlan *bp) {
     drop(bp->rowidx_all);
     drop(bp->tile_row_all);
     drop(bp->segs);
-    drop(bp->spills);
+    drop(bp->rspills);
+    drop(bp->rsp_off);
     drop(bp->spills_y);
     drop(bp->wg_seg);
     drop(bp->groups);
@@ -470,7 +507,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     SPRS_TRY_HIP(s_ptr_t.alloc((n_short_rows + 1) * 4));
     hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
                        a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)s_rowidx_t.p,
-                       (uint32_t *)s_ptr_t.p, (uint32_t *)nullptr, (double *)nullptr, bp->long_rows, split);
+                       (uint32_t *)s_ptr_t.p, (uint32_t *)nullptr, (double *)nullptr, bp->long_rows, split, 0, ShortBuckets{nullptr, 1, 1}, 0ull);
     SPRS_TRY_HIP(hipGetLastError());
     uint64_t wblocks = (n_long + 3) / 4;
     if (wblocks > 256 * 64) wblocks = 256 * 64;
@@ -490,7 +527,34 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     bp->host_pieces.assign(NP + 1, BandPiece());
     bp->pair_off.assign(NP + 1, 0);
     std::vector<uint64_t> tile_row_off(NP + 2, 0);
-    uint64_t hot_tiles = 0, cold_ent = (nnz_short + WT - 1) / WT * WT, ptr_off = 0, row_off = 0, tile_off = 0;   // the short piece comes first
+    // ---- the short piece's layout (it comes first in the cold arrays): ranges, buckets, padded size ------------------------
+    int ncu_dev = 0;
+    SPRS_TRY_HIP(hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, a->device));
+    if (ncu_dev < 1) ncu_dev = 1;
+    {   // cold pieces + short rows: few tiles (R-MAT 1M: 4 600) want one tile per wave, or the launch is a handful of waves per CU
+        uint64_t gather_tiles = (nnz_short + WT - 1) / WT;
+        for (uint32_t k = (uint32_t)nh; k < NP; ++k) gather_tiles += (starts[k + 1] - starts[k] + WT - 1) / WT;
+        if (o.spmv_band_cold_tiles <= 0 && gather_tiles < 128ull * (uint64_t)ncu_dev) bp->cold_tiles = 1;
+    }
+    TmpBuf bucket0_d;
+    ShortBuckets sbk{nullptr, 1, 1};
+    uint64_t nnz_short_padded = nnz_short;
+    {
+        const uint64_t R = (uint64_t)bp->cold_tiles * WT;
+        if (nnz_short && split >= 2 && (split - 1) * 16 <= R) {            // the gaps cost (split - 1) / R of the piece: at most 6 %
+            const uint64_t Rp = R - (split - 1), nb = (nnz_short + Rp - 1) / Rp;
+            SPRS_TRY_HIP(bucket0_d.alloc((nb + 1) * 8));
+            hipLaunchKernelGGL(bp_bucket_starts_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, (const uint64_t *)short_ptr.u64(),
+                               rows, Rp, nb, bucket0_d.u64());
+            SPRS_TRY_HIP(hipGetLastError());
+            uint64_t last0 = 0;
+            SPRS_TRY_HIP(hipMemcpy(&last0, bucket0_d.u64() + (nb - 1), 8, hipMemcpyDeviceToHost));
+            sbk = ShortBuckets{(const uint64_t *)bucket0_d.u64(), Rp, R};
+            nnz_short_padded = (nb - 1) * R + (nnz_short - last0);          // (the last bucket may be empty: its first row is then "the end")
+            if (nnz_short_padded >= 0xFFFFFFFFull) return SPRS_HIP_OK;
+        }
+    }
+    uint64_t hot_tiles = 0, cold_ent = (nnz_short_padded + WT - 1) / WT * WT, ptr_off = 0, row_off = 0, tile_off = 0;   // the short piece comes first
     uint32_t max_tiles = 0;
     for (uint32_t k = 0; k < NP; ++k) {
         PieceBuild &b = pb[k];
@@ -525,9 +589,9 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     }
     {   // the short piece: index NP
         BandPiece &d = bp->host_pieces[NP];
-        d.nnz = nnz_short;
+        d.nnz = nnz_short_padded;
         d.nr = (uint32_t)n_short_rows;
-        d.ntiles = (uint32_t)((nnz_short + WT - 1) / WT);
+        d.ntiles = (uint32_t)((nnz_short_padded + WT - 1) / WT);
         d.ent0 = 0;
         d.x0 = 0;
         d.to_y = 1;
@@ -546,8 +610,10 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     SPRS_TRY_HIP(hipMemsetAsync(bp->cid_hot, 0, (hot_entries + WT) * 2, stream));
     SPRS_TRY_HIP(hipMalloc((void **)&bp->vals_cold, (cold_ent + WT) * 8));
     SPRS_TRY_HIP(hipMalloc((void **)&bp->cid_cold, (cold_ent + WT) * 4));
-    SPRS_TRY_HIP(hipMemsetAsync(bp->vals_cold, 0, (cold_ent + WT) * 8, stream));   // the padding of every piece reads as (label 0, value 0)
-    SPRS_TRY_HIP(hipMemsetAsync(bp->cid_cold, 0, (cold_ent + WT) * 4, stream));
+    // the padding of every piece — behind its last entry, and the gaps of the short piece — reads as (label `cols`, value 0):
+    // xp[cols] is never written and stays 0.0, so a padding product is 0 * 0 whatever x holds
+    SPRS_TRY_HIP(hipMemsetAsync(bp->vals_cold, 0, (cold_ent + WT) * 8, stream));
+    SPRS_TRY_HIP(hipMemsetD32Async((hipDeviceptr_t)bp->cid_cold, (int)(uint32_t)cols, cold_ent + WT, stream));
     TmpBuf ptr_all;                                                // entry offsets of the compact rows: only the build reads them
     SPRS_TRY_HIP(ptr_all.alloc((ptr_off + n_short_rows + 2) * 4));
     SPRS_TRY_HIP(hipMalloc((void **)&bp->rowidx_all, (row_off + n_short_rows + 1) * 4));
@@ -557,7 +623,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     // short piece: its entries go straight into place (piece 0 of the cold arrays), its row lists are copied
     hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
                        a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)nullptr,
-                       (uint32_t *)nullptr, bp->cid_cold, bp->vals_cold, bp->long_rows, split);
+                       (uint32_t *)s_ptr_t.p, bp->cid_cold, bp->vals_cold, bp->long_rows, split, 1, sbk, nnz_short_padded);
     SPRS_TRY_HIP(hipGetLastError());
     SPRS_TRY_HIP(hipMemcpyAsync((uint32_t *)ptr_all.p + ptr_off, s_ptr_t.p, (n_short_rows + 1) * 4, hipMemcpyDeviceToDevice, stream));
     if (n_short_rows)
@@ -652,13 +718,6 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         split(0, (uint32_t)nh);
         bp->hot_wgs = (uint32_t)(wg_seg.size() - 1);
     }
-    {   // cold pieces + short rows: few tiles (R-MAT 1M: 4 600) want one tile per wave, or the launch is a handful of waves per CU
-        uint64_t gather_tiles = 0;
-        int ncu2 = 0;
-        SPRS_TRY_HIP(hipDeviceGetAttribute(&ncu2, hipDeviceAttributeMultiprocessorCount, a->device));
-        for (uint32_t k = (uint32_t)nh; k <= NP; ++k) gather_tiles += bp->host_pieces[k].ntiles;
-        if (o.spmv_band_cold_tiles <= 0 && gather_tiles < 128ull * (uint64_t)(ncu2 > 0 ? ncu2 : 1)) bp->cold_tiles = 1;
-    }
     for (uint32_t k = (uint32_t)nh; k <= NP; ++k) {
         BandPiece &d = bp->host_pieces[k];
         d.range0 = nranges;
@@ -703,18 +762,39 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         SPRS_TRY_HIP(hipMemcpyAsync(pcs_d.p, bp->host_pieces.data(), bp->host_pieces.size() * sizeof(BandPiece), hipMemcpyHostToDevice, stream));
         SPRS_TRY_HIP(hipMemcpyAsync(poff_d.p, bp->pair_off.data(), bp->pair_off.size() * 8, hipMemcpyHostToDevice, stream));
         SPRS_TRY_HIP(hipMemsetAsync(cnt_d.p, 0, 8, stream));
-        SPRS_TRY_HIP(hipMalloc(&bp->spills, ((uint64_t)nranges + 1) * sizeof(Spill)));     // at most one per range
+        TmpBuf sp_tmp;                                                                       // the long rows' records, as found (any order)
+        SPRS_TRY_HIP(sp_tmp.alloc(((uint64_t)nranges + 1) * sizeof(Spill)));                 // at most one per range
         SPRS_TRY_HIP(hipMalloc(&bp->spills_y, ((uint64_t)nranges + 1) * sizeof(Spill)));
         hipLaunchKernelGGL(bp_spill_kernel, dim3((nranges + 255) / 256), dim3(256), 0, stream, (const Seg *)bp->segs, bp->nsegs, nranges,
                            (const BandPiece *)pcs_d.p, (const uint64_t *)poff_d.p, bp->nh, (const uint16_t *)bp->cid_hot,
-                           (const uint32_t *)bp->cid_cold, (Spill *)bp->spills_y, (Spill *)bp->spills,
+                           (const uint32_t *)bp->cid_cold, (Spill *)bp->spills_y, (Spill *)sp_tmp.p,
                            (unsigned int *)cnt_d.p);
         SPRS_TRY_HIP(hipGetLastError());
         uint32_t counts[2] = {0, 0};
         SPRS_TRY_HIP(hipMemcpy(counts, cnt_d.p, 8, hipMemcpyDeviceToHost));
         bp->nspills_y = counts[0];
         bp->nspills = counts[1];
-        bp->bytes += ((uint64_t)counts[0] + counts[1]) * sizeof(Spill);
+        if (bp->nspills) {
+            // the reduction reads them by row block: sorted by (long row, first carry slot) — the slot order is the order of the
+            // ranges, so a row's heads are added piece by piece, tile by tile — and indexed per block of 64 long rows
+            std::vector<Spill> found(bp->nspills);
+            SPRS_TRY_HIP(hipMemcpy(found.data(), sp_tmp.p, found.size() * sizeof(Spill), hipMemcpyDeviceToHost));
+            std::sort(found.begin(), found.end(), [](const Spill &a, const Spill &b) { return a.j != b.j ? a.j < b.j : a.first < b.first; });
+            const uint32_t nwb = (uint32_t)((n_long + WAVE - 1) / WAVE);
+            std::vector<RSpill> recs(found.size());
+            std::vector<uint32_t> off(nwb + 1, 0u);
+            for (size_t i = 0; i < found.size(); ++i) {
+                recs[i] = RSpill{found[i].j, found[i].first, found[i].n, 0u};
+                ++off[found[i].j / WAVE + 1];
+            }
+            for (uint32_t w = 0; w < nwb; ++w) off[w + 1] += off[w];
+            SPRS_TRY_HIP(hipMalloc(&bp->rspills, recs.size() * sizeof(RSpill)));
+            SPRS_TRY_HIP(hipMalloc((void **)&bp->rsp_off, off.size() * 4));
+            SPRS_TRY_HIP(hipMemcpy(bp->rspills, recs.data(), recs.size() * sizeof(RSpill), hipMemcpyHostToDevice));
+            SPRS_TRY_HIP(hipMemcpy(bp->rsp_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+            bp->bytes += recs.size() * sizeof(RSpill) + off.size() * 4;
+        }
+        bp->bytes += (uint64_t)counts[0] * sizeof(Spill);
     }
     SPRS_TRY_HIP(hipStreamSynchronize(stream));   // plan complete, temporaries (and the host vectors above) may go
     if (getenv("SPRS_HIP_DEBUG")) {
@@ -724,10 +804,11 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
             (k < nh ? hot_pairs : cold_pairs) += bp->host_pieces[k].nr;
         }
         fprintf(stderr, "[sprs_hip band] rows %llu nnz %llu | long rows %llu, short non-empty rows %llu with %llu entries | hot: %u slices of %llu labels, "
-                        "%llu entries, %llu (row,slice) pairs, %u workgroups, %u segments | cold: %u pieces, %llu entries, %llu pairs | %u ranges | plan %.1f MB\n",
+                        "%llu entries, %llu (row,slice) pairs, %u workgroups, %u segments | cold: %u pieces, %llu entries, %llu pairs | %u ranges, %u + %u heads (long rows + short rows), short piece %llu entries laid out in %llu | plan %.1f MB\n",
                 (unsigned long long)rows, (unsigned long long)nnz, (unsigned long long)n_long, (unsigned long long)n_short_rows,
                 (unsigned long long)nnz_short, (unsigned)nh, (unsigned long long)XT, (unsigned long long)hot_nnz, (unsigned long long)hot_pairs,
-                bp->hot_wgs, bp->nsegs, (unsigned)(8 * phases), (unsigned long long)cold_nnz, (unsigned long long)cold_pairs, bp->nranges, bp->bytes / 1e6);
+                bp->hot_wgs, bp->nsegs, (unsigned)(8 * phases), (unsigned long long)cold_nnz, (unsigned long long)cold_pairs, bp->nranges, bp->nspills, bp->nspills_y,
+                (unsigned long long)nnz_short, (unsigned long long)nnz_short_padded, bp->bytes / 1e6);
     }
     guard.p = nullptr;
     *out = bp;
@@ -790,14 +871,12 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     const bool early_reduce = overlap && options().spmv_band_tail != 2;
     const uint64_t span = acc ? bp->cols : (bp->cols > a->rows ? bp->cols : a->rows);
     hipStream_t cstream = overlap ? sc->aux : stream;
-    auto launch_carry = [&](const void *spills, uint32_t n, hipStream_t st) -> int32_t {
+    // the short rows' heads go into y behind them (the long rows' are read by the reduction itself)
+    auto launch_carry_y = [&](hipStream_t st) -> int32_t {
+        const uint32_t n = bp->nspills_y;
         if (!n) return SPRS_HIP_OK;
-        if (spills == bp->spills_y)
-            hipLaunchKernelGGL(band_carry_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)spills, n, (const double *)sc->carry,
-                               sc->partial, y);
-        else
-            hipLaunchKernelGGL(band_carry_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)spills, n, (const double *)sc->carry,
-                               sc->partial, y);
+        hipLaunchKernelGGL(band_carry_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, st, (const Spill *)bp->spills_y, n, (const double *)sc->carry,
+                           sc->partial, y);
         SPRS_TRY_HIP(hipGetLastError());
         return SPRS_HIP_OK;
     };
@@ -831,19 +910,20 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     };
     // blocks [b0, b0 + nb) of the gather launch: cold pieces (partial sums out) below `cut`, short rows (y out) from there on
     const uint32_t cut = bp->has_short_group ? bp->short_first_block : bp->cold_blocks;
+    auto cold_args = [&](uint32_t b0) {
+        return ColdArgs{sc->pieces, bp->groups, bp->ngroups, bp->vals_cold, bp->cid_cold, sc->xp, y, sc->carry, b0, bp->cold_tiles};
+    };
     auto launch_gather = [&](uint32_t b0, uint32_t nb) -> int32_t {
         if (!nb) return SPRS_HIP_OK;
-#define SPRS_COLD(ACCV, TOYV)                                                                                               \
-    hipLaunchKernelGGL((band_cold_kernel<ACCV, TOYV>), dim3(nb), dim3(CNT), 0, cstream, (const BandPiece *)sc->pieces,          \
-                       (const ColdGroup *)bp->groups, bp->ngroups, (const double *)bp->vals_cold,                             \
-                       (const uint32_t *)bp->cid_cold, (const double *)sc->xp, y, sc->carry, b0, bp->cold_tiles)
-        if (b0 < cut) SPRS_COLD(false, false);
-        else if (acc) SPRS_COLD(true, true);
-        else SPRS_COLD(false, true);
-#undef SPRS_COLD
+        const ColdArgs ca = cold_args(b0);
+        if (b0 < cut) hipLaunchKernelGGL((band_cold_kernel<false, false>), dim3(nb), dim3(CNT), 0, cstream, ca);
+        else if (acc) hipLaunchKernelGGL((band_cold_kernel<true, true>), dim3(nb), dim3(CNT), 0, cstream, ca);
+        else hipLaunchKernelGGL((band_cold_kernel<false, true>), dim3(nb), dim3(CNT), 0, cstream, ca);
         SPRS_TRY_HIP(hipGetLastError());
         return SPRS_HIP_OK;
     };
+    // small plans on one stream: the short rows share the reduction's launch (band_tail_kernel)
+    const bool fused_tail = !overlap && bp->small && options().spmv_band_tail != 2 && bp->cold_blocks > cut;
 
     if (split_permute)
         hipLaunchKernelGGL(band_gather_hot_kernel, dim3((bp->hot_labels + 255) / 256), dim3(256), 0, stream, x,
@@ -864,24 +944,30 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     }
     SPRS_TRY(launch_gather(0, cut));
     if (early_reduce) SPRS_TRY_HIP(hipEventRecord(sc->cold_done, sc->aux));
-    SPRS_TRY(launch_gather(cut, bp->cold_blocks - cut));
+    if (!fused_tail) SPRS_TRY(launch_gather(cut, bp->cold_blocks - cut));
     // the short rows' own carries follow them on their stream
-    if (early_reduce) SPRS_TRY(launch_carry(bp->spills_y, bp->nspills_y, sc->aux));
+    if (early_reduce) SPRS_TRY(launch_carry_y(sc->aux));
     if (overlap) SPRS_TRY_HIP(hipEventRecord(sc->join, sc->aux));
     else SPRS_TRY(launch_hot());
     if (overlap) SPRS_TRY_HIP(hipStreamWaitEvent(stream, early_reduce ? sc->cold_done : sc->join, 0));
-    if (!early_reduce) SPRS_TRY(launch_carry(bp->spills_y, bp->nspills_y, stream));
-    SPRS_TRY(launch_carry(bp->spills, bp->nspills, stream));
+    if (!early_reduce && !fused_tail) SPRS_TRY(launch_carry_y(stream));
     const uint32_t nwb = (bp->n_long + WAVE - 1) / WAVE;
     const uint32_t per_xcd = (nwb + 7) / 8;
     const dim3 rg(((per_xcd + 3) / 4) * 8), rb(256);                 // reduction: one wave per block of 64 long rows, XCD by XCD
-    if (acc)
-        hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, stream, (const double *)sc->partial, (const unsigned long long *)bp->wmask,
-                           (const uint32_t *)bp->wbase, (const uint32_t *)bp->long_rows, y, bp->n_long, bp->np_pad, nwb);
-    else
-        hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, stream, (const double *)sc->partial, (const unsigned long long *)bp->wmask,
-                           (const uint32_t *)bp->wbase, (const uint32_t *)bp->long_rows, y, bp->n_long, bp->np_pad, nwb);
-    SPRS_TRY_HIP(hipGetLastError());
+    const ReduceArgs ra{sc->partial, bp->wmask, bp->wbase, bp->long_rows, (const RSpill *)bp->rspills, bp->nspills ? bp->rsp_off : nullptr,
+                        sc->carry, y, bp->n_long, bp->np_pad, nwb};
+    if (fused_tail) {
+        const ColdArgs ca = cold_args(cut);
+        const dim3 tg(rg.x + (bp->cold_blocks - cut));
+        if (acc) hipLaunchKernelGGL(band_tail_kernel<true>, tg, rb, 0, stream, ra, rg.x, ca);
+        else hipLaunchKernelGGL(band_tail_kernel<false>, tg, rb, 0, stream, ra, rg.x, ca);
+        SPRS_TRY_HIP(hipGetLastError());
+        SPRS_TRY(launch_carry_y(stream));                       // (no records unless the short rows are long enough to forbid the gapped layout)
+    } else {
+        if (acc) hipLaunchKernelGGL(band_reduce_kernel<true>, rg, rb, 0, stream, ra);
+        else hipLaunchKernelGGL(band_reduce_kernel<false>, rg, rb, 0, stream, ra);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
     if (early_reduce) SPRS_TRY_HIP(hipStreamWaitEvent(stream, sc->join, 0));   // the short rows and their carries
     return SPRS_HIP_OK;
 }

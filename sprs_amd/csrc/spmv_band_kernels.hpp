@@ -404,16 +404,31 @@ __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kern
 // ---------------------------------------------------------------------------------------------
 // 8 waves per SIMD (64 VGPRs, 20 bytes of scratch): the gathers live on the number of waves in flight, and two such waves fit
 // beside each wave of the hot kernel.  (Non-temporal and device-scope gathers were measured slower in round 2.)
+struct ColdArgs {
+    const BandPiece *pieces;
+    const ColdGroup *groups;
+    uint32_t ngroups;
+    const double *vals;
+    const uint32_t *cid;
+    const double *xp;
+    double *y, *carry;
+    uint32_t block0, ct;
+};
+
 template <bool ACC, bool TOY>
-__global__ __launch_bounds__(CNT, 8) void band_cold_kernel(const BandPiece *__restrict__ pieces, const ColdGroup *__restrict__ groups,
-                                                        uint32_t ngroups, const double *__restrict__ vals,
-                                                        const uint32_t *__restrict__ cid, const double *__restrict__ xp,
-                                                        double *__restrict__ y, double *__restrict__ carry, uint32_t block0, uint32_t ct) {
+__device__ __forceinline__ void band_cold_body(const ColdArgs &ca, uint32_t block, double (*stage_s)[STG]) {
     constexpr int WPB = CNT / WAVE;
-    __shared__ __attribute__((aligned(16))) double stage_s[WPB][STG];
+    const BandPiece *__restrict__ pieces = ca.pieces;
+    const ColdGroup *__restrict__ groups = ca.groups;
+    const uint32_t ngroups = ca.ngroups, ct = ca.ct;
+    const double *__restrict__ vals = ca.vals;
+    const uint32_t *__restrict__ cid = ca.cid;
+    const double *__restrict__ xp = ca.xp;
+    double *__restrict__ y = ca.y;
+    double *__restrict__ carry = ca.carry;
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     double *stage = stage_s[wave];
-    const uint32_t bid = blockIdx.x + block0;
+    const uint32_t bid = block + ca.block0;
     uint32_t g = 0;
     while (g + 1 < ngroups && bid >= groups[g + 1].first_block) ++g;     // block-uniform
     const ColdGroup cg = groups[g];
@@ -477,6 +492,12 @@ __global__ __launch_bounds__(CNT, 8) void band_cold_kernel(const BandPiece *__re
     }
 }
 
+template <bool ACC, bool TOY>
+__global__ __launch_bounds__(CNT, 8) void band_cold_kernel(ColdArgs ca) {
+    __shared__ __attribute__((aligned(16))) double stage_s[CNT / WAVE][STG];
+    band_cold_body<ACC, TOY>(ca, blockIdx.x, stage_s);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The row that is open at the START of a range began in an earlier range: the part of it each range holds (its HEAD) was
 // left in carry[range].  The first range of a run of ranges that continue the same row adds their heads, in range order,
@@ -510,7 +531,14 @@ __device__ __forceinline__ bool range_has_head(const BandPiece &d, uint32_t piec
 struct Spill {
     uint64_t dst;               // index into the partial sums, or row of y for the short piece
     uint32_t first, n;          // carry slots first .. first + n - 1
-    uint32_t to_y, pad;
+    uint32_t to_y, j;           // j: long-row number of the destination (partial-sum records)
+};
+
+// The long rows' records as the REDUCTION reads them (round 6): sorted by (long row, first carry slot) on the host when the plan
+// is built, one offset per block of 64 long rows — the wave that sums a row block adds its rows' heads itself, so that no
+// launch stands between the hot slices and the reduction (band_carry_kernel<false> was 5 - 12 us of latency on that path).
+struct RSpill {
+    uint32_t j, first, n, pad;
 };
 
 __global__ __launch_bounds__(256) void bp_spill_kernel(const Seg *__restrict__ segs, uint32_t nsegs, uint32_t nranges,
@@ -542,7 +570,7 @@ __global__ __launch_bounds__(256) void bp_spill_kernel(const Seg *__restrict__ s
     // front of the reduction)
     const bool first = d.to_y != 0;
     const unsigned int slot = atomicAdd(count + (first ? 0 : 1), 1u);
-    (first ? spills_y : spills_partial)[slot] = Spill{d.to_y ? (uint64_t)d.rowidx[row] : pair_off[rg.piece] + row, i, n, d.to_y, 0u};
+    (first ? spills_y : spills_partial)[slot] = Spill{d.to_y ? (uint64_t)d.rowidx[row] : pair_off[rg.piece] + row, i, n, d.to_y, d.rowidx[row]};
 }
 
 // per SpMV: the heads of a record's ranges are added to the row's sum in range order.  Two launches: the short rows' records
@@ -633,16 +661,31 @@ __device__ __forceinline__ uint32_t band_mask_rank(uint32_t m_lo, uint32_t m_hi,
 // one byte per pair that names the row, added with ds_add_f64 — 4 x fewer, full load instructions: 126 - 134 us against
 // 122 us, and 99 us even with the partial array read front to back and neither adds nor stores (profiles/r13h ... r13k).  The
 // reduction is not bound by its instruction count or its access pattern; the form with the smaller tables stayed.)
+struct ReduceArgs {
+    const double *partial;
+    const unsigned long long *wmask;
+    const uint32_t *wbase, *long_rows;
+    const RSpill *rsp;           // the heads of rows that run on from one range into the next (sorted by long row), or null
+    const uint32_t *rsp_off;     // nwb + 1: the records of row block wb are rsp[rsp_off[wb]] .. rsp[rsp_off[wb + 1] - 1]
+    const double *carry;
+    double *y;
+    uint32_t n_long, np_pad, nwb;
+};
+
 template <bool ACC>
-__global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restrict__ partial, const unsigned long long *__restrict__ wmask,
-                                                          const uint32_t *__restrict__ wbase, const uint32_t *__restrict__ long_rows,
-                                                          double *__restrict__ y, uint32_t n_long, uint32_t np_pad, uint32_t nwb) {
+__device__ __forceinline__ void band_reduce_body(const ReduceArgs &ra, uint32_t block, uint32_t nblocks) {
+    const double *__restrict__ partial = ra.partial;
+    const unsigned long long *__restrict__ wmask = ra.wmask;
+    const uint32_t *__restrict__ wbase = ra.wbase;
+    const uint32_t *__restrict__ long_rows = ra.long_rows;
+    double *__restrict__ y = ra.y;
+    const uint32_t n_long = ra.n_long, np_pad = ra.np_pad, nwb = ra.nwb;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     // wave -> row block: block b runs on XCD b % 8 (observed; only speed depends on it): every XCD gets a CONTIGUOUS range
     // of row blocks (neighbouring row blocks read neighbouring partials of every piece, often the same 128-byte line)
     const uint32_t wpb = blockDim.x / WAVE;
-    const uint32_t xcd = blockIdx.x & 7u, inx = (blockIdx.x >> 3) * wpb + threadIdx.x / WAVE;   // wave number inside the XCD
-    const uint32_t per_xcd = (nwb + 7u) / 8u, waves_per_xcd = (gridDim.x >> 3) * wpb;
+    const uint32_t xcd = block & 7u, inx = (block >> 3) * wpb + threadIdx.x / WAVE;   // wave number inside the XCD
+    const uint32_t per_xcd = (nwb + 7u) / 8u, waves_per_xcd = (nblocks >> 3) * wpb;
     for (uint32_t i = inx; i < per_xcd; i += waves_per_xcd) {            // wave-uniform
         const uint32_t wb = xcd * per_xcd + i;
         if (wb >= nwb) break;
@@ -672,11 +715,54 @@ __global__ __launch_bounds__(256) void band_reduce_kernel(const double *__restri
                 for (int u = 0; u < RU; ++u) s += v[u];              // ascending pieces (absent ones add +0.0)
             }
         }
+        if (ra.rsp_off) {
+            // the heads of the rows of this block that run on from one range into the next (typically 5 - 10 records per block,
+            // one carry each): lane = record, its carries added in slot order; the totals are handed to their rows one after the
+            // other in record order (sorted by row, then slot) — a fixed order, like everything else in this SpMV
+            const uint32_t sb = ra.rsp_off[wb], se = ra.rsp_off[wb + 1];
+            for (uint32_t i0 = sb; i0 < se; i0 += WAVE) {                // wave-uniform
+                const uint32_t i = i0 + lane;
+                uint32_t jl = 0xFFFFFFFFu, first = 0, n = 0;
+                if (i < se) {
+                    const RSpill rec = ra.rsp[i];
+                    jl = rec.j & (WAVE - 1);
+                    first = rec.first;
+                    n = rec.n;
+                }
+                double c = 0.0;
+                for (uint32_t k = 0; k < n; ++k) c += ra.carry[first + k];
+                const uint32_t cnt = se - i0 < (uint32_t)WAVE ? se - i0 : (uint32_t)WAVE;
+                for (uint32_t t = 0; t < cnt; ++t) {                     // wave-uniform
+                    const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)jl, (int)t);
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(c), (int)t);
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(c), (int)t);
+                    if (lane == tj) s += __hiloint2double(hi, lo);
+                }
+            }
+        }
         if (j < n_long) {
             if constexpr (ACC) y[r] = y[r] + s;
             else y[r] = s;
         }
     }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(256) void band_reduce_kernel(ReduceArgs ra) {
+    band_reduce_body<ACC>(ra, blockIdx.x, gridDim.x);
+}
+
+// SMALL PLANS (a few tiles per wave: R-MAT 1M, a rank's block of an 8-way cut): every launch of such an SpMV is a few
+// microseconds of work behind a latency floor of about five, so the launches that do not depend on each other share one.
+// The reduction of the long rows (needs the hot slices and the cold pieces) and the short rows (need only xp; they write their
+// own rows of y) are the two halves of ONE grid: blocks [0, reduce_blocks) reduce, the rest walk the short piece — both are
+// 256-thread workgroups of independent waves within 64 registers.  Round 5 ran them one after the other (short rows 13.8 us,
+// reduction 9.2 us).
+template <bool ACC>
+__global__ __launch_bounds__(CNT, 8) void band_tail_kernel(ReduceArgs ra, uint32_t reduce_blocks, ColdArgs ca) {
+    __shared__ __attribute__((aligned(16))) double stage_s[CNT / WAVE][STG];
+    if (blockIdx.x < reduce_blocks) band_reduce_body<ACC>(ra, blockIdx.x, reduce_blocks);
+    else band_cold_body<ACC, true>(ca, blockIdx.x - reduce_blocks, stage_s);
 }
 
 }  // namespace

@@ -47,6 +47,8 @@ hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s = nullptr);
 hipError_t hipMemset(void *dst, int v, size_t n);
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s = nullptr);
+typedef void *hipDeviceptr_t;
+hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int v, size_t count, hipStream_t s = nullptr);
 hipError_t hipMemset2DAsync(void *dst, size_t pitch, int v, size_t width, size_t height, hipStream_t s = nullptr);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();

@@ -347,6 +347,10 @@ hipError_t hipMemset(void *dst, int v, size_t n) {
     return hipSuccess;
 }
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t) { return hipMemset(dst, v, n); }
+hipError_t hipMemsetD32Async(hipDeviceptr_t dst, int v, size_t count, hipStream_t) {
+    for (size_t i = 0; i < count; ++i) ((int *)dst)[i] = v;
+    return hipSuccess;
+}
 hipError_t hipMemset2DAsync(void *dst, size_t pitch, int v, size_t width, size_t height, hipStream_t) {
     for (size_t r = 0; r < height; ++r) memset((char *)dst + r * pitch, v, width);
     return hipSuccess;
