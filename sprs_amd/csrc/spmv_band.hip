@@ -344,6 +344,7 @@ struct BandPlan {
     uint32_t *cid_cold = nullptr;
     uint32_t *rowidx_all = nullptr, *tile_row_all = nullptr;
     Seg *segs = nullptr;                           // hot segments (workgroup by workgroup), then one segment per cold piece, the short piece
+    HotSeg *hsegs = nullptr;                       // the hot segments again, as the hot kernel reads them (one record each)
     uint32_t *wg_seg = nullptr;                    // hot workgroup b takes segments wg_seg[b] .. wg_seg[b + 1] - 1
     uint32_t nranges = 0, nsegs = 0, hot_wgs = 0, cold_tiles = 4, hot_run = 4;
     void *spills_y = nullptr;                      // Spill records (device) of the short rows: into y, by band_carry_kernel
@@ -379,6 +380,7 @@ void band_free(BandPlan *bp) {
     drop(bp->rowidx_all);
     drop(bp->tile_row_all);
     drop(bp->segs);
+    drop(bp->hsegs);
     drop(bp->rspills);
     drop(bp->rsp_off);
     drop(bp->spills_y);
@@ -730,6 +732,19 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     if (!segs.empty()) SPRS_TRY_HIP(hipMemcpyAsync(bp->segs, segs.data(), segs.size() * sizeof(Seg), hipMemcpyHostToDevice, stream));
     SPRS_TRY_HIP(hipMemcpyAsync(bp->wg_seg, wg_seg.data(), wg_seg.size() * 4, hipMemcpyHostToDevice, stream));
     bp->bytes += segs.size() * sizeof(Seg);
+    if (bp->hot_wgs) {
+        const uint32_t nhs = wg_seg.back();                              // the hot segments come first
+        std::vector<HotSeg> hs(nhs);
+        for (uint32_t i = 0; i < nhs; ++i) {
+            const Seg &sg = segs[i];
+            const BandPiece &d = bp->host_pieces[sg.piece];
+            hs[i] = HotSeg{d.ent0, d.nnz, d.tile_row, bp->pair_off[sg.piece], d.x0, sg.tile0, sg.ntiles, sg.range0, sg.run, 0u, 0u, 0u};
+        }
+        SPRS_TRY_HIP(hipMalloc((void **)&bp->hsegs, (hs.size() + 1) * sizeof(HotSeg)));
+        SPRS_TRY_HIP(hipMemcpyAsync(bp->hsegs, hs.data(), hs.size() * sizeof(HotSeg), hipMemcpyHostToDevice, stream));
+        SPRS_TRY_HIP(hipStreamSynchronize(stream));                      // (hs goes out of scope)
+        bp->bytes += hs.size() * sizeof(HotSeg);
+    }
 
     std::vector<ColdGroup> groups;
     uint32_t blocks = 0;
@@ -896,14 +911,14 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         }
 #endif
         if (bp->xt_log2 == 13)
-            hipLaunchKernelGGL((band_hot_kernel<13>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
-                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg,
-                               (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry,
+            hipLaunchKernelGGL((band_hot_kernel<13>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const HotSeg *)bp->hsegs,
+                               (const uint32_t *)bp->wg_seg,
+                               (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->partial, sc->carry,
                                (uint32_t)options().spmv_band_debug);
         else
-            hipLaunchKernelGGL((band_hot_kernel<14>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const BandPiece *)sc->pieces,
-                               (const Seg *)bp->segs, (const uint32_t *)bp->wg_seg,
-                               (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->carry,
+            hipLaunchKernelGGL((band_hot_kernel<14>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const HotSeg *)bp->hsegs,
+                               (const uint32_t *)bp->wg_seg,
+                               (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->partial, sc->carry,
                                (uint32_t)options().spmv_band_debug);
         SPRS_TRY_HIP(hipGetLastError());
         return SPRS_HIP_OK;
@@ -911,7 +926,7 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     // blocks [b0, b0 + nb) of the gather launch: cold pieces (partial sums out) below `cut`, short rows (y out) from there on
     const uint32_t cut = bp->has_short_group ? bp->short_first_block : bp->cold_blocks;
     auto cold_args = [&](uint32_t b0) {
-        return ColdArgs{sc->pieces, bp->groups, bp->ngroups, bp->vals_cold, bp->cid_cold, sc->xp, y, sc->carry, b0, bp->cold_tiles};
+        return ColdArgs{sc->pieces, bp->groups, bp->ngroups, bp->vals_cold, bp->cid_cold, sc->xp, y, sc->carry, b0, bp->cold_tiles, 0u, BandPiece()};
     };
     auto launch_gather = [&](uint32_t b0, uint32_t nb) -> int32_t {
         if (!nb) return SPRS_HIP_OK;
@@ -957,7 +972,9 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     const ReduceArgs ra{sc->partial, bp->wmask, bp->wbase, bp->long_rows, (const RSpill *)bp->rspills, bp->nspills ? bp->rsp_off : nullptr,
                         sc->carry, y, bp->n_long, bp->np_pad, nwb};
     if (fused_tail) {
-        const ColdArgs ca = cold_args(cut);
+        ColdArgs ca = cold_args(cut);
+        ca.direct = 1u;                                         // the short piece by value: the blocks from `cut` on walk only it
+        ca.piece = bp->host_pieces[bp->npieces];
         const dim3 tg(rg.x + (bp->cold_blocks - cut));
         if (acc) hipLaunchKernelGGL(band_tail_kernel<true>, tg, rb, 0, stream, ra, rg.x, ca);
         else hipLaunchKernelGGL(band_tail_kernel<false>, tg, rb, 0, stream, ra, rg.x, ca);

@@ -56,6 +56,18 @@ struct Seg {
     uint32_t piece, tile0, ntiles, range0, run, pad0, pad1, pad2;
 };
 
+// What the hot kernel needs of a segment, in ONE 64-byte record (one scalar load): until round 6 a workgroup went
+// wg_seg -> segs[s] -> pieces[seg.piece] -> data, three dependent round trips in front of every x tile — nothing beside the
+// 2 180 tiles per CU of R-MAT 10M, a third of the time of a small plan whose workgroups hold 50 tiles in two or three segments.
+struct alignas(64) HotSeg {
+    uint64_t ent0, nnz;                 // of the slice: first entry in the hot arrays, entries
+    const uint32_t *tile_row;           // of the slice
+    uint64_t out_off;                   // the slice's first partial sum in the scratch's array
+    uint32_t x0, tile0, ntiles, range0; // first label of the slice; the segment's tiles; its first range
+    uint32_t run, pad0, pad1, pad2;
+};
+static_assert(sizeof(HotSeg) == 64, "one scalar load");
+
 struct ColdGroup {              // a run of blocks of the cold launch
     uint32_t first_block, first_piece, npieces;   // npieces 8: block b -> piece b % 8 (XCD b % 8); 1: one piece
 };
@@ -270,10 +282,10 @@ __device__ __forceinline__ void band_tile_sums(const double (&pr)[EPL], uint32_t
 // 96 VGPRs: the 4 waves per SIMD of this kernel then leave room for TWO 64-register waves of the gather kernels beside them
 // (at 98 it was one, and the cold launch crawled beside the hot one: 370 us instead of 86 alone, profiles/r05h)
 template <int XT_LOG2>
-__global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kernel(const BandPiece *__restrict__ pieces, const Seg *__restrict__ segs,
+__global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kernel(const HotSeg *__restrict__ hsegs,
                                                                const uint32_t *__restrict__ wg_seg, const double *__restrict__ vals,
                                                                const uint16_t *__restrict__ cid, const double *__restrict__ xp,
-                                                               double *__restrict__ carry, uint32_t dbg) {
+                                                               double *__restrict__ partial, double *__restrict__ carry, uint32_t dbg) {
     constexpr int XT = 1 << XT_LOG2;
     // dynamic LDS (hot_lds_bytes): with the size known at compile time the compiler sees that only 4 waves per SIMD fit and
     // spends up to 128 registers; it is asked for 5 (96 registers) so that two gather waves fit beside each hot wave
@@ -286,9 +298,16 @@ __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kern
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     double *stage = lds + XT + wave * STG;                              // the wave's window for outgoing sums
     const uint32_t s0 = wg_seg[blockIdx.x], s1 = wg_seg[blockIdx.x + 1];
+    HotSeg nxt = hsegs[s0];
     for (uint32_t s = s0; s < s1; ++s) {
-        const Seg seg = segs[s];
-        const PieceView d(pieces[seg.piece]);
+        const HotSeg seg = nxt;
+        if (s + 1 < s1) nxt = hsegs[s + 1];                              // (requested a whole segment before it is needed)
+        struct {
+            const SPRS_GLOBAL_AS uint32_t *tile_row;
+            SPRS_GLOBAL_AS double *out;
+            uint64_t ent0, nnz;
+            uint32_t x0;
+        } d{(const SPRS_GLOBAL_AS uint32_t *)seg.tile_row, (SPRS_GLOBAL_AS double *)(partial + seg.out_off), seg.ent0, seg.nnz, seg.x0};
         if (s != s0) __syncthreads();                                    // every wave is done with the previous x tile
         {   // x tile of the slice -> LDS (xp is padded to a whole number of tiles)
             const dbl2 *src = (const dbl2 *)(xp + d.x0);
@@ -413,6 +432,8 @@ struct ColdArgs {
     const double *xp;
     double *y, *carry;
     uint32_t block0, ct;
+    uint32_t direct;             // 1: the launch walks ONE piece, given by value below (no look-up of group and piece in memory:
+    BandPiece piece;             //    two dependent round trips less in front of the first tile — the short rows of a small plan)
 };
 
 template <bool ACC, bool TOY>
@@ -429,13 +450,21 @@ __device__ __forceinline__ void band_cold_body(const ColdArgs &ca, uint32_t bloc
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     double *stage = stage_s[wave];
     const uint32_t bid = block + ca.block0;
-    uint32_t g = 0;
-    while (g + 1 < ngroups && bid >= groups[g + 1].first_block) ++g;     // block-uniform
-    const ColdGroup cg = groups[g];
-    const uint32_t lb = bid - cg.first_block;
-    const uint32_t pi = cg.first_piece + (cg.npieces == 1 ? 0u : (lb & 7u));
-    const uint32_t r = (cg.npieces == 1 ? lb : (lb >> 3)) * WPB + wave;  // range of the piece (= of its segment)
-    const PieceView d(pieces[pi]);
+    uint32_t r;                                                          // range of the piece (= of its segment)
+    BandPiece pc;
+    if (ca.direct) {
+        pc = ca.piece;
+        r = block * WPB + wave;
+    } else {
+        uint32_t g = 0;
+        while (g + 1 < ngroups && bid >= groups[g + 1].first_block) ++g;     // block-uniform
+        const ColdGroup cg = groups[g];
+        const uint32_t lb = bid - cg.first_block;
+        const uint32_t pi = cg.first_piece + (cg.npieces == 1 ? 0u : (lb & 7u));
+        r = (cg.npieces == 1 ? lb : (lb >> 3)) * WPB + wave;
+        pc = pieces[pi];
+    }
+    const PieceView d(pc);
     const uint32_t t0 = r * ct;
     if (t0 >= d.ntiles) return;                                          // wave-uniform; no workgroup barrier below
     const uint32_t tend = t0 + ct < d.ntiles ? t0 + ct : d.ntiles;
@@ -692,13 +721,36 @@ __device__ __forceinline__ void band_reduce_body(const ReduceArgs &ra, uint32_t 
         const uint64_t j = (uint64_t)wb * WAVE + lane;
         const uint64_t jc = j < n_long ? j : n_long - 1;
         const uint32_t r = long_rows[jc];                               // (requested early: needed only at the very end)
+        // The heads of this block's rows that run on from one range into the next (typically 5 - 10 records per block, one carry
+        // each) do not depend on the partial sums: record and first carry are requested NOW, beside the tables, and consumed at
+        // the end (a small plan's reduction is a chain of dependent round trips, not a stream: every one taken out counts).
+        uint32_t sb = 0, se = 0;
+        if (ra.rsp_off) {
+            sb = ra.rsp_off[wb];
+            se = ra.rsp_off[wb + 1];
+        }
+        uint32_t h_jl = 0xFFFFFFFFu, h_first = 0, h_n = 0;
+        double h_c = 0.0;
+        if (sb + lane < se) {
+            const RSpill rec = ra.rsp[sb + lane];
+            h_jl = rec.j & (WAVE - 1);
+            h_first = rec.first;
+            h_n = rec.n;
+            h_c = ra.carry[h_first];                                    // n >= 1
+        }
         double s = 0.0;
         const unsigned long long *mrow = wmask + (uint64_t)wb * np_pad;
         const uint32_t *brow = wbase + (uint64_t)wb * np_pad;
+        unsigned long long mk_n = lane < np_pad ? mrow[lane] : 0ull;     // lane l: the table row of piece l (np_pad is a multiple of 16)
+        uint32_t bs_n = lane < np_pad ? brow[lane] : 0u;
         for (uint32_t k0 = 0; k0 < np_pad; k0 += WAVE) {
-            const bool in = k0 + lane < np_pad;
-            const unsigned long long mk = in ? mrow[k0 + lane] : 0ull;   // lane l: the table row of piece k0 + l
-            const uint32_t bs = in ? brow[k0 + lane] : 0u;
+            const unsigned long long mk = mk_n;
+            const uint32_t bs = bs_n;
+            if (k0 + WAVE < np_pad) {                                    // the next 64 pieces' table rows: requested in front of this chunk's sums
+                const bool in = k0 + WAVE + lane < np_pad;
+                mk_n = in ? mrow[k0 + WAVE + lane] : 0ull;
+                bs_n = in ? brow[k0 + WAVE + lane] : 0u;
+            }
             const uint32_t mk_lo = (uint32_t)mk, mk_hi = (uint32_t)(mk >> 32);
 #pragma unroll
             for (int kk = 0; kk < WAVE; kk += RU) {
@@ -715,29 +767,28 @@ __device__ __forceinline__ void band_reduce_body(const ReduceArgs &ra, uint32_t 
                 for (int u = 0; u < RU; ++u) s += v[u];              // ascending pieces (absent ones add +0.0)
             }
         }
-        if (ra.rsp_off) {
-            // the heads of the rows of this block that run on from one range into the next (typically 5 - 10 records per block,
-            // one carry each): lane = record, its carries added in slot order; the totals are handed to their rows one after the
-            // other in record order (sorted by row, then slot) — a fixed order, like everything else in this SpMV
-            const uint32_t sb = ra.rsp_off[wb], se = ra.rsp_off[wb + 1];
-            for (uint32_t i0 = sb; i0 < se; i0 += WAVE) {                // wave-uniform
-                const uint32_t i = i0 + lane;
-                uint32_t jl = 0xFFFFFFFFu, first = 0, n = 0;
-                if (i < se) {
-                    const RSpill rec = ra.rsp[i];
-                    jl = rec.j & (WAVE - 1);
-                    first = rec.first;
-                    n = rec.n;
+        // the heads: lane = record, its carries added in slot order; the totals are handed to their rows one after the other in
+        // record order (sorted by row, then slot) — a fixed order, like everything else in this SpMV
+        for (uint32_t i0 = sb; i0 < se; i0 += WAVE) {                    // wave-uniform
+            if (i0 != sb) {                                              // (more than 64 records in one row block: rare)
+                h_jl = 0xFFFFFFFFu;
+                h_n = 0;
+                h_c = 0.0;
+                if (i0 + lane < se) {
+                    const RSpill rec = ra.rsp[i0 + lane];
+                    h_jl = rec.j & (WAVE - 1);
+                    h_first = rec.first;
+                    h_n = rec.n;
+                    h_c = ra.carry[h_first];
                 }
-                double c = 0.0;
-                for (uint32_t k = 0; k < n; ++k) c += ra.carry[first + k];
-                const uint32_t cnt = se - i0 < (uint32_t)WAVE ? se - i0 : (uint32_t)WAVE;
-                for (uint32_t t = 0; t < cnt; ++t) {                     // wave-uniform
-                    const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)jl, (int)t);
-                    const int lo = __builtin_amdgcn_readlane(__double2loint(c), (int)t);
-                    const int hi = __builtin_amdgcn_readlane(__double2hiint(c), (int)t);
-                    if (lane == tj) s += __hiloint2double(hi, lo);
-                }
+            }
+            for (uint32_t k = 1; k < h_n; ++k) h_c += ra.carry[h_first + k];
+            const uint32_t cnt = se - i0 < (uint32_t)WAVE ? se - i0 : (uint32_t)WAVE;
+            for (uint32_t t = 0; t < cnt; ++t) {                         // wave-uniform
+                const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)h_jl, (int)t);
+                const int lo = __builtin_amdgcn_readlane(__double2loint(h_c), (int)t);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(h_c), (int)t);
+                if (lane == tj) s += __hiloint2double(hi, lo);
             }
         }
         if (j < n_long) {
