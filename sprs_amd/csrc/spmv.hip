@@ -574,7 +574,7 @@ static int32_t build_sliced(sprs_hip_csmat *a, uint64_t nnz_short, uint64_t n_lo
 // the options a plan depends on: a handle rebuilds its plan when one of them changes
 static uint64_t plan_signature(const Options &o) {
     const int64_t v[] = {o.spmv_xcs, o.spmv_xcs_split, o.spmv_xcs_idx32, o.spmv_sort_tiles, o.spmv_relabel, o.spmv_tile, o.spmv_band,
-                         o.spmv_band_hot, o.spmv_band_tile, o.spmv_band_phases, o.spmv_band_split, o.spmv_band_rounds, o.spmv_band_cold_tiles, o.spmv_band_hot_run, o.spmv_band_share};
+                         o.spmv_band_hot, o.spmv_band_tile, o.spmv_band_phases, o.spmv_band_split, o.spmv_band_rounds, o.spmv_band_cold_tiles, o.spmv_band_hot_run, o.spmv_band_share, o.spmv_band_balance};
     uint64_t h = 0xcbf29ce484222325ull;
     for (int64_t x : v) h = (h ^ (uint64_t)x) * 0x100000001b3ull;
     return h | 1ull;

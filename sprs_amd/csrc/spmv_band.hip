@@ -108,6 +108,19 @@ __global__ void bp_bucket_starts_kernel(const uint64_t *__restrict__ short_ptr, 
     bucket0[k] = short_ptr[lo];
 }
 
+// Number of a long row in the plan's row lists.  The reduction takes the long rows in blocks of 64 (one wave each).  In natural
+// order the first block of a power-law matrix is 64 hub rows — on R-MAT 1M 266 of the 27 000 heads of rows that run on from one
+// range into the next, and most (row, slice) pairs — and its wave is the reduction's critical path.  The first 61 blocks' rows
+// are therefore dealt round-robin (61: the hubs of an R-MAT matrix sit at the powers of two and their sums; a power-of-two
+// stride would put them into one block again): row j < 64 * B goes to lane j / B of block j % B.  Every table of the plan is
+// built from this numbering (long_rows[j] is the row), so nothing else knows about it.
+__device__ __forceinline__ uint64_t long_row_number(uint64_t j, uint64_t n_long) {
+    const uint64_t full = n_long / WAVE;
+    const uint64_t B = full < 61 ? full : 61;
+    if (B < 2 || j >= B * WAVE) return j;
+    return (j % B) * WAVE + j / B;
+}
+
 // mode 0: the row lists (s_rowidx, long_rows); mode 1: the entries in the wave-tile layout of band_cold_kernel and the
 // compact rows' positions (s_ptr), both in the layout `sb` describes
 template <typename IDX, typename PTR>
@@ -117,7 +130,8 @@ __global__ void bp_fill_short_kernel(const PTR *__restrict__ indptr, const IDX *
                                      const uint64_t *__restrict__ long_pos, const uint32_t *__restrict__ perm,
                                      uint32_t *__restrict__ s_rowidx, uint32_t *__restrict__ s_ptr,
                                      uint32_t *__restrict__ s_cid, double *__restrict__ s_val,
-                                     uint32_t *__restrict__ long_rows, uint64_t split, int mode, ShortBuckets sb, uint64_t padded_total) {
+                                     uint32_t *__restrict__ long_rows, uint64_t split, int mode, ShortBuckets sb, uint64_t padded_total,
+                                     uint64_t n_long) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r > rows) return;
     if (r == rows) {
@@ -127,7 +141,7 @@ __global__ void bp_fill_short_kernel(const PTR *__restrict__ indptr, const IDX *
     const uint64_t s = (uint64_t)indptr[r], e = (uint64_t)indptr[r + 1];
     if (e == s) return;
     if (e - s >= split) {
-        if (mode == 0) long_rows[long_pos[r]] = (uint32_t)r;
+        if (mode == 0) long_rows[long_row_number(long_pos[r], n_long)] = (uint32_t)r;
         return;
     }
     const uint64_t i = short_pos[r];
@@ -509,7 +523,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     SPRS_TRY_HIP(s_ptr_t.alloc((n_short_rows + 1) * 4));
     hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
                        a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)s_rowidx_t.p,
-                       (uint32_t *)s_ptr_t.p, (uint32_t *)nullptr, (double *)nullptr, bp->long_rows, split, 0, ShortBuckets{nullptr, 1, 1}, 0ull);
+                       (uint32_t *)s_ptr_t.p, (uint32_t *)nullptr, (double *)nullptr, bp->long_rows, split, 0, ShortBuckets{nullptr, 1, 1}, 0ull, n_long);
     SPRS_TRY_HIP(hipGetLastError());
     uint64_t wblocks = (n_long + 3) / 4;
     if (wblocks > 256 * 64) wblocks = 256 * 64;
@@ -625,7 +639,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     // short piece: its entries go straight into place (piece 0 of the cold arrays), its row lists are copied
     hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
                        a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)nullptr,
-                       (uint32_t *)s_ptr_t.p, bp->cid_cold, bp->vals_cold, bp->long_rows, split, 1, sbk, nnz_short_padded);
+                       (uint32_t *)s_ptr_t.p, bp->cid_cold, bp->vals_cold, bp->long_rows, split, 1, sbk, nnz_short_padded, n_long);
     SPRS_TRY_HIP(hipGetLastError());
     SPRS_TRY_HIP(hipMemcpyAsync((uint32_t *)ptr_all.p + ptr_off, s_ptr_t.p, (n_short_rows + 1) * 4, hipMemcpyDeviceToDevice, stream));
     if (n_short_rows)
@@ -695,6 +709,23 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : (small_hot ? 2 : 3);
         if (o.spmv_band_hot_run <= 0 && small_hot) bp->hot_run = 1;
         bp->small = small_hot;
+        // SHARES BY COST (small plans; option spmv_band_balance): a tile of a late slice holds ten times the row ends of an early one
+        // and takes up to three times as long (every row end is a partial sum to scan, stage and store: 658 us against 470 us without
+        // any on R-MAT 10M's 72 per tile), so equal tile counts leave the workgroups of the late slices running when the others are
+        // done.  Beside the gather kernels of a big plan that tail is filled (profiles/r06a: hot kernel alone 681 against 736 us, the
+        // overlapped SpMV unchanged); a small plan's hot kernel runs ALONE and its tail is the SpMV's.  cost(tile) = 180 + row ends.
+        std::vector<uint64_t> cost_pre;                               // cost of the hot tiles before tile t (slice after slice)
+        const bool balance = o.spmv_band_balance == 1 || (o.spmv_band_balance == 0 && small_hot);
+        if (balance && o.spmv_band_share <= 0) {
+            SPRS_TRY_HIP(hipStreamSynchronize(stream));               // bp_tile_rows_kernel
+            std::vector<uint32_t> tr(tile_off + 1);
+            SPRS_TRY_HIP(hipMemcpy(tr.data(), bp->tile_row_all, tr.size() * 4, hipMemcpyDeviceToHost));
+            cost_pre.assign(1, 0ull);
+            for (uint32_t k = 0; k < nh; ++k) {
+                const uint32_t *t = tr.data() + tile_row_off[k];
+                for (uint32_t c = 0; c < bp->host_pieces[k].ntiles; ++c) cost_pre.push_back(cost_pre.back() + 180ull + (uint64_t)(t[c + 1] - t[c]));
+            }
+        }
         auto split = [&](uint32_t k_lo, uint32_t k_hi) {             // equal shares of the tiles of slices [k_lo, k_hi) per workgroup
             uint64_t tiles = 0;
             for (uint32_t k = k_lo; k < k_hi; ++k) tiles += bp->host_pieces[k].ntiles;
@@ -703,11 +734,20 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
             if (nwg > tiles) nwg = tiles;
             uint64_t Q = (tiles + nwg - 1) / nwg;                     // wave tiles per workgroup
             if (o.spmv_band_share > 0) Q = (uint64_t)o.spmv_band_share;   // (A/B: the share sets how far apart the workgroups stream)
+            // share b = tiles [cut(b), cut(b + 1)): equal counts, or equal cost (the first tile whose cost prefix reaches b / nwg of the total)
+            const uint64_t nshares = cost_pre.empty() ? (tiles + Q - 1) / Q : nwg;
+            auto cut = [&](uint64_t b) -> uint64_t {
+                if (cost_pre.empty()) return std::min(tiles, b * Q);
+                if (b >= nshares) return tiles;
+                const uint64_t target = (uint64_t)((long double)cost_pre.back() * (long double)b / (long double)nshares);
+                return (uint64_t)(std::lower_bound(cost_pre.begin(), cost_pre.end(), target) - cost_pre.begin());
+            };
             uint32_t k = k_lo;
             uint64_t k_first = 0;                                     // number (inside the group) of slice k's first tile
-            for (uint64_t b = 0; b * Q < tiles; ++b) {
-                uint64_t t = b * Q;
-                const uint64_t t_end = std::min(tiles, t + Q);
+            for (uint64_t b = 0; b < nshares; ++b) {
+                uint64_t t = cut(b);
+                const uint64_t t_end = std::min(tiles, cut(b + 1));
+                if (t >= t_end) continue;                             // (an empty share: more workgroups than tiles of that cost)
                 while (t < t_end) {
                     while (k_first + bp->host_pieces[k].ntiles <= t) k_first += bp->host_pieces[k++].ntiles;   // (slices without tiles are skipped)
                     const uint64_t s_end = std::min(t_end, k_first + bp->host_pieces[k].ntiles);
@@ -796,11 +836,15 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
             SPRS_TRY_HIP(hipMemcpy(found.data(), sp_tmp.p, found.size() * sizeof(Spill), hipMemcpyDeviceToHost));
             std::sort(found.begin(), found.end(), [](const Spill &a, const Spill &b) { return a.j != b.j ? a.j < b.j : a.first < b.first; });
             const uint32_t nwb = (uint32_t)((n_long + WAVE - 1) / WAVE);
-            std::vector<RSpill> recs(found.size());
+            // (a lane adds the carries of its record one after the other: a hub row's run of 40 ranges is cut into records of 8)
+            std::vector<RSpill> recs;
+            recs.reserve(found.size() + found.size() / 8);
             std::vector<uint32_t> off(nwb + 1, 0u);
             for (size_t i = 0; i < found.size(); ++i) {
-                recs[i] = RSpill{found[i].j, found[i].first, found[i].n, 0u};
-                ++off[found[i].j / WAVE + 1];
+                for (uint32_t k = 0; k < found[i].n; k += 8) {
+                    recs.push_back(RSpill{found[i].j, found[i].first + k, std::min(8u, found[i].n - k), 0u});
+                    ++off[found[i].j / WAVE + 1];
+                }
             }
             for (uint32_t w = 0; w < nwb; ++w) off[w + 1] += off[w];
             SPRS_TRY_HIP(hipMalloc(&bp->rspills, recs.size() * sizeof(RSpill)));
@@ -910,17 +954,53 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
             }
         }
 #endif
+        unsigned long long *prof = nullptr;
+        if (DEVTOOLS && (options().spmv_band_debug & 16)) {
+            static unsigned long long *buf = nullptr;
+            static uint32_t cap = 0;
+            if (cap < bp->hot_wgs) {
+                if (buf) (void)hipFree(buf);
+                cap = bp->hot_wgs;
+                SPRS_TRY_HIP(hipMalloc((void **)&buf, (size_t)cap * 24));
+            }
+            prof = buf;
+        }
         if (bp->xt_log2 == 13)
             hipLaunchKernelGGL((band_hot_kernel<13>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const HotSeg *)bp->hsegs,
                                (const uint32_t *)bp->wg_seg,
                                (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->partial, sc->carry,
-                               (uint32_t)options().spmv_band_debug);
+                               (uint32_t)options().spmv_band_debug, prof);
         else
             hipLaunchKernelGGL((band_hot_kernel<14>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const HotSeg *)bp->hsegs,
                                (const uint32_t *)bp->wg_seg,
                                (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->partial, sc->carry,
-                               (uint32_t)options().spmv_band_debug);
+                               (uint32_t)options().spmv_band_debug, prof);
         SPRS_TRY_HIP(hipGetLastError());
+        if (DEVTOOLS && prof && getenv("SPRS_HIP_HOTPROF")) {      // (synchronous: a developer printout, not a timing run)
+            SPRS_TRY_HIP(hipStreamSynchronize(stream));
+            std::vector<unsigned long long> t((size_t)bp->hot_wgs * 3);
+            SPRS_TRY_HIP(hipMemcpy(t.data(), prof, t.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (uint32_t b = 0; b < bp->hot_wgs; ++b) {
+                t0 = std::min(t0, t[3 * b]);
+                t1 = std::max(t1, t[3 * b + 2]);
+            }
+            std::vector<double> st, xw, du, en;
+            for (uint32_t b = 0; b < bp->hot_wgs; ++b) {
+                st.push_back((t[3 * b] - t0) * 0.01);
+                xw.push_back((t[3 * b + 1] - t[3 * b]) * 0.01);
+                du.push_back((t[3 * b + 2] - t[3 * b]) * 0.01);
+                en.push_back((t[3 * b + 2] - t0) * 0.01);
+            }
+            auto q = [](std::vector<double> v, double f) {
+                std::sort(v.begin(), v.end());
+                return v[(size_t)(f * (v.size() - 1))];
+            };
+            fprintf(stderr, "[hot_prof] %u workgroups, span %.1f us | start min/med/p90/max %.1f %.1f %.1f %.1f | first x tile after %.1f %.1f %.1f %.1f | "
+                            "duration %.1f %.1f %.1f %.1f | end %.1f %.1f %.1f %.1f\n", bp->hot_wgs, (t1 - t0) * 0.01,
+                    q(st, 0), q(st, .5), q(st, .9), q(st, 1), q(xw, 0), q(xw, .5), q(xw, .9), q(xw, 1), q(du, 0), q(du, .5), q(du, .9), q(du, 1),
+                    q(en, 0), q(en, .5), q(en, .9), q(en, 1));
+        }
         return SPRS_HIP_OK;
     };
     // blocks [b0, b0 + nb) of the gather launch: cold pieces (partial sums out) below `cut`, short rows (y out) from there on

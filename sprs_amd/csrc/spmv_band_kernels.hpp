@@ -285,8 +285,14 @@ template <int XT_LOG2>
 __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kernel(const HotSeg *__restrict__ hsegs,
                                                                const uint32_t *__restrict__ wg_seg, const double *__restrict__ vals,
                                                                const uint16_t *__restrict__ cid, const double *__restrict__ xp,
-                                                               double *__restrict__ partial, double *__restrict__ carry, uint32_t dbg) {
+                                                               double *__restrict__ partial, double *__restrict__ carry, uint32_t dbg,
+                                                               unsigned long long *__restrict__ prof) {
     constexpr int XT = 1 << XT_LOG2;
+    // developer builds, option spmv_band_debug & 16 (env SPRS_HIP_HOTPROF): when does each workgroup start, see its first x tile,
+    // and end (100 MHz wall clock) — is the hot kernel's time its work or its tail?
+    if constexpr (DEVTOOLS) {
+        if (prof && threadIdx.x == 0) prof[3 * blockIdx.x] = (unsigned long long)wall_clock64();
+    }
     // dynamic LDS (hot_lds_bytes): with the size known at compile time the compiler sees that only 4 waves per SIMD fit and
     // spends up to 128 registers; it is asked for 5 (96 registers) so that two gather waves fit beside each hot wave
 #ifdef SPRS_HIP_EMU
@@ -333,6 +339,9 @@ __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kern
         uint32_t t = r * run;                                            // current tile, relative to the segment
         if (t < n) request(seg.tile0 + t);                               // the first tile is requested before the barrier
         __syncthreads();                                                 // xs complete
+        if constexpr (DEVTOOLS) {
+            if (prof && threadIdx.x == 0 && s == s0) prof[3 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+        }
         double open = 0.0;
         bool mine = false;
         uint32_t last = 0;
@@ -409,6 +418,12 @@ __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kern
             if (DEVTOOLS && (dbg & 1u)) return;
             d.out[row] = v;
         });
+    }
+    if constexpr (DEVTOOLS) {
+        if (prof) {
+            __syncthreads();
+            if (threadIdx.x == 0) prof[3 * blockIdx.x + 2] = (unsigned long long)wall_clock64();
+        }
     }
 }
 
