@@ -706,7 +706,10 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         // (small plans: 4 rounds until round 4; 2 measured better with split 8, profiles/r10u.  Big plans: 2 until round 5; with the
         // hot kernel no longer waiting for its stores 3 rounds measured 3 - 5 % better on three boxes — 1.046 / 1.049 - 1.089 / 1.059 - 1.098
         // against 1.081 / 1.114 - 1.117 / 1.080 - 1.116 ms — and 4 rounds 5 % worse, profiles/r13b, r13n, r13o)
-        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds : (small_hot ? 2 : 3);
+        // (round 6, small plans: with the shares cut by modelled cost ONE round is best — 0.0717 against 0.0731 ms with two and 0.0784 with
+        // three on R-MAT 1M, profiles/r15d: every workgroup pays ~5 us for its first x tile, 256 CUs asking for theirs at once)
+        const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds
+                                : (small_hot ? (o.spmv_band_balance == 2 ? 2 : 1) : 3);
         if (o.spmv_band_hot_run <= 0 && small_hot) bp->hot_run = 1;
         bp->small = small_hot;
         // SHARES BY COST (small plans; option spmv_band_balance): a tile of a late slice holds ten times the row ends of an early one
