@@ -357,10 +357,11 @@ def main():
     ap.add_argument("--workload", default="rmat10m")
     ap.add_argument("--idx-bytes", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", default="lib", choices=("torch", "lib"),
-                    help="N > 1: all-gather-v of y inside the library (sprs_hip_dist_*: sub-block pipeline, RCCL loaded by the "
-                         "library itself; default, what `value` times) or through torch.distributed (grouped send/recv on RCCL); "
-                         "the other route and the multiply without any exchange are timed after the K steps and reported beside it")
+    ap.add_argument("--exchange", default="lib", choices=("torch", "lib", "peer"),
+                    help="N > 1: all-gather-v of y inside the library over RCCL (sprs_hip_dist_*: sub-block pipeline, grouped ncclSend / "
+                         "ncclRecv; default, what `value` times), inside the library by stores into the peers' windows over xGMI (peer: "
+                         "hand-written, no RCCL call on the data path) or through torch.distributed (grouped send/recv on RCCL); the "
+                         "other routes and the multiply without any exchange are timed after the K steps and reported beside it")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="N > 1: torch.distributed backend.  nccl = RCCL over xGMI (the product path).  gloo: the y blocks are staged "
                          "through host memory — for running the N > 1 code path (self-launch, partition, RowShardedSpMV on the HIP "
@@ -545,24 +546,38 @@ def main():
         return sh.y
 
     step = torch_step
-    if world > 1 and args.backend != "nccl":
-        if args.exchange == "lib" and rank == 0:
-            print("bench.py: --backend gloo: the library's RCCL exchange is not attempted; timing the torch.distributed route "
-                  "(y blocks staged through host memory)", file=sys.stderr)
-    elif world > 1:
-        try:
-            from sprs_amd.dist import DistSpMV
-            rb = sh.block
-            libdist = DistSpMV((n, n), DeviceCsMat.wrap_torch((rb[0], rb[1]), rb[2], rb[3], rb[4]), sh.cuts, rank, world,
-                               unique_id=DistSpMV.broadcast_id(dev), nsub=2)
-            yv_all = DeviceVec.borrow(sh.y)
-        except Exception as e:                          # the library route needs librccl: say so, fall back to the torch route
+    peerdist = None                                     # the library handle on the peer-store route (its own handle: the route is per handle)
+    if world > 1:
+        from sprs_amd.dist import DistSpMV
+        rb = sh.block
+        yv_all = DeviceVec.borrow(sh.y)
+        if args.backend != "nccl":
             if args.exchange == "lib" and rank == 0:
-                print("bench.py: library exchange unavailable (%s); timing the torch.distributed route" % repr(e)[:200], file=sys.stderr)
-            libdist = None
+                print("bench.py: --backend gloo: the library's RCCL exchange is not attempted; timing the torch.distributed route "
+                      "(y blocks staged through host memory)", file=sys.stderr)
+        else:
+            try:
+                libdist = DistSpMV((n, n), DeviceCsMat.wrap_torch((rb[0], rb[1]), rb[2], rb[3], rb[4]), sh.cuts, rank, world,
+                                   unique_id=DistSpMV.broadcast_id(dev), nsub=2)
+            except Exception as e:                      # the library route needs librccl: say so, fall back to the torch route
+                if args.exchange == "lib" and rank == 0:
+                    print("bench.py: library exchange unavailable (%s); timing the torch.distributed route" % repr(e)[:200], file=sys.stderr)
+                libdist = None
+        try:   # the peer-store route needs no RCCL: window handles through torch.distributed (any backend), also for ranks sharing a device
+            peerdist = DistSpMV((n, n), DeviceCsMat.wrap_torch((rb[0], rb[1]), rb[2], rb[3], rb[4]), sh.cuts, rank, world,
+                                unique_id=None, nsub=2)
+            peerdist.connect_peers(dev).set_route("peer")
+        except Exception as e:
+            if rank == 0:
+                print("bench.py: peer-store exchange unavailable (%s)" % repr(e)[:200], file=sys.stderr)
+            peerdist = None
 
     def lib_step(xv):                                   # multiply + exchange inside the library, sub-blocks pipelined
         libdist.spmv(DeviceVec.borrow(xv), yv_all, stream=stream)
+        return sh.y
+
+    def peer_step(xv):                                  # the same with stores into the peers' windows instead of ncclSend / ncclRecv
+        peerdist.spmv(DeviceVec.borrow(xv), yv_all, stream=stream)
         return sh.y
 
     routes_check = None
@@ -571,29 +586,44 @@ def main():
         # gives what one step through torch.distributed gives (the two exchanges move the same blocks; the multiply is the same
         # kernel) — otherwise all ranks time the torch route together and the line says so
         import torch.distributed as dist
-        flag = torch.tensor([1.0 if libdist is not None else 0.0], dtype=torch.float64, device=cdev)
+        flag = torch.tensor([1.0 if libdist is not None else 0.0, 1.0 if peerdist is not None else 0.0], dtype=torch.float64, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag.item()) < 0.5:
+        if float(flag[0].item()) < 0.5:
             libdist = None
-        if libdist is not None:
+        if float(flag[1].item()) < 0.5:
+            peerdist = None
+        routes_check = {}
+        for label, have, fn in (("lib", libdist is not None, lib_step), ("peer", peerdist is not None, peer_step)):
+            if not have:
+                continue
             worst = torch.tensor([float("inf")], dtype=torch.float64, device=dev)
             try:
                 y_t = torch_step(x).clone()
-                y_l = lib_step(x)
+                sh.y.fill_(float("nan"))                # the route under test must write every row itself
+                y_l = fn(x)
                 torch.cuda.synchronize()
                 worst = ((y_l - y_t).abs() / y_t.abs().clamp_min(1e-300)).max().reshape(1)
                 worst = torch.where(torch.isfinite(worst), worst, torch.full_like(worst, float("inf")))
                 del y_t
             except Exception as e:
                 if rank == 0:
-                    print("bench.py: library exchange failed in the cross-check (%s)" % repr(e)[:200], file=sys.stderr)
+                    print("bench.py: %s exchange failed in the cross-check (%s)" % (label, repr(e)[:200]), file=sys.stderr)
+            worst = worst.to(cdev)
             dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-            routes_check = {"lib_vs_torch_max_rel_diff": float(worst.item()), "tolerance": 1e-10, "ok": bool(float(worst.item()) <= 1e-10)}
-            if not routes_check["ok"]:
-                libdist = None
-    use_lib = libdist is not None and args.exchange == "lib"
+            routes_check[label + "_vs_torch_max_rel_diff"] = float(worst.item())
+            if not float(worst.item()) <= 1e-10:
+                if label == "lib":
+                    libdist = None
+                else:
+                    peerdist = None
+        if routes_check:
+            routes_check.update({"tolerance": 1e-10, "ok": bool(all(v <= 1e-10 for k, v in routes_check.items() if k.endswith("_diff")))})
+        else:
+            routes_check = None
+    use_lib = (libdist is not None and args.exchange == "lib") or (peerdist is not None and args.exchange == "peer")
     if use_lib:
-        step = lib_step
+        step = lib_step if args.exchange == "lib" else peer_step
+        lib_step_timed = step
     del indptr, indices, data   # only the rank's block stays resident
     torch.cuda.empty_cache()
 
@@ -629,7 +659,7 @@ def main():
             flush.add_(1.0)   # reads and writes 1 GiB: evicts L2 and the Infinity Cache; part of ms_per_step, not of the kernel events
         ev[s][0].record(stream)
         if use_lib:
-            lib_step(x)                                 # multiply + exchange inside the library, pipelined
+            lib_step_timed(x)                           # multiply + exchange inside the library (RCCL or peer stores), pipelined
             ev[s][1].record(stream)
         else:
             sh.local_spmv(sh.block, x, sh.y[sh.r0:sh.r1])   # kernel(s) on `stream`, bracketed by HIP events
@@ -665,7 +695,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return round(float(tt.item()) * 1e3 / k, 5)
         k2 = max(3, args.steps // 2)
-        exchange_times = {"timed_route": "lib" if use_lib else "torch", "steps_each": k2, "backend": args.backend,
+        exchange_times = {"timed_route": args.exchange if use_lib else "torch", "steps_each": k2, "backend": args.backend,
                           "devices": args.devices or ",".join(str(i) for i in range(world))}
         if libdist is not None:
             try:
@@ -673,7 +703,8 @@ def main():
             except Exception as e:
                 exchange_times["rccl_comm_ranks"] = "failed: " + repr(e)[:120]
         for label, fn in (("multiply_only_ms", multiply_only), ("torch_route_ms", torch_step),
-                          ("lib_route_ms", lib_step if libdist is not None else None)):
+                          ("lib_route_ms", lib_step if libdist is not None else None),
+                          ("peer_route_ms", peer_step if peerdist is not None else None)):
             try:
                 exchange_times[label] = timed_ms(fn, k2) if fn is not None else None
             except Exception as e:                      # the headline line must not depend on a secondary measurement
@@ -725,7 +756,8 @@ def main():
             "rows": n, "cols": n, "nnz": nnz_total,
             "index_bytes": args.idx_bytes, "indptr_bytes": args.idx_bytes,
             "partition": ("cost-balanced (nnz + %g/row) contiguous row blocks x%d, direct all-gather-v of y (%s)" %
-                          (sh.row_weight, world, "sprs_hip_dist_*, RCCL inside the library" if use_lib else
+                          (sh.row_weight, world, ("sprs_hip_dist_*, RCCL inside the library" if args.exchange == "lib" else
+                                                  "sprs_hip_dist_*, stores into the peers' windows (no RCCL on the data path)") if use_lib else
                            "torch.distributed grouped send/recv on RCCL" if args.backend == "nccl" else "torch.distributed send/recv on gloo, staged through host memory"))
                          if world > 1 else "single GPU",
             "generate_s": round(gen_s, 2),
@@ -974,6 +1006,9 @@ def main():
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
+        torch.cuda.synchronize()
+        dist.barrier()                                  # no rank frees its receive window while a peer may still store into it
+        peerdist = libdist = None
         dist.destroy_process_group()
 
 

@@ -367,7 +367,8 @@ int32_t sprs_hip_csmat_mul_csmat(const sprs_hip_csmat *lhs, const sprs_hip_csmat
  *                            (nsub = 1: multiply, then exchange).  Every rank passes the same world, row_starts, nsub.
  *   sprs_hip_dist_spmv_f64   collective.  y (length rows, on this rank's device) = A * x (x: length cols, replicated).
  *                            Asynchronous on `stream`; y is complete for work queued on `stream` afterwards.
- * RCCL is loaded at run time (dlopen); world = 1 needs none.  SPRS_HIP_HIP_ERROR carries RCCL's message. */
+ * RCCL is loaded at run time (dlopen); world = 1 needs none.  SPRS_HIP_HIP_ERROR carries RCCL's message.
+ * id_128_bytes = NULL with world > 1: no communicator is made, the handle exchanges over the peer route only (below). */
 typedef struct sprs_hip_dist sprs_hip_dist;
 int32_t sprs_hip_dist_unique_id(void *id_128_bytes);
 int32_t sprs_hip_dist_create(sprs_hip_dist **d, const void *id_128_bytes, int32_t world, int32_t rank, uint64_t rows,
@@ -377,6 +378,22 @@ int32_t sprs_hip_dist_spmv_f64(sprs_hip_dist *d, const double *x_dev, uint64_t x
                                void *stream);
 /* the rank count the RCCL communicator itself reports (ncclCommCount); a world of one has no communicator and reports 1 */
 int32_t sprs_hip_dist_comm_count(const sprs_hip_dist *d, int32_t *ranks);
+/* THE SECOND EXCHANGE ROUTE: stores into the peers' receive windows over xGMI instead of ncclSend / ncclRecv (both
+ * routes, to be compared by the first multi-GPU run).  Every rank exports its window (sprs_hip_dist_peer_handle: 64 bytes, a
+ * HIP IPC handle), the host program hands all of them to every rank in rank order — like the RCCL id — and
+ * sprs_hip_dist_peer_connect maps them; sprs_hip_dist_set_route(d, SPRS_HIP_ROUTE_PEER) then makes sprs_hip_dist_spmv_f64
+ * push every finished sub-block into all peers' windows with one kernel (all links at once), publish an epoch word, wait for
+ * the peers' epoch words and copy their rows into y.  Same result as the RCCL route, bit for bit (the multiply is the same
+ * kernel).  A handle made with id_128_bytes = NULL and world > 1 has no RCCL communicator and can ONLY use this route (ranks
+ * that share a device; hosts without RCCL).  All three calls are collective in the sense that every rank must make them; a
+ * peer that does not arrive within 2 s turns the NEXT call into SPRS_HIP_HIP_ERROR instead of hanging the device.
+ * sprs_hip_dist_free must not run while a peer may still store into this rank's window (synchronise the ranks first). */
+#define SPRS_HIP_ROUTE_RCCL 0
+#define SPRS_HIP_ROUTE_PEER 1
+int32_t sprs_hip_dist_peer_handle(sprs_hip_dist *d, void *handle_64_bytes);
+int32_t sprs_hip_dist_peer_connect(sprs_hip_dist *d, const void *handles /* world x 64 bytes, rank order */, int32_t world);
+int32_t sprs_hip_dist_set_route(sprs_hip_dist *d, int32_t route);
+int32_t sprs_hip_dist_route(const sprs_hip_dist *d, int32_t *route);
 int32_t sprs_hip_dist_free(sprs_hip_dist *d);
 
 /* Triplet (COO) assembly: twin of TriMatBase::to_csr / to_csc (triplet.rs:262-276) = TriMatIter::into_cs

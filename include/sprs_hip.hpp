@@ -279,6 +279,22 @@ public:
         check(sprs_hip_dist_comm_count(d_, &n));
         return n;
     }
+    // the peer-store route (sprs_hip.h): export this rank's window, connect with every rank's handle (rank order), choose the route
+    std::vector<unsigned char> peer_handle() {
+        std::vector<unsigned char> h(64);
+        check(sprs_hip_dist_peer_handle(d_, h.data()));
+        return h;
+    }
+    void peer_connect(const std::vector<unsigned char> &all_handles, int32_t world) {
+        if ((int64_t)all_handles.size() != (int64_t)world * 64) throw Error(SPRS_HIP_DIM_MISMATCH, "Dimension mismatch");
+        check(sprs_hip_dist_peer_connect(d_, all_handles.data(), world));
+    }
+    void set_route(int32_t route) { check(sprs_hip_dist_set_route(d_, route)); }
+    int32_t route() const {
+        int32_t r = 0;
+        check(sprs_hip_dist_route(d_, &r));
+        return r;
+    }
 
 private:
     sprs_hip_dist *d_ = nullptr;

@@ -16,6 +16,8 @@ pub const SPRS_HIP_CSR: i32 = 0;
 pub const SPRS_HIP_CSC: i32 = 1;
 pub const SPRS_HIP_ROW_MAJOR: i32 = 0;
 pub const SPRS_HIP_COL_MAJOR: i32 = 1;
+pub const SPRS_HIP_ROUTE_RCCL: i32 = 0;
+pub const SPRS_HIP_ROUTE_PEER: i32 = 1;
 
 #[repr(C)]
 pub struct sprs_hip_spgemm_plan {
@@ -150,6 +152,10 @@ extern "C" {
     ) -> i32;
     pub fn sprs_hip_dist_spmv_f64(d: *mut sprs_hip_dist, x_dev: *const f64, x_len: u64, y_dev: *mut f64, y_len: u64, stream: *mut c_void) -> i32;
     pub fn sprs_hip_dist_comm_count(d: *const sprs_hip_dist, ranks: *mut i32) -> i32;
+    pub fn sprs_hip_dist_peer_handle(d: *mut sprs_hip_dist, handle_64_bytes: *mut c_void) -> i32;
+    pub fn sprs_hip_dist_peer_connect(d: *mut sprs_hip_dist, handles: *const c_void, world: i32) -> i32;
+    pub fn sprs_hip_dist_set_route(d: *mut sprs_hip_dist, route: i32) -> i32;
+    pub fn sprs_hip_dist_route(d: *const sprs_hip_dist, route: *mut i32) -> i32;
     pub fn sprs_hip_dist_free(d: *mut sprs_hip_dist) -> i32;
     pub fn sprs_hip_csmat_mul_csmat(lhs: *const sprs_hip_csmat, rhs: *const sprs_hip_csmat, out: *mut *mut sprs_hip_csmat) -> i32;
     pub fn sprs_hip_triplets_to_cs(

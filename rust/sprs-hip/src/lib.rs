@@ -302,6 +302,25 @@ pub mod dist {
             unsafe { check(sys::sprs_hip_dist_comm_count(self.d, &mut n)) };
             n as usize
         }
+        /// the peer-store route: this rank's receive window as a 64-byte HIP IPC handle
+        pub fn peer_handle(&mut self) -> [u8; 64] {
+            let mut h = [0u8; 64];
+            unsafe { check(sys::sprs_hip_dist_peer_handle(self.d, h.as_mut_ptr() as *mut c_void)) };
+            h
+        }
+        /// collective: every rank's handle, in rank order
+        pub fn peer_connect(&mut self, all_handles: &[[u8; 64]]) {
+            unsafe { check(sys::sprs_hip_dist_peer_connect(self.d, all_handles.as_ptr() as *const c_void, all_handles.len() as i32)) };
+        }
+        /// 0: grouped ncclSend / ncclRecv, 1: stores into the peers' windows
+        pub fn set_route(&mut self, route: i32) {
+            unsafe { check(sys::sprs_hip_dist_set_route(self.d, route)) };
+        }
+        pub fn route(&self) -> i32 {
+            let mut r = 0i32;
+            unsafe { check(sys::sprs_hip_dist_route(self.d, &mut r)) };
+            r
+        }
     }
     impl Drop for DistSpMV {
         fn drop(&mut self) {

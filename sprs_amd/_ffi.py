@@ -17,6 +17,7 @@ OK, DIM_MISMATCH, STORAGE_MISMATCH, INDEX_OVERFLOW, BAD_STRUCTURE, INVALID_ARG, 
     OUT_OF_MEMORY, HIP_ERROR, NO_DEVICE = range(9)
 CSR, CSC = 0, 1
 ROW_MAJOR, COL_MAJOR = 0, 1
+ROUTE_RCCL, ROUTE_PEER = 0, 1
 
 STATUS_NAMES = {
     OK: "OK", DIM_MISMATCH: "DIM_MISMATCH", STORAGE_MISMATCH: "STORAGE_MISMATCH",
@@ -78,6 +79,10 @@ SIGNATURES = {
     "sprs_hip_dist_unique_id": (i32, [vp]),
     "sprs_hip_dist_create": (i32, [P(vp), vp, i32, i32, u64, u64, P(u64), vp, i32]),
     "sprs_hip_dist_spmv_f64": (i32, [vp, vp, u64, vp, u64, vp]),
+    "sprs_hip_dist_peer_handle": (i32, [vp, vp]),
+    "sprs_hip_dist_peer_connect": (i32, [vp, vp, i32]),
+    "sprs_hip_dist_set_route": (i32, [vp, i32]),
+    "sprs_hip_dist_route": (i32, [vp, P(i32)]),
     "sprs_hip_dist_free": (i32, [vp]),
     "sprs_hip_csmat_mul_csmat": (i32, [vp, vp, P(vp)]),
     "sprs_hip_triplets_to_cs": (i32, [u64, u64, u64, vp, vp, i32, vp, i32, i32, i32, P(vp)]),

@@ -1066,6 +1066,30 @@ int32_t sprs_hip_dist_comm_count(const sprs_hip_dist *d, int32_t *ranks) {
     return dist_comm_count(d, ranks);
 }
 
+int32_t sprs_hip_dist_peer_handle(sprs_hip_dist *d, void *handle_64_bytes) {
+    clear_error();
+    if (!d || !handle_64_bytes) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    return dist_peer_handle(d, handle_64_bytes);
+}
+
+int32_t sprs_hip_dist_peer_connect(sprs_hip_dist *d, const void *handles, int32_t world) {
+    clear_error();
+    if (!d || !handles) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    return dist_peer_connect(d, handles, world);
+}
+
+int32_t sprs_hip_dist_set_route(sprs_hip_dist *d, int32_t route) {
+    clear_error();
+    if (!d) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL handle");
+    return dist_set_route(d, route);
+}
+
+int32_t sprs_hip_dist_route(const sprs_hip_dist *d, int32_t *route) {
+    clear_error();
+    if (!d || !route) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    return dist_route(d, route);
+}
+
 int32_t sprs_hip_dist_free(sprs_hip_dist *d) {
     clear_error();
     dist_free(d);

@@ -255,6 +255,10 @@ void dist_free(sprs_hip_dist *d);
 uint64_t dist_rows(const sprs_hip_dist *d);
 uint64_t dist_cols(const sprs_hip_dist *d);
 int32_t dist_comm_count(const sprs_hip_dist *d, int32_t *ranks);
+int32_t dist_peer_handle(sprs_hip_dist *d, void *handle64);                       // the peer-store route (dist.hip)
+int32_t dist_peer_connect(sprs_hip_dist *d, const void *handles, int32_t world);
+int32_t dist_set_route(sprs_hip_dist *d, int32_t route);
+int32_t dist_route(const sprs_hip_dist *d, int32_t *route);
 // triplet.hip
 int32_t triplets_to_cs(uint64_t rows, uint64_t cols, uint64_t n, const void *row_inds, const void *col_inds, int32_t in_idx_bytes,
                        const double *data, int32_t storage, int32_t out_idx_bytes, int32_t out_iptr_bytes, sprs_hip_csmat **out);

@@ -111,6 +111,12 @@ struct sprs_hip_dist {
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> done;                      // sub-block s multiplied (recorded on the caller's stream)
     hipEvent_t gathered = nullptr;                     // exchange complete (recorded on comm_stream)
+    // ---- the second exchange route: peer stores over xGMI (SURVEY 8e "report both") --------------------------------------
+    int32_t route = 0;                                 // 0: grouped ncclSend / ncclRecv; 1: stores into the peers' receive windows
+    void *window = nullptr;                            // this rank's receive window: [flags: one epoch word per peer | y copy 0 | y copy 1]
+    std::vector<void *> peer_window;                   // the peers' windows, opened from their IPC handles (own entry: `window`)
+    unsigned long long epoch = 0;                      // collective multiplies so far on the peer route
+    int *peer_status = nullptr;                        // host-mapped: set by the wait kernel when a peer does not arrive in time
 };
 
 namespace sprs_hip {
@@ -142,6 +148,15 @@ int32_t dist_unique_id(void *id128) {
 
 void dist_free(sprs_hip_dist *d) {
     if (!d) return;
+    (void)hipDeviceSynchronize();                      // nothing of this handle's exchanges may still be running
+    for (size_t p = 0; p < d->peer_window.size(); ++p)
+#ifndef SPRS_HIP_EMU
+        if (d->peer_window[p] && (int32_t)p != d->rank) (void)hipIpcCloseMemHandle(d->peer_window[p]);
+    if (d->window) (void)hipFree(d->window);
+    if (d->peer_status) (void)hipHostFree(d->peer_status);
+#else
+        (void)p;
+#endif
     for (auto *m : d->sub) sprs_hip_csmat_free(m);
     for (auto e : d->done)
         if (e) (void)hipEventDestroy(e);
@@ -215,8 +230,9 @@ int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world
     d->sub_starts.push_back(r0 + lrows);
     // ---- communicator, second stream, events -------------------------------------------------------------------------------
     // (a world of ONE with an id given goes through RCCL as well — an empty exchange: what a 1-GPU box can exercise of this path)
-    if (world > 1 || unique_id128) {
-        if (!unique_id128) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "multi-GPU: the RCCL unique id is missing (sprs_hip_dist_unique_id on one rank, handed to all)");
+    // world > 1 WITHOUT an id: no RCCL communicator is made; the handle can only exchange over the peer route
+    // (sprs_hip_dist_peer_handle / _peer_connect / _set_route) — ranks sharing one device, or a host program that has no RCCL
+    if (unique_id128) {
         Rccl *R = nullptr;
         SPRS_TRY(rccl(&R));
         NcclId id;
@@ -258,15 +274,214 @@ int32_t dist_create(sprs_hip_dist **out, const void *unique_id128, int32_t world
                 SPRS_FAIL(SPRS_HIP_INVALID_ARG, "rank %d cut its block differently from the row_starts given here", p);
         }
     }
+    if (world > 1 && !d->comm_stream) {                // the peer route's own second stream and events
+        SPRS_TRY_HIP(hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking));
+        d->done.assign(d->sub.size(), nullptr);
+        for (auto &e : d->done) SPRS_TRY_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        SPRS_TRY_HIP(hipEventCreateWithFlags(&d->gathered, hipEventDisableTiming));
+    }
     guard.p = nullptr;
     *out = d;
     return SPRS_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The PEER route: hand-written stores over xGMI instead of ncclSend / ncclRecv.
+//
+// Every rank owns a RECEIVE WINDOW — one allocation: an epoch word per peer, then two copies of y (rows doubles each) — exported
+// as a HIP IPC handle; the host program hands the 64-byte handles round (as it does the RCCL id) and every rank maps its peers'
+// windows.  One multiply, epoch e:
+//   * sub-block s is multiplied into the caller's y on `stream`; behind it, on the second stream, ONE kernel stores those rows
+//     into copy e & 1 of EVERY peer's window (blockIdx.y = peer: all seven links carry data at once; a chain of
+//     hipMemcpyPeerAsync on one stream would use them one after the other), and the multiply of sub-block s + 1 runs beside it;
+//   * after the last sub-block a tiny kernel stores e into this rank's epoch word in every peer's window (system-scope
+//     release, behind a system fence that closes the push kernels' stores);
+//   * a one-wave kernel polls the own window's epoch words until every peer's reads e (system-scope acquire; a peer that
+//     does not arrive within the timeout raises a status word instead of hanging the device), then the peers' rows are copied
+//     from the window into the caller's y, and `stream` waits for that.
+// Two copies, by parity of the epoch: a peer writes copy (e + 1) & 1 while this rank may still read copy e & 1; it writes copy
+// e & 1 again only in epoch e + 2, which it cannot start before it has this rank's rows of epoch e + 1 — sent after this rank's
+// copy-out of epoch e in stream order.  The windows are fine-grained device memory where the runtime offers it (remote stores
+// into coarse-grained memory are not guaranteed to be seen by the local L2s before the next kernel boundary with a system-scope
+// acquire); a world whose ranks share one device (tests) runs the same code through the same mappings.
+// No RCCL call on this path.  Not measured on more than one GPU (none reachable from the build environment): correctness is
+// covered by N ranks on one GPU, the route's speed is for the first multi-GPU run to report beside the RCCL route's.
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifdef SPRS_HIP_EMU
+// (the CPU kernel emulator has no IPC and no second device: the route exists on the hardware only)
+int32_t dist_peer_handle(sprs_hip_dist *, void *) { SPRS_FAIL(SPRS_HIP_INVALID_ARG, "peer route: not available in the CPU emulator"); }
+int32_t dist_peer_connect(sprs_hip_dist *, const void *, int32_t) { SPRS_FAIL(SPRS_HIP_INVALID_ARG, "peer route: not available in the CPU emulator"); }
+int32_t dist_set_route(sprs_hip_dist *d, int32_t route) {
+    if (route != 0) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "peer route: not available in the CPU emulator");
+    d->route = 0;
+    return SPRS_HIP_OK;
+}
+int32_t dist_route(const sprs_hip_dist *d, int32_t *route) {
+    *route = d->route;
+    return SPRS_HIP_OK;
+}
+static int32_t dist_spmv_peer(sprs_hip_dist *, const double *, double *, hipStream_t) { SPRS_FAIL(SPRS_HIP_INVALID_ARG, "peer route: not available in the CPU emulator"); }
+#else
+namespace {
+
+constexpr int PEER_MAX = 16;
+constexpr uint64_t PEER_FLAG_BYTES = 4096;             // the epoch words' share of a window (one per peer, padded)
+
+struct PeerPtrs {
+    double *dst[PEER_MAX];                             // copy e & 1 of every OTHER rank's window
+    unsigned long long *flag[PEER_MAX];                // this rank's epoch word in every other rank's window
+    int32_t n;
+};
+
+__global__ __launch_bounds__(256) void peer_push_kernel(const double *__restrict__ src, PeerPtrs pp, uint64_t off, uint64_t n) {
+    double *dst = pp.dst[blockIdx.y] + off;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    __threadfence_system();                            // the stores have left for the peer before the kernel counts as done
+}
+
+__global__ void peer_flag_kernel(PeerPtrs pp, unsigned long long epoch) {
+    __threadfence_system();
+    if ((int)threadIdx.x < pp.n) __hip_atomic_store(pp.flag[threadIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void peer_wait_kernel(const unsigned long long *flags, int world, int me, unsigned long long epoch, long long timeout_ticks,
+                                 int *status) {
+    const int p = (int)threadIdx.x;
+    if (p < world && p != me) {
+        const long long t0 = (long long)wall_clock64();
+        while (__hip_atomic_load(flags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(32);
+            if ((long long)wall_clock64() - t0 > timeout_ticks) {
+                *status = 1 + p;
+                break;
+            }
+        }
+    }
+    __threadfence_system();
+}
+
+__global__ __launch_bounds__(256) void peer_copy_out_kernel(const double *__restrict__ win, double *__restrict__ y, uint64_t own0, uint64_t own1,
+                                                            uint64_t rows) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += stride)
+        if (i < own0 || i >= own1) y[i] = win[i];
+}
+
+int32_t peer_alloc_window(sprs_hip_dist *d) {
+    if (d->window) return SPRS_HIP_OK;
+    if (d->world > PEER_MAX) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "peer route: at most %d ranks", PEER_MAX);
+    const size_t bytes = PEER_FLAG_BYTES + 2 * (size_t)d->rows * 8 + 256;
+#ifndef SPRS_HIP_EMU
+    if (hipExtMallocWithFlags(&d->window, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        d->window = nullptr;
+    }
+#endif
+    if (!d->window) SPRS_TRY_HIP(hipMalloc(&d->window, bytes));
+    SPRS_TRY_HIP(hipMemset(d->window, 0, bytes));
+    SPRS_TRY_HIP(hipDeviceSynchronize());
+    SPRS_TRY_HIP(hipHostMalloc((void **)&d->peer_status, sizeof(int), hipHostMallocMapped));
+    *d->peer_status = 0;
+    return SPRS_HIP_OK;
+}
+
+}  // namespace
+
+int32_t dist_peer_handle(sprs_hip_dist *d, void *handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI hands 64-byte handles round");
+    SPRS_TRY(peer_alloc_window(d));
+    hipIpcMemHandle_t h;
+    SPRS_TRY_HIP(hipIpcGetMemHandle(&h, d->window));
+    memcpy(handle64, &h, 64);
+    return SPRS_HIP_OK;
+}
+
+int32_t dist_peer_connect(sprs_hip_dist *d, const void *handles, int32_t world) {
+    if (world != d->world) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "peer route: %d handles for a world of %d", world, d->world);
+    SPRS_TRY(peer_alloc_window(d));
+    if (!d->peer_window.empty()) return SPRS_HIP_OK;   // connected already
+    d->peer_window.assign(world, nullptr);
+    d->peer_window[d->rank] = d->window;
+    for (int32_t p = 0; p < world; ++p) {
+        if (p == d->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + (size_t)p * 64, 64);
+        SPRS_TRY_HIP(hipIpcOpenMemHandle(&d->peer_window[p], h, hipIpcMemLazyEnablePeerAccess));
+    }
+    return SPRS_HIP_OK;
+}
+
+int32_t dist_set_route(sprs_hip_dist *d, int32_t route) {
+    if (route != 0 && route != 1) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "route must be 0 (RCCL) or 1 (peer stores)");
+    if (route == 0 && d->world > 1 && !d->comm) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "this handle was made without an RCCL id: only the peer route is available");
+    if (route == 1 && d->world > 1 && d->peer_window.empty())
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "peer route: exchange the window handles first (sprs_hip_dist_peer_handle on every rank, sprs_hip_dist_peer_connect with all of them)");
+    d->route = route;
+    return SPRS_HIP_OK;
+}
+
+int32_t dist_route(const sprs_hip_dist *d, int32_t *route) {
+    *route = d->route;
+    return SPRS_HIP_OK;
+}
+
+static int32_t dist_spmv_peer(sprs_hip_dist *d, const double *x, double *y, hipStream_t stream) {
+    if (d->peer_status && *d->peer_status) {
+        const int who = *d->peer_status - 1;
+        *d->peer_status = 0;
+        SPRS_FAIL(SPRS_HIP_HIP_ERROR, "peer route: rank %d did not deliver its rows of the previous multiply in time", who);
+    }
+    const unsigned long long e = ++d->epoch;
+    const uint64_t copy_off = PEER_FLAG_BYTES / 8 + (e & 1ull) * d->rows;           // in doubles
+    PeerPtrs pp;
+    pp.n = 0;
+    for (int32_t p = 0; p < d->world; ++p) {
+        if (p == d->rank) continue;
+        pp.dst[pp.n] = (double *)d->peer_window[p] + copy_off;
+        pp.flag[pp.n] = (unsigned long long *)d->peer_window[p] + d->rank;
+        ++pp.n;
+    }
+    for (size_t s = 0; s < d->sub.size(); ++s) {
+        sprs_hip_csmat *m = d->sub[s];
+        const uint64_t r0 = d->sub_starts[s], n = d->sub_starts[s + 1] - r0;
+        if (m->rows) SPRS_TRY(spmv_f64(m, x, y + r0, false, stream));
+        SPRS_TRY_HIP(hipEventRecord(d->done[s], stream));
+        SPRS_TRY_HIP(hipStreamWaitEvent(d->comm_stream, d->done[s], 0));
+        if (n && pp.n) {
+            uint64_t blocks = (n + 255) / 256;
+            if (blocks > 512) blocks = 512;                                        // per peer: 7 x 512 workgroups keep every link busy
+            hipLaunchKernelGGL(peer_push_kernel, dim3((unsigned)blocks, (unsigned)pp.n), dim3(256), 0, d->comm_stream, (const double *)(y + r0), pp, r0, n);
+            SPRS_TRY_HIP(hipGetLastError());
+        }
+    }
+    if (pp.n) {
+        hipLaunchKernelGGL(peer_flag_kernel, dim3(1), dim3(64), 0, d->comm_stream, pp, e);
+        SPRS_TRY_HIP(hipGetLastError());
+        // 2 s at the 100 MHz wall clock: a peer that died must not hang the device (and the box with it)
+        hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(64), 0, d->comm_stream, (const unsigned long long *)d->window, d->world, d->rank, e,
+                           200000000ll, d->peer_status);
+        SPRS_TRY_HIP(hipGetLastError());
+        uint64_t blocks = (d->rows + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(peer_copy_out_kernel, dim3((unsigned)blocks), dim3(256), 0, d->comm_stream, (const double *)d->window + copy_off, y,
+                           d->row_starts[d->rank], d->row_starts[d->rank + 1], d->rows);
+        SPRS_TRY_HIP(hipGetLastError());
+    }
+    SPRS_TRY_HIP(hipEventRecord(d->gathered, d->comm_stream));
+    SPRS_TRY_HIP(hipStreamWaitEvent(stream, d->gathered, 0));
+    return SPRS_HIP_OK;
+}
+
+#endif
+
 // y (full length, on this rank's device) = A * x: the own block is multiplied sub-block by sub-block on `stream`; as soon
 // as one is done its rows go to every peer on the second stream, and the peers' blocks arrive into y; `stream` then waits
 // for the exchange.  Every rank must call this with the same sequence of calls (collective).
 int32_t dist_spmv(sprs_hip_dist *d, const double *x, double *y, hipStream_t stream) {
+    if (d->world > 1 && d->route == 1) return dist_spmv_peer(d, x, y, stream);
+    if (d->world > 1 && !d->comm)
+        SPRS_FAIL(SPRS_HIP_INVALID_ARG, "this handle was made without an RCCL id: connect the peer route first (sprs_hip_dist_peer_connect, sprs_hip_dist_set_route)");
     Rccl *R = nullptr;
     if (d->comm) SPRS_TRY(rccl(&R));
     const size_t groups = d->comm ? d->peer_starts[0].size() - 1 : d->sub.size();

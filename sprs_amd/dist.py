@@ -191,6 +191,43 @@ class DistSpMV:
         dist.broadcast(buf, src=src, group=group)
         return bytes(buf.cpu().numpy().tobytes())
 
+    # ---- the second exchange route: stores into the peers' receive windows over xGMI (sprs_hip.h, dist.hip) ------------
+    def peer_handle(self):
+        """this rank's receive window as a 64-byte HIP IPC handle"""
+        import ctypes as C
+        from ._ffi import check, lib
+        buf = (C.c_char * 64)()
+        check(lib.sprs_hip_dist_peer_handle(self._h, buf))
+        return bytes(buf)
+
+    def connect_peers(self, device, group=None):
+        """collective: all-gather the 64-byte window handles through torch.distributed (whatever backend the group has) and
+        map every peer's window; afterwards `set_route("peer")` is allowed"""
+        import ctypes as C
+        from ._ffi import check, lib
+        world = dist.get_world_size(group)
+        on = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        mine = torch.frombuffer(bytearray(self.peer_handle()), dtype=torch.uint8).to(on)
+        got = [torch.zeros(64, dtype=torch.uint8, device=on) for _ in range(world)]
+        dist.all_gather(got, mine, group=group)
+        blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in got)
+        check(lib.sprs_hip_dist_peer_connect(self._h, (C.c_char * len(blob)).from_buffer_copy(blob), world))
+        dist.barrier(group)                            # every rank has mapped every window before anybody stores into one
+        return self
+
+    def set_route(self, route):
+        """"rccl" (grouped ncclSend / ncclRecv) or "peer" (stores into the peers' windows)"""
+        from ._ffi import check, lib
+        check(lib.sprs_hip_dist_set_route(self._h, {"rccl": 0, "peer": 1}[route]))
+        return self
+
+    def route(self):
+        import ctypes as C
+        from ._ffi import check, lib
+        r = C.c_int32(0)
+        check(lib.sprs_hip_dist_route(self._h, C.byref(r)))
+        return ("rccl", "peer")[r.value]
+
     def comm_count(self):
         """ranks of the RCCL communicator as RCCL itself counts them (ncclCommCount; 1 for a world of one)"""
         import ctypes as C

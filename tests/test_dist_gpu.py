@@ -134,9 +134,85 @@ def _rank_main(rank, world, port, n, out):
     prod.csmat_mul_vec(full, DeviceVec.borrow(x), out=DeviceVec.borrow(ref))
     torch.cuda.synchronize()
     ok = bool(((y - ref).abs() <= 1e-10 * ref.abs()).all())
+    # the same handle on the peer-store route: the same multiply kernels, rows moved by stores instead of ncclSend / ncclRecv
+    y2 = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    d.connect_peers(dev).set_route("peer")
+    for _ in range(3):
+        d.spmv(DeviceVec.borrow(x), DeviceVec.borrow(y2), stream=torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    ok = ok and bool(torch.equal(y, y2))
+    d.set_route("rccl")
+    dist.barrier()
     if rank == 0:
         open(out, "w").write("ok" if ok else "mismatch")
     dist.destroy_process_group()
+
+
+def _peer_rank_main(rank, world, port, n, out, devices):
+    """one rank of the PEER-route test: gloo is only the bootstrap (window handles, barriers); the rows travel by stores into
+    the peers' receive windows (sprs_amd/csrc/dist.hip) — through IPC mappings of the same device when the ranks share one"""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    di = devices[rank]
+    torch.cuda.set_device(di)
+    dev = torch.device("cuda", di)
+    dist.init_process_group("gloo")
+    import sprs_amd
+    from sprs_amd import _ffi, gen, prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    from sprs_amd.dist import DistSpMV
+    _ffi.check(_ffi.lib.sprs_hip_set_device(di))
+    indptr, indices, data = gen.rmat_csr(n, 16, seed=7, device=dev)
+    cuts = gen.balanced_row_blocks(indptr, world, row_weight=8.0)
+    full = DeviceCsMat.wrap_torch((n, n), indptr, indices, data)
+    block = full.slice_outer(cuts[rank], cuts[rank + 1])
+    d = DistSpMV((n, n), block, cuts, rank, world, unique_id=None, nsub=3)
+    ok = True
+    try:                                                 # no RCCL communicator, route not connected yet: the multiply must refuse
+        d.spmv(DeviceVec.borrow(torch.zeros(n, dtype=torch.float64, device=dev)), DeviceVec.borrow(torch.zeros(n, dtype=torch.float64, device=dev)))
+        ok = False
+    except sprs_amd.SprsHipError as e:
+        ok = ok and e.status == _ffi.INVALID_ARG
+    d.connect_peers(dev).set_route("peer")
+    ok = ok and d.route() == "peer"
+    x = gen.dense_vector(n, seed=3, device=dev)
+    ref = torch.empty(n, dtype=torch.float64, device=dev)
+    y = torch.empty(n, dtype=torch.float64, device=dev)
+    for it in range(5):                                  # y is fed back as the next x: both copies of the window are in use in turn
+        y.fill_(float("nan"))
+        d.spmv(DeviceVec.borrow(x), DeviceVec.borrow(y), stream=torch.cuda.current_stream())
+        prod.csmat_mul_vec(full, DeviceVec.borrow(x), out=DeviceVec.borrow(ref))
+        torch.cuda.synchronize()
+        # the own block is the same kernel on a row block (another plan than the whole matrix: equal to rounding); every rank must hold ALL rows
+        ok = ok and bool(((y - ref).abs() <= 1e-10 * ref.abs()).all())
+        x = y / y.abs().max()
+    # every rank has the same gathered vector, bit for bit
+    chk = torch.tensor([float((y * (1.0 + (torch.arange(n, device=dev) % 7))).sum().item())], dtype=torch.float64)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    ok = ok and float(lo.item()) == float(hi.item())
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.barrier()                                       # nobody frees its window while a peer may still store into it
+    del d
+    if rank == 0:
+        open(out, "w").write("ok" if float(flag.item()) > 0.5 else "mismatch")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_route_ranks_sharing_this_gpu(hip, tmp_path, world):
+    """the second exchange route as far as ONE GPU can run it: `world` processes on device 0, every
+    rank's receive window exported as a HIP IPC handle and mapped by the others, five chained SpMVs whose sub-blocks are pushed
+    into the peers' windows while the next sub-block multiplies; every rank ends with the whole vector, equal to the one-handle
+    product and identical across ranks.  (With two devices test_two_gpus_rccl_exchange also compares this route with RCCL's.)"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_peer_rank_main, args=(world, 29541 + world, 300000, out, [0] * world), nprocs=world, join=True)
+    assert open(out).read() == "ok"
 
 
 def test_two_gpus_rccl_exchange(hip, tmp_path):
@@ -184,6 +260,8 @@ def test_bench_n_ranks_on_this_gpu(hip, world):
     ex = out["exchange"]
     assert ex["timed_route"] == "torch" and ex["backend"] == "gloo" and ex["devices"] == ",".join(["0"] * world)
     assert isinstance(ex["multiply_only_ms"], float) and isinstance(ex["torch_route_ms"], float) and ex["lib_route_ms"] is None
+    # the peer-store route needs no RCCL: it runs here too (windows mapped through IPC on the one device) and must agree with the torch route
+    assert isinstance(ex["peer_route_ms"], float) and ex["routes_agree"]["ok"] and ex["routes_agree"]["peer_vs_torch_max_rel_diff"] <= 1e-10
     assert ex["torch_route_ms"] >= ex["multiply_only_ms"] * 0.5
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["algorithmic_bytes_per_launch"] > 0
