@@ -349,6 +349,50 @@ def spgemm_uniform(dev, n=2_500_000, nnz_over_rows=4, steps=3, with_cpu=True):
     return out
 
 
+def sparse_dense_micro(dev, with_oracle=True):
+    """The reference's own micro-benchmark of the dense product (sprs/benches/sparse_dense_products.rs:21-55): a 3 x 1 000 000
+    CsMat with 5 stored entries times the dense vector Array::range(0., 10., 0.00001) — `&a * &w` and the specialised
+    csr_mulacc_dense_colmaj call are the same kernel here.  Five multiply-adds: on a GPU this is one launch's latency, reported
+    as such beside the oracle's time for the same call (it is not a shape to offload; the line says so instead of hiding it)."""
+    from sprs_amd import prod
+    from sprs_amd.device import DeviceCsMat, DeviceVec
+    n = 1_000_000
+    w = torch.arange(n, dtype=torch.float64, device=dev) * 0.00001
+    ip = np.array([0, 2, 4, 5], dtype=np.uint64)
+    ix = np.array([0, 1, 0, 2, 2], dtype=np.uint64)
+    dt = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    a = DeviceCsMat.from_host((3, n), ip, ix, dt)
+    y = torch.empty(3, dtype=torch.float64, device=dev)
+    wv, yv = DeviceVec.borrow(w), DeviceVec.borrow(y)
+    stream = torch.cuda.current_stream()
+    for _ in range(5):
+        prod.csmat_mul_vec(a, wv, out=yv, stream=stream)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+    t = time.perf_counter()
+    for p_, q_ in ev:
+        p_.record(stream)
+        prod.csmat_mul_vec(a, wv, out=yv, stream=stream)
+        q_.record(stream)
+    torch.cuda.synchronize()
+    wall_us = (time.perf_counter() - t) / len(ev) * 1e6
+    us = [p_.elapsed_time(q_) * 1e3 for p_, q_ in ev]
+    out = {"workload": "sprs/benches/sparse_dense_products.rs: (3 x 1e6 CsMat, 5 entries) * dense vec of 1e6", "gpu_us_per_call_events": round(float(np.mean(us)), 2),
+           "gpu_us_per_call_wall": round(wall_us, 2), "note": "launch-latency bound: five multiply-adds; not a shape to offload"}
+    if with_oracle:
+        from oracle import oracle   # test infrastructure: the checker + the timed CPU port, never the product
+        w_h = w.cpu().numpy()
+        y_h = np.zeros(3)
+        reps = 2000
+        t = time.perf_counter()
+        for _ in range(reps):
+            y_h[:] = 0.0
+            oracle.mul_acc_mat_vec_csr((3, n), ip, ix, dt, w_h, y_h)
+        out["cpu_us_per_call"] = round((time.perf_counter() - t) / reps * 1e6, 2)       # includes the ctypes call overhead of the harness
+        out["parity"] = {"bit_exact": bool(np.array_equal(y.cpu().numpy(), y_h)), "ok": bool(np.array_equal(y.cpu().numpy(), y_h))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -981,6 +1025,10 @@ def main():
             except Exception as e:   # the headline line must not depend on a secondary measurement
                 out["configs"][cfg] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
+        try:
+            out["sparse_dense_products"] = sparse_dense_micro(dev, with_oracle=not args.no_cpu_baseline)
+        except Exception as e:
+            out["sparse_dense_products"] = {"error": repr(e)[:200]}
         try:
             out["spgemm_uniform"] = spgemm_uniform(dev, with_cpu=not args.no_cpu_baseline)
         except Exception as e:

@@ -889,7 +889,7 @@ int32_t sprs_hip_dist_unique_id(void *id_128_bytes) {
 int32_t sprs_hip_dist_create(sprs_hip_dist **d, const void *id_128_bytes, int32_t world, int32_t rank, uint64_t rows,
                              uint64_t cols, const uint64_t *row_starts, const sprs_hip_csmat *local_block, int32_t nsub) {
     clear_error();
-    if (!d || !row_starts || !local_block || (world > 1 && !id_128_bytes)) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");
+    if (!d || !row_starts || !local_block) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "NULL argument");   // (no id with world > 1: a handle for the peer route only)
     *d = nullptr;
     return dist_create(d, id_128_bytes, world, rank, rows, cols, row_starts, local_block, nsub);
 }
