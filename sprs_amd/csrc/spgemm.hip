@@ -187,28 +187,43 @@ __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 3
 // ---------------------------------------------------------------------------
 // pass 0: per-row product count and number of tasks
 // ---------------------------------------------------------------------------
+// classes of a row by its product count (and k's): 0 none, 1 tiny and 2 small (one wave, hash table), 3 mid (one wave, column
+// windows), 4 large (a workgroup); 5 / 6 / 7 MICRO rows — at most 16 / 32 / 64 products AND k's: 4 / 2 / 1 rows per wave, no LDS
+// (micro_rows_kernel) — every row of the reference's own benchmark matrices (uniform density, 4 entries per row) is one
+constexpr uint8_t CLS_MICRO16 = 5, CLS_MICRO32 = 6, CLS_MICRO64 = 7;
+
+// 16 lanes per row, four rows per wave (round 6: one wave per row left 60 lanes idle on the 4-entry rows of the reference's
+// benchmark matrices and made this pass 0.5 ms of their 4.6 ms product; long rows just take more strides)
 template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
                                                        uint64_t b_cols, uint64_t heavy_products, uint32_t wl, uint32_t min_wl, uint64_t mid_max,
                                                        uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks,
-                                                       uint8_t *__restrict__ cls, uint8_t *__restrict__ wlog) {
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
+                                                       uint8_t *__restrict__ cls, uint8_t *__restrict__ wlog, uint32_t micro) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1), sub = lane >> 4, sl = lane & 15u;
     const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
-    for (uint64_t r = w0; r < rows; r += nw) {
-        const uint64_t s = (uint64_t)A.indptr[r], e = (uint64_t)A.indptr[r + 1];
+    for (uint64_t rb = w0 * 4; rb < rows; rb += nw * 4) {                // wave-uniform
+        const uint64_t r = rb + sub;
+        const bool ok = r < rows;
+        const uint64_t s = ok ? (uint64_t)A.indptr[r] : 0, e = ok ? (uint64_t)A.indptr[r + 1] : 0;
         uint64_t acc = 0;
-        for (uint64_t p = s + lane; p < e; p += WAVE) {
+        for (uint64_t p = s + sl; p < e; p += 16) {
             const uint64_t k = (uint64_t)A.indices[p];
             acc += (uint64_t)B.indptr[k + 1] - (uint64_t)B.indptr[k];
         }
-        acc = wave_sum_u64(acc);
-        if (lane == 0) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);   // the 16 lanes of the row
+        if (ok && sl == 0) {
             ub[r] = acc;
             // A large row is ONE task that walks its column windows (2^wl columns each) one after the other.
             uint64_t nt = acc ? 1 : 0;
-            // classes: 1 tiny and 2 small (one wave, hash table), 3 mid (one wave, column windows), 4 large (a workgroup)
-            const uint8_t c = !acc ? 0 : acc <= TINY_MAX ? 1 : acc <= SMALL_MAX ? 2 : (e - s <= 64 && acc <= mid_max) ? 3 : 4;
+            uint8_t c = !acc ? 0 : acc <= TINY_MAX ? 1 : acc <= SMALL_MAX ? 2 : (e - s <= 64 && acc <= mid_max) ? 3 : 4;
+            if (c == 1 && micro) {
+                const uint64_t nk = e - s;
+                if (acc <= 16 && nk <= 16) c = CLS_MICRO16;
+                else if (acc <= 32 && nk <= 32) c = CLS_MICRO32;
+                else if (nk <= 64) c = CLS_MICRO64;
+            }
             cls[r] = c;
             uint32_t wl_r = wl;
             if (c == 4 && acc > heavy_products) {
@@ -227,6 +242,10 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
     }
 }
 
+struct alignas(16) MicroRec {       // a micro row in its class list: its task (= slot of its count / offset) and the row itself
+    uint64_t t, r;
+};
+
 // Task lists, deterministic (first version: atomicAdd tickets, i.e. an arbitrary order that changed from call to call).
 // Classes of a row: tiny (<= 64 products), small (<= 512), large (one task per column window).
 __global__ void task_class_kernel(const uint8_t *__restrict__ cls, const uint64_t *__restrict__ ntasks, uint64_t rows,
@@ -235,9 +254,10 @@ __global__ void task_class_kernel(const uint8_t *__restrict__ cls, const uint64_
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const uint8_t c = cls[r];
-    is_tiny[r] = c == 1;
-    is_small[r] = c == 2;
-    is_mid[r] = c == 3;
+    // the micro classes ride in the high halves of the same words: one scan gives both positions (rows < 2^32 per class)
+    is_tiny[r] = (uint64_t)(c == 1) | ((uint64_t)(c == CLS_MICRO16) << 32);
+    is_small[r] = (uint64_t)(c == 2) | ((uint64_t)(c == CLS_MICRO32) << 32);
+    is_mid[r] = (uint64_t)(c == 3) | ((uint64_t)(c == CLS_MICRO64) << 32);
     n_large[r] = c == 4 ? ntasks[r] : 0;
 }
 
@@ -251,7 +271,8 @@ __global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uin
                                   uint64_t *__restrict__ task_row, uint64_t *__restrict__ tiny_list,
                                   uint64_t *__restrict__ small_list, uint64_t *__restrict__ mid_list,
                                   uint64_t *__restrict__ large_list, uint64_t *__restrict__ large_key,
-                                  uint64_t *__restrict__ mid_key) {
+                                  uint64_t *__restrict__ mid_key, MicroRec *__restrict__ m16, MicroRec *__restrict__ m32,
+                                  MicroRec *__restrict__ m64) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const uint64_t n = ntasks[r];
@@ -259,13 +280,20 @@ __global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uin
     const uint64_t f = first_task[r];
     for (uint64_t j = 0; j < n; ++j) task_row[f + j] = r;
     const uint8_t c = cls[r];
+    constexpr uint64_t LOW = 0xFFFFFFFFull;
     if (c == 1) {
-        tiny_list[pos_tiny[r]] = f;
+        tiny_list[pos_tiny[r] & LOW] = f;
     } else if (c == 2) {
-        small_list[pos_small[r]] = f;
+        small_list[pos_small[r] & LOW] = f;
     } else if (c == 3) {
-        mid_list[pos_mid[r]] = f;
-        mid_key[pos_mid[r]] = (uint64_t)__clzll((long long)(ub[r] | 1));
+        mid_list[pos_mid[r] & LOW] = f;
+        mid_key[pos_mid[r] & LOW] = (uint64_t)__clzll((long long)(ub[r] | 1));
+    } else if (c == CLS_MICRO16) {
+        m16[pos_tiny[r] >> 32] = MicroRec{f, r};
+    } else if (c == CLS_MICRO32) {
+        m32[pos_small[r] >> 32] = MicroRec{f, r};
+    } else if (c == CLS_MICRO64) {
+        m64[pos_mid[r] >> 32] = MicroRec{f, r};
     } else {
         const uint64_t pos = pos_large[r];
         const uint64_t cost = ub[r] / n;
@@ -477,6 +505,111 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
                 }
             }
             wave_sync_lds();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// MICRO rows (round 6): G = 16 / 32 / 64 lanes per row, 64 / G rows per wave, no LDS, no hash table.
+//
+// The reference's own benchmark (sprs-benches/src/main.rs:148-163: uniform density, 4 entries per row, up to 2.5 M rows) is
+// made of rows of ~16 products.  One wave per such row (small_rows_kernel) idles 48 lanes and walks a chain of nine dependent
+// round trips per row: 2.1 + 1.5 ms of the 4.6 ms product (profiles/r15a).  Here a lane group owns a row:
+//   * lane j of the group holds k_j (a micro row has at most G k's) and the bounds of B's row k_j; a group-wide prefix of the
+//     lengths places the row's expansion — k ascending, columns ascending inside a k: the reference's own order
+//     (smmp.rs:174-181) — one product per lane;
+//   * every lane meets every other lane of its group once (rotation by 1 .. G - 1): a product is the FIRST of its column when no
+//     lower lane holds the same column; the first one adds the later ones in ascending position, from 0.0 + its own — the
+//     reference's chain, bit for bit; a second rotation counts the first occurrences with a smaller column: the rank in the
+//     sorted output row (smmp.rs:124: rows come out sorted);
+//   * symbolic: the count of first occurrences.
+// ---------------------------------------------------------------------------
+template <typename IDX, typename PTR, bool NUMERIC, int G>
+__global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, const MicroRec *__restrict__ list,
+                                                         uint64_t n, uint64_t *__restrict__ count, const uint64_t *__restrict__ off,
+                                                         IDX *__restrict__ c_indices, double *__restrict__ c_data) {
+    constexpr int R = WAVE / G;
+    const uint32_t lane = threadIdx.x & (WAVE - 1), g = lane / G, gl = lane % G;
+    const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+    const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
+    for (uint64_t q0 = w0 * R; q0 < n; q0 += nw * R) {                   // wave-uniform
+        const uint64_t q = q0 + g;
+        const bool row_ok = q < n;
+        const MicroRec rec = list[row_ok ? q : n - 1];
+        const uint64_t as = (uint64_t)A.indptr[rec.r], ae = (uint64_t)A.indptr[rec.r + 1];
+        const uint64_t o = NUMERIC ? off[rec.t] : 0;                     // (requested beside the row bounds)
+        const uint32_t nk = row_ok ? (uint32_t)(ae - as) : 0u;          // <= G by the row's class
+        const bool has = gl < nk;
+        const uint64_t k = has ? (uint64_t)A.indices[as + gl] : 0;
+        double av = 0.0;
+        if constexpr (NUMERIC) av = has ? A.data[as + gl] : 0.0;
+        const uint64_t bs = has ? (uint64_t)B.indptr[k] : 0;
+        const uint32_t len = has ? (uint32_t)((uint64_t)B.indptr[k + 1] - bs) : 0u;
+        uint32_t inc = len;                                              // inclusive prefix of the lengths over the group
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            const uint32_t v = __shfl_up(inc, d, G);
+            if (gl >= (uint32_t)d) inc += v;
+        }
+        const uint32_t total = __shfl(inc, G - 1, G);                    // products of the row (<= G)
+        const bool valid = gl < total;                                   // lane = position gl of the expansion
+        uint32_t own = 0;                                                // its k: the number of group lanes whose prefix is <= gl
+#pragma unroll
+        for (int step = G / 2; step > 0; step >>= 1) {
+            const uint32_t v = __shfl(inc, (int)(own + step - 1), G);
+            if (v <= gl) own += step;
+        }
+        own &= G - 1;
+        const uint32_t inc_o = __shfl(inc, (int)own, G), len_o = __shfl(len, (int)own, G);
+        const uint64_t bs_o = __shfl(bs, (int)own, G);
+        const uint64_t pos = valid ? bs_o + (uint64_t)(gl - (inc_o - len_o)) : 0ull;   // (a lane without a product loads entry 0 and drops it)
+        uint32_t c = (uint32_t)B.indices[pos];
+        double pr = 0.0;
+        if constexpr (NUMERIC) {
+            const double av_o = __shfl(av, (int)own, G);
+            pr = av_o * B.data[pos];
+        }
+        if (!valid) c = EMPTY;                                           // (no column equals it: b_cols < 2^32 - 1 on this path)
+        bool first = valid;
+        double acc = 0.0 + pr;                                           // tmp starts at N::zero() (smmp.rs:166-170)
+        // (four exchanges in flight per step: fully unrolled the compiler hoists all G of them — 256 registers at G = 64)
+#pragma clang loop unroll(disable)
+        for (int s0 = 1; s0 < G; s0 += 4)
+#pragma unroll
+        for (int s = s0; s < s0 + 4; ++s) {
+            if (s >= G) break;
+            const int src = (int)((gl + (uint32_t)s) & (uint32_t)(G - 1));
+            const uint32_t cj = __shfl(c, src, G);
+            double pj = 0.0;
+            if constexpr (NUMERIC) pj = __shfl(pr, src, G);              // (every lane takes part in every exchange: no shuffle under a lane's condition)
+            const bool same = valid && cj == c;
+            const bool lower = gl + (uint32_t)s >= (uint32_t)G;          // the partner is a LOWER position of the expansion
+            if (same && lower) first = false;                            // ... with the same column: this one is not the first
+            if constexpr (NUMERIC) {
+                if (same && !lower) acc += pj;                           // higher positions, in ascending order: the reference's chain
+            }
+        }
+        if constexpr (!NUMERIC) {
+            const unsigned long long fm = __ballot(first);
+            if (row_ok && gl == 0) {
+                const unsigned long long mine = G == WAVE ? fm : (fm >> (g * G)) & ((1ull << (G % WAVE)) - 1ull);
+                count[rec.t] = (uint64_t)__popcll(mine);
+            }
+        } else {
+            const uint32_t key = first ? c : EMPTY;                      // only first occurrences are output columns
+            uint32_t rank = 0;
+#pragma clang loop unroll(disable)
+            for (int s0 = 1; s0 < G; s0 += 4)
+#pragma unroll
+            for (int s = s0; s < s0 + 4; ++s) {
+                if (s >= G) break;
+                const uint32_t kj = __shfl(key, (int)((gl + (uint32_t)s) & (uint32_t)(G - 1)), G);
+                rank += kj < c ? 1u : 0u;
+            }
+            if (first) {
+                if (c_indices) c_indices[o + rank] = (IDX)c;             // null: C already has its structure (numeric on a kept plan)
+                if (c_data) c_data[o + rank] = acc;                      // null: structure only (the twin of smmp::symbolic)
+            }
         }
     }
 }
@@ -1500,6 +1633,8 @@ struct sprs_hip_spgemm_plan {
     uint64_t rows = 0, inner = 0, b_cols = 0, nnz_a = 0, nnz_b = 0;
     const void *a_indptr = nullptr, *a_indices = nullptr, *b_indptr = nullptr, *b_indices = nullptr;   // whose structure it describes
     uint64_t ntask_total = 0, n_small = 0, n_mid = 0, n_large = 0, n_tiny = 0, c_nnz = 0, nb = 0;
+    uint64_t n_micro[3] = {0, 0, 0};   // micro rows of at most 16 / 32 / 64 products and k's (micro_rows_kernel)
+    sprs_hip::DevBuf micro_list[3];
     int64_t winlog = 17, midwin = 14;
     uint32_t xcd_chunk = 0;        // how the launch deals the task list to the XCDs (task_of_block)
     uint64_t kept_words = 0;       // 64-bit words per row of the kept bitmaps (0: none kept)
@@ -1678,7 +1813,8 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         hipLaunchKernelGGL((row_work_kernel<IDX, PTR>), dim3((unsigned)blocks), dim3(256), 0, stream, A, B, rows, b_cols,
                            (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint32_t)options().spgemm_minwin,
                            pl->nb ? (uint64_t)options().spgemm_mid : 0ull,      /* the wave-per-row kernel takes its window edges from the bucket table */
-                           pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), cls.as<uint8_t>(), pl->wlog.as<uint8_t>());
+                           pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), cls.as<uint8_t>(), pl->wlog.as<uint8_t>(),
+                           (options().spgemm_micro != 2 && b_cols < 0xFFFFFFFFull) ? 1u : 0u);
         SPRS_TRY_HIP(hipGetLastError());
         hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, (const uint8_t *)cls.as<uint8_t>(), pl->ntasks.as<uint64_t>(), rows,
                            is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), is_mid.as<uint64_t>(), n_large_r.as<uint64_t>());
@@ -1694,7 +1830,15 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     SPRS_TRY_HIP(hipMemcpy(&pl->n_small, pos_small.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
     SPRS_TRY_HIP(hipMemcpy(&pl->n_mid, pos_mid.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
     SPRS_TRY_HIP(hipMemcpy(&pl->n_large, pos_large.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
+    // (the micro classes' counts ride in the high halves of the tiny / small / mid scans)
+    pl->n_micro[0] = pl->n_tiny >> 32;
+    pl->n_micro[1] = pl->n_small >> 32;
+    pl->n_micro[2] = pl->n_mid >> 32;
+    pl->n_tiny &= 0xFFFFFFFFull;
+    pl->n_small &= 0xFFFFFFFFull;
+    pl->n_mid &= 0xFFFFFFFFull;
     const uint64_t ntask_total = pl->ntask_total, n_small = pl->n_small, n_mid = pl->n_mid, n_large = pl->n_large, n_tiny = pl->n_tiny;
+    for (int m = 0; m < 3; ++m) SPRS_TRY_HIP(pl->micro_list[m].alloc((pl->n_micro[m] ? pl->n_micro[m] : 1) * sizeof(MicroRec)));
     if (n_large > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many SpGEMM tasks for one launch");
 
     SPRS_TRY_HIP(pl->task_row.alloc(ntask_total * 8));
@@ -1711,7 +1855,8 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
                            pl->ub.as<uint64_t>(), rows, pos_tiny.as<uint64_t>(), pos_small.as<uint64_t>(), pos_mid.as<uint64_t>(),
                            pos_large.as<uint64_t>(), (const uint8_t *)cls.as<uint8_t>(), pl->task_row.as<uint64_t>(),
                            pl->tiny_list.as<uint64_t>(), pl->small_list.as<uint64_t>(), pl->mid_list.as<uint64_t>(),
-                           pl->large_list.as<uint64_t>(), large_key.as<uint64_t>(), mid_key.as<uint64_t>());
+                           pl->large_list.as<uint64_t>(), large_key.as<uint64_t>(), mid_key.as<uint64_t>(),
+                           pl->micro_list[0].as<MicroRec>(), pl->micro_list[1].as<MicroRec>(), pl->micro_list[2].as<MicroRec>());
         SPRS_TRY_HIP(hipGetLastError());
     }
     // costliest tasks first (stable sort by cost class); option spgemm_task_order = 2 keeps the row order (A/B)
@@ -1765,6 +1910,22 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         if (g > 256 * 32) g = 256 * 32;
         return dim3((unsigned)g);
     };
+    auto micro_grid = [&](uint64_t n_rows, int per_wave) {
+        uint64_t g = ((n_rows + per_wave - 1) / per_wave + 3) / 4;       // four waves per block
+        if (g > 256 * 8) g = 256 * 8;                                    // what the chip holds at once; the waves stride over the list
+        return dim3((unsigned)g);
+    };
+#define SPRS_MICRO_SYM(M, GV)                                                                                                       \
+    if (pl->n_micro[M]) {                                                                                                           \
+        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, false, GV>), micro_grid(pl->n_micro[M], WAVE / GV), dim3(256), 0, wstream, A, B, \
+                           (const MicroRec *)pl->micro_list[M].as<MicroRec>(), pl->n_micro[M], pl->count.as<uint64_t>(),             \
+                           (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);                                            \
+        SPRS_TRY_HIP(hipGetLastError());                                                                                            \
+    }
+    SPRS_MICRO_SYM(0, 16)
+    SPRS_MICRO_SYM(1, 32)
+    SPRS_MICRO_SYM(2, 64)
+#undef SPRS_MICRO_SYM
     if (n_tiny) {
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, wstream,
                            A, B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
@@ -1924,6 +2085,19 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     uint32_t bin_shift = 0;
     while (bin_shift < 32 && ((pl->b_cols - (pl->b_cols ? 1 : 0)) >> bin_shift) >= (uint64_t)SM_NBIN) ++bin_shift;
     const uint32_t small_flags = add_flags();
+#define SPRS_MICRO_NUM(M, GV)                                                                                                       \
+    if (pl->n_micro[M]) {                                                                                                           \
+        uint64_t mg = ((pl->n_micro[M] + (WAVE / GV) - 1) / (WAVE / GV) + 3) / 4;                                                     \
+        if (mg > 256 * 8) mg = 256 * 8;                                                                                             \
+        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, true, GV>), dim3((unsigned)mg), dim3(256), 0, wstream, A, B,                 \
+                           (const MicroRec *)pl->micro_list[M].as<MicroRec>(), pl->n_micro[M], pl->count.as<uint64_t>(),             \
+                           (const uint64_t *)pl->off.as<uint64_t>(), c_indices, c_values);                                           \
+        SPRS_TRY_HIP(hipGetLastError());                                                                                            \
+    }
+    SPRS_MICRO_NUM(0, 16)
+    SPRS_MICRO_NUM(1, 32)
+    SPRS_MICRO_NUM(2, 64)
+#undef SPRS_MICRO_NUM
     if (n_tiny)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, wstream, A,
                            B, pl->tiny_list.as<uint64_t>(), n_tiny, pl->task_row.as<uint64_t>(), pl->ub.as<uint64_t>(),
