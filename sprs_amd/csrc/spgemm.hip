@@ -532,17 +532,35 @@ __global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, Cs
     const uint32_t lane = threadIdx.x & (WAVE - 1), g = lane / G, gl = lane % G;
     const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
-    for (uint64_t q0 = w0 * R; q0 < n; q0 += nw * R) {                   // wave-uniform
+    // A row is a chain of dependent round trips (record -> bounds of the A row -> k's -> bounds of the B rows -> entries) and a
+    // wave has nothing else to do meanwhile: the record of the row after next and the bounds of the next row are requested while
+    // this row is worked on — three round trips per row instead of five.
+    const uint64_t stride = nw * R;
+    auto load_rec = [&](uint64_t qq0) {
+        const uint64_t qq = qq0 + g;
+        return list[qq < n ? qq : n - 1];
+    };
+    MicroRec rec = load_rec(w0 * R), rec1 = load_rec(w0 * R + stride);
+    uint64_t as = (uint64_t)A.indptr[rec.r], ae = (uint64_t)A.indptr[rec.r + 1];
+    uint64_t o = NUMERIC ? off[rec.t] : 0;
+    for (uint64_t q0 = w0 * R; q0 < n; q0 += stride) {                   // wave-uniform
+        const MicroRec rec2 = load_rec(q0 + 2 * stride);
+        const uint64_t as1 = (uint64_t)A.indptr[rec1.r], ae1 = (uint64_t)A.indptr[rec1.r + 1];
+        const uint64_t o1 = NUMERIC ? off[rec1.t] : 0;
+        const uint64_t as_c = as, ae_c = ae, o_c = o;
+        const MicroRec rec_c = rec;
+        rec = rec1;                                                      // (handed on: the body below works on the _c copies)
+        rec1 = rec2;
+        as = as1;
+        ae = ae1;
+        o = o1;
         const uint64_t q = q0 + g;
         const bool row_ok = q < n;
-        const MicroRec rec = list[row_ok ? q : n - 1];
-        const uint64_t as = (uint64_t)A.indptr[rec.r], ae = (uint64_t)A.indptr[rec.r + 1];
-        const uint64_t o = NUMERIC ? off[rec.t] : 0;                     // (requested beside the row bounds)
-        const uint32_t nk = row_ok ? (uint32_t)(ae - as) : 0u;          // <= G by the row's class
+        const uint32_t nk = row_ok ? (uint32_t)(ae_c - as_c) : 0u;      // <= G by the row's class
         const bool has = gl < nk;
-        const uint64_t k = has ? (uint64_t)A.indices[as + gl] : 0;
+        const uint64_t k = has ? (uint64_t)A.indices[as_c + gl] : 0;
         double av = 0.0;
-        if constexpr (NUMERIC) av = has ? A.data[as + gl] : 0.0;
+        if constexpr (NUMERIC) av = has ? A.data[as_c + gl] : 0.0;
         const uint64_t bs = has ? (uint64_t)B.indptr[k] : 0;
         const uint32_t len = has ? (uint32_t)((uint64_t)B.indptr[k + 1] - bs) : 0u;
         uint32_t inc = len;                                              // inclusive prefix of the lengths over the group
@@ -593,7 +611,7 @@ __global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, Cs
             const unsigned long long fm = __ballot(first);
             if (row_ok && gl == 0) {
                 const unsigned long long mine = G == WAVE ? fm : (fm >> (g * G)) & ((1ull << (G % WAVE)) - 1ull);
-                count[rec.t] = (uint64_t)__popcll(mine);
+                count[rec_c.t] = (uint64_t)__popcll(mine);
             }
         } else {
             const uint32_t key = first ? c : EMPTY;                      // only first occurrences are output columns
@@ -607,8 +625,8 @@ __global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, Cs
                 rank += kj < c ? 1u : 0u;
             }
             if (first) {
-                if (c_indices) c_indices[o + rank] = (IDX)c;             // null: C already has its structure (numeric on a kept plan)
-                if (c_data) c_data[o + rank] = acc;                      // null: structure only (the twin of smmp::symbolic)
+                if (c_indices) c_indices[o_c + rank] = (IDX)c;             // null: C already has its structure (numeric on a kept plan)
+                if (c_data) c_data[o_c + rank] = acc;                      // null: structure only (the twin of smmp::symbolic)
             }
         }
     }
