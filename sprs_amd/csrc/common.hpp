@@ -68,6 +68,7 @@ constexpr bool DEVTOOLS = false;
     X(spmv_band_debug, 0, 0, 255, 1)    /* TIMING EXPERIMENTS ONLY (wrong results): hot kernel 1 no stores of the row sums, 2 one row start per lane, 4 none */ \
     X(spmv_band_tail, 0, 0, 2, 0)       /* with the overlap: 0/1 the reduction of the long rows starts when the hot slices and the cold pieces are done, beside what is left of the short rows; 2 it waits for the whole second stream (rounds 2-4, A/B); on ONE stream (small plans): 0/1 the short rows share the reduction's launch (band_tail_kernel), 2 they run as their own launch in front of the hot slices (round 5) */ \
     X(spmv_band_balance, 0, 0, 2, 0)    /* shares of the hot workgroups: by modelled COST of their tiles (1 + row ends / 180) — 0 auto (small plans, whose hot kernel runs alone on one stream), 1 on, 2 off (equal tile counts) */ \
+    X(spmv_band_xcd, 0, 0, 2, 0)        /* hot workgroups: every XCD takes a contiguous run of shares (its L2 serves a slice's x tile to its neighbours) — 0 auto (small plans), 1 on, 2 off (shares dealt round-robin over the XCDs) */ \
     X(spmv_band_share, 0, 0, 1ll << 30, 0) /* wave tiles per workgroup of the hot kernel (0 = default: an equal share for rounds x CUs workgroups) */ \
     X(spmv_band_hot_run, 0, 0, 4096, 0) /* consecutive wave tiles per range of the hot kernel (0 = default 4); a workgroup streams 16 neighbouring ranges */ \
     X(spmv_band_cold_tiles, 0, 0, 64, 0) /* consecutive wave tiles per wave of the cold kernel (0 = default 4) */                 \

@@ -359,6 +359,7 @@ struct BandPlan {
     uint32_t *rowidx_all = nullptr, *tile_row_all = nullptr;
     Seg *segs = nullptr;                           // hot segments (workgroup by workgroup), then one segment per cold piece, the short piece
     HotSeg *hsegs = nullptr;                       // the hot segments again, as the hot kernel reads them (one record each)
+    HotSeg *wg_first = nullptr;                    // per hot workgroup: its first segment's record with the segment range in the pad words
     uint32_t *wg_seg = nullptr;                    // hot workgroup b takes segments wg_seg[b] .. wg_seg[b + 1] - 1
     uint32_t nranges = 0, nsegs = 0, hot_wgs = 0, cold_tiles = 4, hot_run = 4;
     void *spills_y = nullptr;                      // Spill records (device) of the short rows: into y, by band_carry_kernel
@@ -395,6 +396,7 @@ void band_free(BandPlan *bp) {
     drop(bp->tile_row_all);
     drop(bp->segs);
     drop(bp->hsegs);
+    drop(bp->wg_first);
     drop(bp->rspills);
     drop(bp->rsp_off);
     drop(bp->spills_y);
@@ -783,10 +785,18 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
             const BandPiece &d = bp->host_pieces[sg.piece];
             hs[i] = HotSeg{d.ent0, d.nnz, d.tile_row, bp->pair_off[sg.piece], d.x0, sg.tile0, sg.ntiles, sg.range0, sg.run, 0u, 0u, 0u};
         }
+        std::vector<HotSeg> wf(bp->hot_wgs);
+        for (uint32_t b = 0; b < bp->hot_wgs; ++b) {
+            wf[b] = hs[wg_seg[b]];
+            wf[b].pad0 = wg_seg[b];
+            wf[b].pad1 = wg_seg[b + 1];
+        }
+        SPRS_TRY_HIP(hipMalloc((void **)&bp->wg_first, (wf.size() + 1) * sizeof(HotSeg)));
+        SPRS_TRY_HIP(hipMemcpyAsync(bp->wg_first, wf.data(), wf.size() * sizeof(HotSeg), hipMemcpyHostToDevice, stream));
         SPRS_TRY_HIP(hipMalloc((void **)&bp->hsegs, (hs.size() + 1) * sizeof(HotSeg)));
         SPRS_TRY_HIP(hipMemcpyAsync(bp->hsegs, hs.data(), hs.size() * sizeof(HotSeg), hipMemcpyHostToDevice, stream));
         SPRS_TRY_HIP(hipStreamSynchronize(stream));                      // (hs goes out of scope)
-        bp->bytes += hs.size() * sizeof(HotSeg);
+        bp->bytes += (hs.size() + wf.size()) * sizeof(HotSeg);
     }
 
     std::vector<ColdGroup> groups;
@@ -968,16 +978,17 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
             }
             prof = buf;
         }
+        const uint32_t xcd_shares = options().spmv_band_xcd == 1 || (options().spmv_band_xcd == 0 && bp->small) ? 1u : 0u;
         if (bp->xt_log2 == 13)
             hipLaunchKernelGGL((band_hot_kernel<13>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const HotSeg *)bp->hsegs,
-                               (const uint32_t *)bp->wg_seg,
+                               (const HotSeg *)bp->wg_first,
                                (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->partial, sc->carry,
-                               (uint32_t)options().spmv_band_debug, prof);
+                               (uint32_t)options().spmv_band_debug, prof, xcd_shares);
         else
             hipLaunchKernelGGL((band_hot_kernel<14>), dim3(bp->hot_wgs), dim3(HOT_THREADS), lds, stream, (const HotSeg *)bp->hsegs,
-                               (const uint32_t *)bp->wg_seg,
+                               (const HotSeg *)bp->wg_first,
                                (const double *)bp->vals_hot, (const uint16_t *)bp->cid_hot, (const double *)sc->xp, sc->partial, sc->carry,
-                               (uint32_t)options().spmv_band_debug, prof);
+                               (uint32_t)options().spmv_band_debug, prof, xcd_shares);
         SPRS_TRY_HIP(hipGetLastError());
         if (DEVTOOLS && prof && getenv("SPRS_HIP_HOTPROF")) {      // (synchronous: a developer printout, not a timing run)
             SPRS_TRY_HIP(hipStreamSynchronize(stream));

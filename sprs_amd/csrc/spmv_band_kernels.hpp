@@ -283,10 +283,10 @@ __device__ __forceinline__ void band_tile_sums(const double (&pr)[EPL], uint32_t
 // (at 98 it was one, and the cold launch crawled beside the hot one: 370 us instead of 86 alone, profiles/r05h)
 template <int XT_LOG2>
 __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kernel(const HotSeg *__restrict__ hsegs,
-                                                               const uint32_t *__restrict__ wg_seg, const double *__restrict__ vals,
+                                                               const HotSeg *__restrict__ wg_first, const double *__restrict__ vals,
                                                                const uint16_t *__restrict__ cid, const double *__restrict__ xp,
                                                                double *__restrict__ partial, double *__restrict__ carry, uint32_t dbg,
-                                                               unsigned long long *__restrict__ prof) {
+                                                               unsigned long long *__restrict__ prof, uint32_t xcd_shares) {
     constexpr int XT = 1 << XT_LOG2;
     // developer builds, option spmv_band_debug & 16 (env SPRS_HIP_HOTPROF): when does each workgroup start, see its first x tile,
     // and end (100 MHz wall clock) — is the hot kernel's time its work or its tail?
@@ -303,8 +303,19 @@ __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kern
     double *xs = lds;                                                    // XT doubles: the x tile
     const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
     double *stage = lds + XT + wave * STG;                              // the wave's window for outgoing sums
-    const uint32_t s0 = wg_seg[blockIdx.x], s1 = wg_seg[blockIdx.x + 1];
-    HotSeg nxt = hsegs[s0];
+    // share of this workgroup.  xcd_shares: block b runs on XCD b % 8 (observed dispatch order; only speed depends on it) and every
+    // XCD takes a CONTIGUOUS run of shares — the workgroups that stream one slice then sit behind one L2, which serves its x tile
+    // to all but the first of them (dealt round-robin, every XCD's L2 fetched every slice: 256 workgroups x 128 KiB = 32 MB through
+    // the fabric in the first microseconds of a small plan's hot kernel).
+    uint32_t share = blockIdx.x;
+    if (xcd_shares) {
+        const uint32_t nq = gridDim.x >> 3, rem = gridDim.x & 7u, k = blockIdx.x & 7u;
+        share = k * nq + (k < rem ? k : rem) + (blockIdx.x >> 3);
+    }
+    // the share's FIRST segment comes with its segment range in one record (wg_first[share]: pad0 / pad1 = first segment, end) —
+    // one round trip in front of the first x tile instead of two (wg_seg -> hsegs)
+    HotSeg nxt = wg_first[share];
+    const uint32_t s0 = nxt.pad0, s1 = nxt.pad1;
     for (uint32_t s = s0; s < s1; ++s) {
         const HotSeg seg = nxt;
         if (s + 1 < s1) nxt = hsegs[s + 1];                              // (requested a whole segment before it is needed)
@@ -704,7 +715,10 @@ __device__ __forceinline__ uint32_t band_mask_rank(uint32_t m_lo, uint32_t m_hi,
 // partials of the block inside a piece are a contiguous run cut into chunks of 64, loaded with every lane busy together with
 // one byte per pair that names the row, added with ds_add_f64 — 4 x fewer, full load instructions: 126 - 134 us against
 // 122 us, and 99 us even with the partial array read front to back and neither adds nor stores (profiles/r13h ... r13k).  The
-// reduction is not bound by its instruction count or its access pattern; the form with the smaller tables stayed.)
+// reduction is not bound by its instruction count or its access pattern; the form with the smaller tables stayed.
+// Round 6 tried TWO lanes per row for small plans (a wave per 32 rows, lane l / l + 32 summing the lower / upper 32 pieces of a
+// chunk, half the dependent groups per wave, twice the waves): R-MAT 1M 21.6 us against 15.4 us alone, 28.6 against 21.7 us
+// inside the tail launch (profiles/r15l) — not a chain of round trips either.)
 struct ReduceArgs {
     const double *partial;
     const unsigned long long *wmask;
