@@ -207,9 +207,13 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
         const bool ok = r < rows;
         const uint64_t s = ok ? (uint64_t)A.indptr[r] : 0, e = ok ? (uint64_t)A.indptr[r + 1] : 0;
         uint64_t acc = 0;
-        for (uint64_t p = s + sl; p < e; p += 16) {
-            const uint64_t k = (uint64_t)A.indices[p];
-            acc += (uint64_t)B.indptr[k + 1] - (uint64_t)B.indptr[k];
+        for (uint64_t p = s + sl; p < e; p += 64) {                      // four strides of the 16 lanes in flight (a hub row of 2e4 k's is this pass's tail)
+            uint64_t k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = p + 16 * u < e ? (uint64_t)A.indices[p + 16 * u] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k[u] != ~0ull) acc += (uint64_t)B.indptr[k[u] + 1] - (uint64_t)B.indptr[k[u]];
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);   // the 16 lanes of the row

@@ -712,7 +712,9 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
         // three on R-MAT 1M, profiles/r15d: every workgroup pays ~5 us for its first x tile, 256 CUs asking for theirs at once)
         const uint64_t rounds = o.spmv_band_rounds > 0 ? (uint64_t)o.spmv_band_rounds
                                 : (small_hot ? (o.spmv_band_balance == 2 ? 2 : 1) : 3);
-        if (o.spmv_band_hot_run <= 0 && small_hot) bp->hot_run = 1;
+        // (small plans: single-tile ranges until round 6; with one balanced round a workgroup holds ~115 tiles, 7 per wave, and ranges of
+        // two halve the heads the reduction reads: R-MAT 1M 0.0682 - 0.0687 against 0.0699 - 0.0701 ms, ranges of four 0.0768, gpurun_out/r15m)
+        if (o.spmv_band_hot_run <= 0 && small_hot) bp->hot_run = 2;
         bp->small = small_hot;
         // SHARES BY COST (small plans; option spmv_band_balance): a tile of a late slice holds ten times the row ends of an early one
         // and takes up to three times as long (every row end is a partial sum to scan, stage and store: 658 us against 470 us without
