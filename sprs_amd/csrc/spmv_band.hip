@@ -954,6 +954,10 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         SPRS_TRY_HIP(hipGetLastError());
         return SPRS_HIP_OK;
     };
+    const uint32_t cut = bp->has_short_group ? bp->short_first_block : bp->cold_blocks;
+    // small plans on one stream: the short rows share the reduction's launch (band_tail_kernel); spmv_band_tail = 2: their own launch in
+    // front of the hot slices (round 5, A/B)
+    const bool fused_tail = !overlap && bp->small && options().spmv_band_tail != 2 && bp->cold_blocks > cut;
     auto launch_hot = [&]() -> int32_t {
         if (!bp->hot_wgs) return SPRS_HIP_OK;
         const uint32_t lds = hot_lds_bytes(bp->xt_log2);
@@ -1020,7 +1024,6 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         return SPRS_HIP_OK;
     };
     // blocks [b0, b0 + nb) of the gather launch: cold pieces (partial sums out) below `cut`, short rows (y out) from there on
-    const uint32_t cut = bp->has_short_group ? bp->short_first_block : bp->cold_blocks;
     auto cold_args = [&](uint32_t b0) {
         return ColdArgs{sc->pieces, bp->groups, bp->ngroups, bp->vals_cold, bp->cid_cold, sc->xp, y, sc->carry, b0, bp->cold_tiles, 0u, BandPiece()};
     };
@@ -1033,8 +1036,6 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         SPRS_TRY_HIP(hipGetLastError());
         return SPRS_HIP_OK;
     };
-    // small plans on one stream: the short rows share the reduction's launch (band_tail_kernel)
-    const bool fused_tail = !overlap && bp->small && options().spmv_band_tail != 2 && bp->cold_blocks > cut;
 
     if (split_permute)
         hipLaunchKernelGGL(band_gather_hot_kernel, dim3((bp->hot_labels + 255) / 256), dim3(256), 0, stream, x,

@@ -281,6 +281,15 @@ __device__ __forceinline__ void band_tile_sums(const double (&pr)[EPL], uint32_t
 // ---------------------------------------------------------------------------------------------
 // 96 VGPRs: the 4 waves per SIMD of this kernel then leave room for TWO 64-register waves of the gather kernels beside them
 // (at 98 it was one, and the cold launch crawled beside the hot one: 370 us instead of 86 alone, profiles/r05h)
+template <bool ACC, bool TOY>
+__device__ __forceinline__ void band_cold_wave(const PieceView d, uint32_t r, uint32_t ct, const double *__restrict__ vals,
+                                               const uint32_t *__restrict__ cid, const double *__restrict__ xp, double *__restrict__ y,
+                                               double *__restrict__ carry, double *stage, uint32_t lane);
+
+// (Round 6 also ran the short rows in THIS kernel's prologue — the upper 8 waves of a workgroup walking short-row ranges while the lower
+// 8 fetched the first x tile: the short tile's chain of round trips, 13 us, then stood in front of every workgroup's first hot tile:
+// hot kernel 36.7 -> 45.7 us for a reduction alone of 12.4 instead of a 19.3 us tail, 0.0696 - 0.0702 against 0.0684 - 0.0689 ms on
+// R-MAT 1M, profiles/r15o.  Not kept.)
 template <int XT_LOG2>
 __global__ __launch_bounds__(HOT_THREADS) SPRS_HOT_WAVES_ATTR void band_hot_kernel(const HotSeg *__restrict__ hsegs,
                                                                const HotSeg *__restrict__ wg_first, const double *__restrict__ vals,
@@ -490,7 +499,14 @@ __device__ __forceinline__ void band_cold_body(const ColdArgs &ca, uint32_t bloc
         r = (cg.npieces == 1 ? lb : (lb >> 3)) * WPB + wave;
         pc = pieces[pi];
     }
-    const PieceView d(pc);
+    band_cold_wave<ACC, TOY>(PieceView(pc), r, ct, vals, cid, xp, y, carry, stage, lane);
+}
+
+// one wave, one range (ct consecutive tiles) of a gather piece
+template <bool ACC, bool TOY>
+__device__ __forceinline__ void band_cold_wave(const PieceView d, uint32_t r, uint32_t ct, const double *__restrict__ vals,
+                                               const uint32_t *__restrict__ cid, const double *__restrict__ xp, double *__restrict__ y,
+                                               double *__restrict__ carry, double *stage, uint32_t lane) {
     const uint32_t t0 = r * ct;
     if (t0 >= d.ntiles) return;                                          // wave-uniform; no workgroup barrier below
     const uint32_t tend = t0 + ct < d.ntiles ? t0 + ct : d.ntiles;
@@ -510,8 +526,16 @@ __device__ __forceinline__ void band_cold_body(const ColdArgs &ca, uint32_t bloc
     bool mine = false;
     uint32_t last = 0;
     SPRS_GLOBAL_AS double *cslot = (SPRS_GLOBAL_AS double *)carry + d.range0 + r;
+    // Where a short row's sum goes (rowidx) is known as soon as the tile's first row is: the rows that end in a tile are the compact
+    // rows R0 - 1 + o, o = lane + 64 m — requested for m < 4 (256 row ends; R-MAT's short rows: ~195 per tile) beside the gathers
+    // instead of one dependent load per flush pass (a short tile was a chain of six round trips, four of them these: 13 us on
+    // R-MAT 1M whichever launch it ran in, profiles/r15n).
+    uint32_t yr_pre[4] = {0u, 0u, 0u, 0u}, yr_base = 0;
     auto emit_y = [&](uint32_t row, double v) {
-        const uint32_t yr = d.rowidx[row];
+        const uint32_t m = (row - yr_base) >> 6;                         // wave-uniform inside a flush pass; lane 0's last row: whatever
+        uint32_t yr;
+        if (TOY && m < 4u && ((row - yr_base) & 63u) == lane) yr = m == 0 ? yr_pre[0] : m == 1 ? yr_pre[1] : m == 2 ? yr_pre[2] : yr_pre[3];
+        else yr = d.rowidx[row];
         if constexpr (ACC) y[yr] = y[yr] + v;                            // every compact row has entries: empty rows are never touched (prod.rs:120-126)
         else y[yr] = v;
     };
@@ -526,6 +550,14 @@ __device__ __forceinline__ void band_cold_body(const ColdArgs &ca, uint32_t bloc
             const uint32_t c = lw[q / 4][q % 4];
             xv[q] = xp[c & ~ROW_START32];                                // padding: label 0, value 0, never summed into a row
             fb |= (c >> 31) << q;
+        }
+        if constexpr (TOY) {
+            yr_base = R0n - 1u;                                          // (tile 0 of the piece: R0n = 0, the wrap only names the range's open row, which has no y)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint32_t rr = yr_base + lane + 64u * (uint32_t)m;
+                yr_pre[m] = d.rowidx[rr < d.nr ? rr : d.nr - 1u];
+            }
         }
         double pr[EPL];
 #pragma unroll
