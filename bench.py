@@ -778,8 +778,8 @@ def main():
     except (OSError, KeyError, ValueError):
         traffic = None
     plan_kind, plan_bytes = handles[id(sh.block)].spmv_plan_info() if handles else (0, 0)
-    kernel_name = {3: "all kernels of one SpMV on the banded plan: band_permute + band_hot (x tile in LDS) + band_cold "
-                      "(cold pieces, short rows) + band_carry + band_reduce",
+    kernel_name = {3: "all kernels of one SpMV on the banded plan: band_gather (x into the plan's labelling) + band_hot (x tile in LDS) + "
+                      "band_cold (cold pieces, short rows) + band_reduce (small plans: band_tail = reduction + short rows)",
                    2: "all kernels of one SpMV on the XCD-sliced plan: rl_permute_x + spmv_tile (short rows) + spmv_sliced + carry / reduce kernels",
                    1: "sprs_hip::spmv_tile_kernel (+ spmv_carry_kernel)"}.get(plan_kind, "sprs_hip::spmv_rowwave_kernel")
     out = {

@@ -15,7 +15,8 @@ import sys
 
 PER_SPMV = ("spmv_tile_kernel", "spmv_sliced_kernel", "spmv_carry_kernel", "spmv_sliced_carry_kernel",
             "xcs_reduce_kernel", "spmv_rowwave_kernel", "rl_permute_x_kernel",
-            "band_permute_kernel", "band_gather_hot_kernel", "band_hot_kernel", "band_cold_kernel", "band_carry_kernel", "band_reduce_kernel")
+            "band_permute_kernel", "band_gather_hot_kernel", "band_gather_kernel", "band_hot_kernel", "band_cold_kernel", "band_carry_kernel", "band_reduce_kernel",
+            "band_tail_kernel")
 
 
 def main():

@@ -38,8 +38,8 @@ constexpr int MAX_HOT = 384;
 constexpr int MAX_PHASES = 8;
 constexpr int MAX_PIECES = MAX_HOT + 8 * MAX_PHASES + 1;
 
-__global__ __launch_bounds__(256) void bp_inverse_hot_kernel(const uint32_t *__restrict__ perm, uint64_t cols, uint32_t hot_labels,
-                                                             uint32_t *__restrict__ inv_hot) {
+__global__ __launch_bounds__(256) void bp_inverse_kernel(const uint32_t *__restrict__ perm, uint64_t cols, uint32_t hot_labels,
+                                                         uint32_t *__restrict__ inv_hot) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= cols) return;
     const uint32_t l = perm[j];
@@ -351,7 +351,8 @@ struct BandPlan {
     uint32_t n_long = 0, n_short_rows = 0;
     uint64_t cols = 0, cols_pad = 0;
     uint32_t *perm = nullptr, *long_rows = nullptr;
-    uint32_t *inv_hot = nullptr;                   // column of each hot label (0xFFFFFFFF: label not in use)
+    uint32_t *inv_hot = nullptr;                   // inverse of the labelling for the labels of REFERENCED columns: inv_hot[l] = column
+    uint32_t nref = 0;                             // referenced columns = labels in use ([nref, cols) are the columns nobody references)
     uint32_t hot_labels = 0;                       // nh << xt_log2, at most cols_pad
     double *vals_hot = nullptr, *vals_cold = nullptr;
     uint16_t *cid_hot = nullptr;
@@ -500,12 +501,14 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     }
 
     // ---- labels ---------------------------------------------------------------------------
-    SPRS_TRY(build_column_labels<IDX>(ix, nnz, cols, stream, &bp->perm));
+    uint64_t nref = 0;
+    SPRS_TRY(build_column_labels<IDX>(ix, nnz, cols, stream, &bp->perm, &nref));
+    bp->nref = (uint32_t)nref;
     bp->hot_labels = (uint32_t)(map.hot_labels < bp->cols_pad ? map.hot_labels : bp->cols_pad);
-    SPRS_TRY_HIP(hipMalloc((void **)&bp->inv_hot, ((uint64_t)bp->hot_labels + 1) * 4));
-    SPRS_TRY_HIP(hipMemsetAsync(bp->inv_hot, 0xFF, ((uint64_t)bp->hot_labels + 1) * 4, stream));
-    hipLaunchKernelGGL(bp_inverse_hot_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, (const uint32_t *)bp->perm,
-                       cols, bp->hot_labels, bp->inv_hot);
+    SPRS_TRY_HIP(hipMalloc((void **)&bp->inv_hot, (nref + 4) * 4));
+    SPRS_TRY_HIP(hipMemsetAsync(bp->inv_hot, 0, (nref + 4) * 4, stream));
+    hipLaunchKernelGGL(bp_inverse_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, (const uint32_t *)bp->perm,
+                       cols, bp->nref, bp->inv_hot);
     SPRS_TRY_HIP(hipGetLastError());
 
     // ---- short piece + list of long rows ------------------------------------------------------
@@ -637,7 +640,7 @@ int32_t band_build_t(sprs_hip_csmat *a, hipStream_t stream, BandPlan **out) {
     SPRS_TRY_HIP(hipMalloc((void **)&bp->rowidx_all, (row_off + n_short_rows + 1) * 4));
     SPRS_TRY_HIP(hipMalloc((void **)&bp->tile_row_all, (tile_off + 1) * 4));
     bp->bytes = (hot_entries + WT) * 10 + (cold_ent + WT) * 12 + (row_off + n_short_rows + tile_off) * 4 + cols * 4 + n_long * 4 +
-                ((uint64_t)bp->hot_labels + 1) * 4;
+                ((uint64_t)bp->nref + 4) * 4;
     // short piece: its entries go straight into place (piece 0 of the cold arrays), its row lists are copied
     hipLaunchKernelGGL((bp_fill_short_kernel<IDX, PTR>), dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, stream, ip, ix,
                        a->data, rows, short_pos.u64(), short_ptr.u64(), long_pos.u64(), bp->perm, (uint32_t *)nullptr,
@@ -943,7 +946,6 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
     const bool overlap = options().spmv_band_overlap != 2 && bp->hot_wgs && bp->cold_blocks && (!bp->small || options().spmv_band_overlap == 1);
     const bool split_permute = overlap && options().spmv_band_split_permute != 2 && bp->hot_labels;
     const bool early_reduce = overlap && options().spmv_band_tail != 2;
-    const uint64_t span = acc ? bp->cols : (bp->cols > a->rows ? bp->cols : a->rows);
     hipStream_t cstream = overlap ? sc->aux : stream;
     // the short rows' heads go into y behind them (the long rows' are read by the reduction itself)
     auto launch_carry_y = [&](hipStream_t st) -> int32_t {
@@ -1037,23 +1039,38 @@ int32_t band_spmv(sprs_hip_csmat *a, BandPlan *bp, const double *x, double *y, b
         return SPRS_HIP_OK;
     };
 
-    if (split_permute)
-        hipLaunchKernelGGL(band_gather_hot_kernel, dim3((bp->hot_labels + 255) / 256), dim3(256), 0, stream, x,
-                           (const uint32_t *)bp->inv_hot, bp->hot_labels, sc->xp);
-    else
-        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, stream, x,
-                           (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, 0u);
-    SPRS_TRY_HIP(hipGetLastError());
+    // x into the plan's labelling (referenced columns only) and y cleared: one launch; with the overlap the hot labels first, the
+    // rest and y on the second stream beside the hot kernel (option spmv_band_split_permute)
+    const bool by_gather = (uint64_t)bp->nref * 3 <= bp->cols;        // (see band_gather_kernel)
+    auto launch_xp = [&](uint32_t l0, uint32_t l1, bool clear_y, hipStream_t st, bool hot_only = false) -> int32_t {
+        if (!by_gather && !hot_only) {                                   // the scatter form; a big plan's hot labels are always gathered
+            const uint64_t span = clear_y ? std::max<uint64_t>(bp->cols, a->rows) : bp->cols;
+            hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, st, x, (const uint32_t *)bp->perm, bp->cols,
+                               sc->xp, clear_y ? y : (double *)nullptr, a->rows, l0, (uint32_t)bp->cols_pad);     // (every label from l0 on: leaving out the
+            // unreferenced columns' stores made R-MAT 10M 5 - 8 % SLOWER on average — 1.10 - 1.14 against 1.05 ms, same best step —, gpurun_out/r15x)
+            SPRS_TRY_HIP(hipGetLastError());
+            return SPRS_HIP_OK;
+        }
+        const uint64_t n4 = std::max<uint64_t>(l1 > l0 ? ((uint64_t)(l1 - l0) + 3) / 4 : 0, clear_y ? (a->rows + 3) / 4 : 0);
+        if (!n4) return SPRS_HIP_OK;
+        if (clear_y)
+            hipLaunchKernelGGL(band_gather_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, (const uint32_t *)bp->inv_hot, l0,
+                               l1 > l0 ? l1 : l0, sc->xp, y, a->rows);
+        else
+            hipLaunchKernelGGL(band_gather_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, (const uint32_t *)bp->inv_hot, l0,
+                               l1 > l0 ? l1 : l0, sc->xp, (double *)nullptr, a->rows);
+        SPRS_TRY_HIP(hipGetLastError());
+        return SPRS_HIP_OK;
+    };
+    const uint32_t hot_end = bp->hot_labels < bp->nref ? bp->hot_labels : bp->nref;
+    if (split_permute) SPRS_TRY(launch_xp(0u, hot_end, false, stream, true));
+    else SPRS_TRY(launch_xp(0u, bp->nref, !acc, stream));
     if (overlap) {
         SPRS_TRY_HIP(hipEventRecord(sc->fork, stream));           // the hot labels of xp (or all of it, and the cleared y) are ready
         SPRS_TRY(launch_hot());
         SPRS_TRY_HIP(hipStreamWaitEvent(sc->aux, sc->fork, 0));
     }
-    if (split_permute) {
-        hipLaunchKernelGGL(band_permute_kernel, dim3((unsigned)((span + 1023) / 1024)), dim3(256), 0, cstream, x,
-                           (const uint32_t *)bp->perm, bp->cols, sc->xp, acc ? (double *)nullptr : y, a->rows, bp->hot_labels);
-        SPRS_TRY_HIP(hipGetLastError());
-    }
+    if (split_permute) SPRS_TRY(launch_xp(hot_end, bp->nref, !acc, cstream));
     SPRS_TRY(launch_gather(0, cut));
     if (early_reduce) SPRS_TRY_HIP(hipEventRecord(sc->cold_done, sc->aux));
     if (!fused_tail) SPRS_TRY(launch_gather(cut, bp->cold_blocks - cut));

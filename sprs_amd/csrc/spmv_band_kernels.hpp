@@ -674,23 +674,60 @@ __global__ __launch_bounds__(256) void band_carry_kernel(const Spill *__restrict
     *dst = acc;
 }
 
-// xp[label[c]] = x[c] for the labels from first_label on, y cleared: four consecutive columns / rows per thread (16-byte
-// loads; one column per thread left this kernel latency-bound beside the hot kernel: 360 us instead of 50, profiles/r05e)
+// x in the plan's labelling: xp[l] = x[inv[l]] for the labels l0 <= l < l1, four per thread (one 16-byte load of inv, four
+// gathers, two 16-byte stores), and y cleared, four rows per thread.  Only the labels of REFERENCED columns are moved (the
+// columns nobody references are the last class of the labelling: on R-MAT 47 % of them, in a rank's block of an 8-way cut most;
+// xp behind them stays 0.0 and is never read).  Until round 6 this was a scatter over all columns (xp[label[c]] = x[c]: eight-byte
+// stores to ten million places) with only the hot labels gathered; the gather reads x in ascending order inside a popularity
+// class and writes whole lines.  The hot kernel needs only the hot labels: big plans gather those first on the main stream and
+// the rest (and the clearing of y) on the second stream beside it.
+// Measured against the scatter below in one session (gpurun_out/r15u): a rank's block of the 8-way cut of R-MAT 10M (a quarter of the
+// columns referenced) 0.208 - 0.216 against 0.228 - 0.231 ms; the whole R-MAT 10M (53 % referenced) 1.08 - 1.11 against 1.04 - 1.07 ms — the
+// gathers of x cost the fabric more lines than the scatter's stores once most columns take part; R-MAT 1M equal.  So: the gather
+// when at most a third of the columns are referenced, the scatter over all columns otherwise.
+// (CLEAR_Y tells the two launches of a big plan apart in a profile: <false> the hot labels, <true> the rest and y)
+template <bool CLEAR_Y>
+__global__ __launch_bounds__(256) void band_gather_kernel(const double *__restrict__ x, const uint32_t *__restrict__ inv, uint32_t l0,
+                                                          uint32_t l1, double *__restrict__ xp, double *__restrict__ y_zero, uint64_t rows) {
+    const uint64_t t4 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const uint64_t l = (uint64_t)l0 + t4;
+    if (l + 4 <= (uint64_t)l1 && (l0 & 3u) == 0) {
+        const u32x4 j = *(const u32x4 *)(inv + l);
+        const double a0 = x[j[0]], a1 = x[j[1]], a2 = x[j[2]], a3 = x[j[3]];
+        *(dbl2 *)(xp + l) = dbl2{a0, a1};
+        *(dbl2 *)(xp + l + 2) = dbl2{a2, a3};
+    } else {
+        for (uint64_t q = l; q < (uint64_t)l1 && q < l + 4; ++q) xp[q] = x[inv[q]];
+    }
+    if (CLEAR_Y && y_zero) {
+        if (t4 + 4 <= rows && ((uintptr_t)y_zero & 15) == 0) {
+            *(dbl2 *)(y_zero + t4) = dbl2{0.0, 0.0};
+            *(dbl2 *)(y_zero + t4 + 2) = dbl2{0.0, 0.0};
+        } else {
+            for (uint64_t r = t4; r < rows && r < t4 + 4; ++r) y_zero[r] = 0.0;
+        }
+    }
+}
+
+// The scatter form: xp[label[c]] = x[c] for the labels in [first_label, nref) — the labels below were gathered (hot labels of a big
+// plan); the caller passes nref = every label — and y cleared: four consecutive columns / rows per thread
+// (16-byte loads; one column per thread left this kernel latency-bound beside the hot kernel: 360 us instead of 50, profiles/r05e)
 __global__ __launch_bounds__(256) void band_permute_kernel(const double *__restrict__ x, const uint32_t *__restrict__ perm,
                                                            uint64_t cols, double *__restrict__ xp, double *__restrict__ y_zero,
-                                                           uint64_t rows, uint32_t first_label) {
+                                                           uint64_t rows, uint32_t first_label, uint32_t nref) {
     const uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const uint32_t span = nref - first_label;                            // label in range <=> label - first_label < span
     if (j + 4 <= cols && (((uintptr_t)x | (uintptr_t)perm) & 15) == 0) {
         const u32x4 l = *(const u32x4 *)(perm + j);
         const dbl2 a = *(const dbl2 *)(x + j), b = *(const dbl2 *)(x + j + 2);
-        if (l[0] >= first_label) xp[l[0]] = a[0];     // labels below first_label were gathered by band_gather_hot_kernel
-        if (l[1] >= first_label) xp[l[1]] = a[1];
-        if (l[2] >= first_label) xp[l[2]] = b[0];
-        if (l[3] >= first_label) xp[l[3]] = b[1];
+        if (l[0] - first_label < span) xp[l[0]] = a[0];
+        if (l[1] - first_label < span) xp[l[1]] = a[1];
+        if (l[2] - first_label < span) xp[l[2]] = b[0];
+        if (l[3] - first_label < span) xp[l[3]] = b[1];
     } else {
         for (uint64_t c = j; c < cols && c < j + 4; ++c) {
             const uint32_t l = perm[c];
-            if (l >= first_label) xp[l] = x[c];
+            if (l - first_label < span) xp[l] = x[c];
         }
     }
     if (y_zero) {
@@ -701,17 +738,6 @@ __global__ __launch_bounds__(256) void band_permute_kernel(const double *__restr
             for (uint64_t r = j; r < rows && r < j + 4; ++r) y_zero[r] = 0.0;
         }
     }
-}
-
-// The hot kernel only reads the labels of the hot slices: those are gathered first, through the inverse of the labelling
-// (a few MB), so that the hot kernel starts a few us into the SpMV while the scatter of the rest of x (and the clearing
-// of y) runs beside it on the second stream, in front of the cold launch that needs them.
-__global__ __launch_bounds__(256) void band_gather_hot_kernel(const double *__restrict__ x, const uint32_t *__restrict__ inv_hot,
-                                                              uint32_t hot_labels, double *__restrict__ xp) {
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= hot_labels) return;
-    const uint32_t j = inv_hot[l];
-    xp[l] = j != 0xFFFFFFFFu ? x[j] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------

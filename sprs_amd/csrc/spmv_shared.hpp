@@ -131,7 +131,8 @@ struct TmpBuf {
 // perm[col] = label of the column: popularity classes, most referenced first (see the rl_* kernels).
 // Allocates *perm (cols entries); the caller owns it.
 template <typename IDX>
-static int32_t build_column_labels(const IDX *indices, uint64_t nnz, uint64_t cols, hipStream_t stream, uint32_t **perm) {
+static int32_t build_column_labels(const IDX *indices, uint64_t nnz, uint64_t cols, hipStream_t stream, uint32_t **perm,
+                                   uint64_t *nref = nullptr) {
     const uint64_t nchunks = (cols + RL_CHUNK - 1) / RL_CHUNK;
     TmpBuf ccount, hist, base;
     SPRS_TRY_HIP(ccount.alloc(cols * 4));
@@ -148,6 +149,8 @@ static int32_t build_column_labels(const IDX *indices, uint64_t nnz, uint64_t co
     hipLaunchKernelGGL(rl_rank_kernel, wgrid, dim3(256), 0, stream, (const uint32_t *)ccount.p, cols, nchunks,
                        (const uint64_t *)base.u64(), *perm);
     SPRS_TRY_HIP(hipGetLastError());
+    // the columns nobody references are the last class: its first label = the number of referenced columns
+    if (nref) SPRS_TRY_HIP(hipMemcpy(nref, base.u64() + (uint64_t)(RL_DIGITS - 1) * nchunks, 8, hipMemcpyDeviceToHost));
     SPRS_TRY_HIP(hipStreamSynchronize(stream));   // the temporaries go away here
     return SPRS_HIP_OK;
 }
