@@ -43,10 +43,12 @@ class RowShardedSpMV:
         # blocks of the exchange (R-MAT keeps its long rows in front: the last blocks have the most rows) at the price of uneven
         # multiplies.  Chosen on the one-GPU model max(block multiply) + max(y block) / one xGMI link (scripts/virtual_ranks.py,
         # profiles/r13t_virtual_ranks_row_weight_sweep.jsonl): 8 is best up to 4 ranks (0.562 ms against 0.582 at 16), 16 - 24 at 8
-        # ranks (0.358 against 0.378 at 8) — a model, not a multi-GPU measurement.  NOTE: the default therefore depends on the world
-        # size (8 up to 4 ranks, 16 above): a caller that must keep one partition across world sizes passes row_weight itself.
+        # ranks (0.358 against 0.378 at 8) — a model, not a multi-GPU measurement.  (Round 5's default depended on the world size, 8 up to
+        # 4 ranks and 16 above; see below.)
+        # Round 6 (profiles/r16a_virtual_ranks_scaling_model.jsonl): with the small-plan kernels 8 is best at 8 ranks as well (modelled step
+        # 0.3545 against 0.3625 ms at 16) — one default for every world size again.
         if row_weight is None:
-            row_weight = 8.0 if self.world <= 4 else 16.0
+            row_weight = 8.0
         self.row_weight = row_weight
         self.cuts = gen.balanced_row_blocks(indptr, self.world, row_weight=row_weight)
         r0, r1 = self.cuts[self.rank], self.cuts[self.rank + 1]
