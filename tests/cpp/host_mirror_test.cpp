@@ -200,6 +200,17 @@ int main() {
         DeviceVec x(std::vector<double>{1., 2., 3., 4., 5.}), y(5);
         d.mul(x, y);
         REQUIRE(y.to_host() == (a * x).to_host());
+        // the second exchange route through the mirror: a world of one exports its window, connects with its own handle and
+        // multiplies on the peer route (no peer to store to: the route's bookkeeping and the copy-out of an empty exchange)
+        REQUIRE(d.route() == SPRS_HIP_ROUTE_RCCL);
+        const std::vector<unsigned char> h = d.peer_handle();
+        REQUIRE(h.size() == 64);
+        d.peer_connect(h, 1);
+        d.set_route(SPRS_HIP_ROUTE_PEER);
+        REQUIRE(d.route() == SPRS_HIP_ROUTE_PEER);
+        DeviceVec y2(5);
+        d.mul(x, y2);
+        REQUIRE(y2.to_host() == y.to_host());
     }
     {   // panics -> exceptions with the reference's text
         DeviceCsMat a = mat1();
