@@ -607,14 +607,26 @@ def main():
                 if args.exchange == "lib" and rank == 0:
                     print("bench.py: library exchange unavailable (%s); timing the torch.distributed route" % repr(e)[:200], file=sys.stderr)
                 libdist = None
-        try:   # the peer-store route needs no RCCL: window handles through torch.distributed (any backend), also for ranks sharing a device
+        # the peer-store route needs no RCCL: window handles through torch.distributed (any backend), also for ranks sharing a device.
+        # Every step that can fail on ONE rank is followed by an agreement of all ranks, so that nobody waits in a collective alone.
+        import torch.distributed as dist
+        perr = None
+        try:
             peerdist = DistSpMV((n, n), DeviceCsMat.wrap_torch((rb[0], rb[1]), rb[2], rb[3], rb[4]), sh.cuts, rank, world,
                                 unique_id=None, nsub=2)
-            peerdist.connect_peers(dev).set_route("peer")
         except Exception as e:
-            if rank == 0:
-                print("bench.py: peer-store exchange unavailable (%s)" % repr(e)[:200], file=sys.stderr)
+            perr, peerdist = e, None
+        made = torch.tensor([1.0 if peerdist is not None else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(made, op=dist.ReduceOp.MIN)
+        if float(made.item()) > 0.5:
+            try:
+                peerdist.connect_peers(dev).set_route("peer")      # (collective-safe itself: sprs_amd/dist.py)
+            except Exception as e:
+                perr, peerdist = e, None
+        else:
             peerdist = None
+        if peerdist is None and rank == 0:
+            print("bench.py: peer-store exchange unavailable (%s)" % repr(perr)[:200], file=sys.stderr)
 
     def lib_step(xv):                                   # multiply + exchange inside the library, sub-blocks pipelined
         libdist.spmv(DeviceVec.borrow(xv), yv_all, stream=stream)

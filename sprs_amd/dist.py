@@ -204,17 +204,33 @@ class DistSpMV:
 
     def connect_peers(self, device, group=None):
         """collective: all-gather the 64-byte window handles through torch.distributed (whatever backend the group has) and
-        map every peer's window; afterwards `set_route("peer")` is allowed"""
+        map every peer's window; afterwards `set_route("peer")` is allowed.  A failure on ANY rank (no IPC for this kind of
+        memory, a peer that cannot be mapped) is agreed on by all ranks before anybody raises: no rank is left waiting in a
+        collective the failed one never enters."""
         import ctypes as C
         from ._ffi import check, lib
         world = dist.get_world_size(group)
         on = device if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        mine = torch.frombuffer(bytearray(self.peer_handle()), dtype=torch.uint8).to(on)
+        err = None
+        try:
+            handle = self.peer_handle()
+        except Exception as e:                          # (still take part in the collectives below)
+            err, handle = e, bytes(64)
+        mine = torch.frombuffer(bytearray(handle), dtype=torch.uint8).to(on)
         got = [torch.zeros(64, dtype=torch.uint8, device=on) for _ in range(world)]
         dist.all_gather(got, mine, group=group)
-        blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in got)
-        check(lib.sprs_hip_dist_peer_connect(self._h, (C.c_char * len(blob)).from_buffer_copy(blob), world))
-        dist.barrier(group)                            # every rank has mapped every window before anybody stores into one
+        ok = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device=on)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if float(ok.item()) > 0.5:                      # every rank exported a window: map them
+            blob = b"".join(bytes(t.cpu().numpy().tobytes()) for t in got)
+            try:
+                check(lib.sprs_hip_dist_peer_connect(self._h, (C.c_char * len(blob)).from_buffer_copy(blob), world))
+            except Exception as e:
+                err = e
+            ok = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64, device=on)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)   # (also the barrier: every rank has mapped every window before anybody stores)
+        if float(ok.item()) < 0.5:
+            raise err if err is not None else RuntimeError("peer route: another rank could not export or map a receive window")
         return self
 
     def set_route(self, route):
