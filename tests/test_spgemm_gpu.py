@@ -298,6 +298,64 @@ def test_row_class_boundaries(hip, idx, ptr):
             hip.set_option("spgemm_heavy", 131072)
 
 
+@pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
+def test_micro_rows_lane_groups(hip, idx, ptr):
+    """Rows of at most 16 / 32 / 64 products AND k's run on lane groups (micro_rows_kernel: 4 / 2 / 1 rows per wave, no LDS):
+    rows sitting exactly on 16 / 17, 32 / 33, 64 / 65 products; rows whose k's outnumber their products (k's with empty rows of
+    B: 17 and 39 k's for 12 and 22 products — must fall to the wider group or to the hash kernel); duplicate columns across k's (the
+    first-occurrence / ordered-sum logic: values of wildly different magnitude, bits compared); a last group with fewer rows
+    than the wave has room for; the reference's own benchmark shape in small (uniform density 4 / cols, sprs-benches
+    main.rs:148-163).  Structure and value BITS against the oracle, with the hash kernel (spgemm_micro = 2) as the A/B."""
+    from oracle import oracle
+    from sprs_amd import gen
+    rng = np.random.default_rng(77)
+    n_b, cols = 120, 700
+    b_lens = [0] * 30 + [1] * 10 + [2] * 10 + [3] * 10 + [4] * 20 + [8] * 10 + [16] * 10 + [17, 31, 32, 33, 63, 64, 65, 5, 6, 7] + [12] * 10
+    B = ragged_csr(b_lens, cols, seed=31, idx=idx, ptr=ptr, positive=False)
+    _, bip, bix, bdt = B
+    bdt[:] = rng.standard_normal(bdt.size) * 10.0 ** rng.integers(-12, 13, size=bdt.size)      # order-sensitive sums
+    lens = np.diff(bip.astype(np.int64))
+    pick = lambda want: [int(k) for k in np.nonzero(lens == want)[0]]
+    empty, ones, fours, eights, sixteens, twelves = pick(0), pick(1), pick(4), pick(8), pick(16), pick(12)
+    a_rows = [
+        fours[:4],                       # 16 products, 4 k's
+        fours[:4] + ones[:1],            # 17 products
+        eights[:4],                      # 32
+        eights[:4] + ones[:1],           # 33
+        sixteens[:4],                    # 64
+        sixteens[:4] + ones[:1],         # 65: not a micro row any more
+        empty[:16] + twelves[:1],        # 12 products, 17 k's: too many k's for a group of 16
+        empty[:28] + twelves[:1] + ones[:10],   # 22 products, 39 k's: too many k's for a group of 32
+        pick(17), pick(31), pick(32), pick(33), pick(63), pick(64), pick(65),   # single k's on the edges
+        twelves[:5],                     # 60 products with many columns shared between the k's
+        [],                              # empty row
+        ones[:3],                        # a lone short row at the end of its class list
+    ]
+    a_rows = [sorted(r) for r in a_rows]
+    a_ip = np.zeros(len(a_rows) + 1, dtype=np.int64)
+    a_ip[1:] = np.cumsum([len(r) for r in a_rows])
+    a_ix = np.array([k for r in a_rows for k in r], dtype=np.int64)
+    a_dt = rng.standard_normal(a_ix.size) * 10.0 ** rng.integers(-12, 13, size=a_ix.size)
+    A = ((len(a_rows), n_b), a_ip.astype(ptr), a_ix.astype(idx), a_dt)
+    ub = [int(sum(lens[k] for k in r)) for r in a_rows]
+    assert [16, 17, 32, 33, 64, 65, 12, 22] == ub[:8]
+    cases = [(A, B)]
+    for n, per, seed in ((3000, 4, 1), (500, 30, 4)):                   # uniform density: every row a micro row / most of them
+        a = gen.uniform_csr((n, n), per / n, seed=seed, value_seed=seed + 50)
+        b = gen.uniform_csr((n, n), per / n, seed=seed + 100, value_seed=seed + 150)
+        cases.append(tuple(((n, n), m[0].numpy().astype(ptr), m[1].numpy().astype(idx), m[2].numpy()) for m in (a, b)))
+    for a, b in cases:
+        ref = oracle.mul_csr_csr(*a, *b, threads=1)
+        for micro in (0, 2):
+            hip.set_option("spgemm_micro", micro)
+            try:
+                _, ip, ix, dt = gpu_mul(a, b)
+            finally:
+                hip.set_option("spgemm_micro", 0)
+            assert np.array_equal(ip, ref[1]) and np.array_equal(ix, ref[2])
+            assert np.array_equal(dt.view(np.uint64), ref[3].view(np.uint64)), "value bits differ (micro = %d)" % micro
+
+
 _DENSE_CASE = []
 
 
