@@ -425,6 +425,8 @@ def main():
     ap.add_argument("--relabel", type=int, default=None, help="sliced plan column relabelling: 0 auto, 1 on, 2 off")
     ap.add_argument("--ldspad", type=int, default=None, help="extra dynamic LDS per workgroup (occupancy cap, tuning)")
     ap.add_argument("--band", type=int, default=None, help="banded plan (hot columns from LDS): 0 auto, 1 on, 2 off")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="any library option (sprs_hip_set_option) for an A/B, e.g. --opt spgemm_micro=3; repeatable")
     ap.add_argument("--cold-cache", action="store_true",
                     help="stream a 1 GiB scratch buffer between steps (outside the per-step kernel events): the matrix and x "
                          "then come from HBM, not from the 256 MiB Infinity Cache (SURVEY 8d, config 2)")
@@ -477,6 +479,8 @@ def main():
     for opt, val in (("spmv_kernel", args.kernel), ("spmv_xcs", args.xcs), ("spmv_xcs_split", args.split), ("spmv_xcs_idx32", args.idx32), ("spmv_sort_tiles", args.sort), ("spmv_tile", args.tile), ("spmv_relabel", args.relabel), ("spmv_lds_pad", args.ldspad), ("spmv_band", args.band)):
         if val is not None:
             sprs_amd.set_option(opt, val)
+    for nv in args.opt:
+        sprs_amd.set_option(nv.split("=")[0], int(nv.split("=")[1]))
 
     if args.workload == "spgemm_uniform":
         if world != 1:

@@ -18,7 +18,7 @@
 #   spgemm_pmc[:env]      SQ / TCC counter passes over SpGEMM config 5 (per kernel means) -> spgemm_pmc.txt
 #   spgemm_traffic        FETCH_SIZE / WRITE_SIZE pass over SpGEMM config 5 -> spgemm_traffic.txt (scripts/spgemm_traffic.py)
 #   spmm[:args]           SpMM on R-MAT 10M (scripts/spmm_bench.py [n nnz_per_row k ...]) + its kernel stats
-#   spgemm_uniform        bench.py --workload spgemm_uniform (sprs-benches shape) + its kernel stats (small_rows_kernel throughput)
+#   spgemm_uniform[:args] bench.py --workload spgemm_uniform (sprs-benches shape) + its kernel stats (small_rows_kernel throughput)
 #   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
 #   pmcsq:<config>        SQ counter passes (instruction mix, busy / wait cycles) over one sweep config, per kernel means -> pmcsq.txt
 #   probe:<name>[:args]   scripts/probes/<name>.out [args] (stand-alone hardware probe, built here with hipcc; JSON lines -> <name>.jsonl)
@@ -102,8 +102,8 @@ for step in "$@"; do
     spmm)   timeout 600 python scripts/spmm_bench.py $arg 2>&1 | grep -E "^\{" | tee -a $OUT/spmm.jsonl
             ( cd /tmp && rm -rf /tmp/st && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/scripts/spmm_bench.py ${arg:-10000000 32 16} > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|spmm" | cut -c1-200 | head -8 | tee -a $OUT/spmm_kernels.txt ;;
     spgemm_uniform) # the reference's own bench shape (uniform 2.5M x 2.5M, 4 per row): the line, then per-kernel times of the same command
-            timeout 600 python bench.py --workload spgemm_uniform 2>/dev/null | tee -a $OUT/spgemm_uniform.jsonl
-            ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/bench.py --workload spgemm_uniform --no-cpu-baseline --steps 3 > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|^#|sprs_hip" | cut -c1-200 | head -24 | tee $OUT/spgemm_uniform_kernel_stats.txt ;;
+            timeout 600 python bench.py --workload spgemm_uniform $arg 2>/dev/null | tee -a $OUT/spgemm_uniform.jsonl
+            ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/bench.py --workload spgemm_uniform --no-cpu-baseline --steps 3 $arg > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|^#|sprs_hip" | cut -c1-200 | head -24 | tee -a $OUT/spgemm_uniform_kernel_stats.txt ;;
     py)     timeout 900 python $arg 2>&1 | grep -v amdgpu.ids | tee -a $OUT/py.log ;;
     *)      echo "unknown step $name" ;;
   esac

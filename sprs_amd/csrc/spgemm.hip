@@ -528,7 +528,7 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
 //     sorted output row (smmp.rs:124: rows come out sorted);
 //   * symbolic: the count of first occurrences.
 // ---------------------------------------------------------------------------
-template <typename IDX, typename PTR, bool NUMERIC, int G>
+template <typename IDX, typename PTR, bool NUMERIC, int G, bool SORTED>
 __global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, const MicroRec *__restrict__ list,
                                                          uint64_t n, uint64_t *__restrict__ count, const uint64_t *__restrict__ off,
                                                          IDX *__restrict__ c_indices, double *__restrict__ c_data) {
@@ -592,6 +592,47 @@ __global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, Cs
             pr = av_o * B.data[pos];
         }
         if (!valid) c = EMPTY;                                           // (no column equals it: b_cols < 2^32 - 1 on this path)
+        if constexpr (SORTED) {
+            // The group SORTS its products by (column, position) — a bitonic network over the lanes, log2(G)(log2(G)+1)/2
+            // exchanges instead of the 2(G - 1) of the rotations below (G = 64: 21 against 126).  Equal columns then sit
+            // side by side in ascending position: the first of a run is the output entry, its rank is the number of runs before
+            // it (the row comes out sorted), and it adds the rest of its run one by one, from 0.0 + its own — the reference's
+            // chain (smmp.rs:166-181).  The loop over a run's length ends for the whole wave when no run goes on.
+            uint64_t sk = ((uint64_t)c << 6) | gl;                       // (lanes without a product: EMPTY, the end of the order)
+#pragma unroll
+            for (int k2 = 2; k2 <= G; k2 <<= 1)
+#pragma unroll
+                for (int j = k2 >> 1; j > 0; j >>= 1) {
+                    const uint64_t p = __shfl_xor(sk, j, G);
+                    const bool take_min = ((gl & (uint32_t)j) == 0) == ((gl & (uint32_t)k2) == 0);
+                    sk = ((p < sk) == take_min) ? p : sk;
+                }
+            const uint32_t cs = (uint32_t)(sk >> 6), ps = (uint32_t)sk & 63u;
+            const uint32_t cprev = __shfl_up(cs, 1, G);
+            const bool head = cs != EMPTY && (gl == 0 || cprev != cs);
+            const unsigned long long hm = __ballot(head);
+            const unsigned long long mine = G == WAVE ? hm : (hm >> (g * G)) & ((1ull << (G % WAVE)) - 1ull);
+            if constexpr (!NUMERIC) {
+                if (row_ok && gl == 0) count[rec_c.t] = (uint64_t)__popcll(mine);
+            } else {
+                const double v = __shfl(pr, (int)ps, G);
+                const uint32_t rank = (uint32_t)__popcll(mine & ((1ull << gl) - 1ull));
+                double acc = 0.0 + v;                                    // tmp starts at N::zero() (smmp.rs:166-170)
+                bool alive = head;
+                for (int t = 1; t < G; ++t) {                            // (every lane takes part in every exchange; the exit is wave-uniform)
+                    const uint32_t cn = __shfl_down(cs, (unsigned)t, G);
+                    const double vn = __shfl_down(v, (unsigned)t, G);
+                    alive = alive && gl + (uint32_t)t < (uint32_t)G && cn == cs;
+                    if (__ballot(alive) == 0ull) break;
+                    if (alive) acc += vn;
+                }
+                if (head) {
+                    if (c_indices) c_indices[o_c + rank] = (IDX)cs;       // null: C already has its structure (numeric on a kept plan)
+                    if (c_data) c_data[o_c + rank] = acc;                 // null: structure only (the twin of smmp::symbolic)
+                }
+            }
+            continue;
+        }
         bool first = valid;
         double acc = 0.0 + pr;                                           // tmp starts at N::zero() (smmp.rs:166-170)
         // (four exchanges in flight per step: fully unrolled the compiler hoists all G of them — 256 registers at G = 64)
@@ -1937,16 +1978,22 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         if (g > 256 * 8) g = 256 * 8;                                    // what the chip holds at once; the waves stride over the list
         return dim3((unsigned)g);
     };
-#define SPRS_MICRO_SYM(M, GV)                                                                                                       \
+#define SPRS_MICRO_SYM(M, GV, SV)                                                                                                     \
     if (pl->n_micro[M]) {                                                                                                           \
-        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, false, GV>), micro_grid(pl->n_micro[M], WAVE / GV), dim3(256), 0, wstream, A, B, \
+        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, false, GV, SV>), micro_grid(pl->n_micro[M], WAVE / GV), dim3(256), 0, wstream, A, B, \
                            (const MicroRec *)pl->micro_list[M].as<MicroRec>(), pl->n_micro[M], pl->count.as<uint64_t>(),             \
                            (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);                                            \
         SPRS_TRY_HIP(hipGetLastError());                                                                                            \
     }
-    SPRS_MICRO_SYM(0, 16)
-    SPRS_MICRO_SYM(1, 32)
-    SPRS_MICRO_SYM(2, 64)
+    if (options().spgemm_micro != 3) {
+        SPRS_MICRO_SYM(0, 16, true)
+        SPRS_MICRO_SYM(1, 32, true)
+        SPRS_MICRO_SYM(2, 64, true)
+    } else {                                                             // the rotation exchanges of the first version (A/B)
+        SPRS_MICRO_SYM(0, 16, false)
+        SPRS_MICRO_SYM(1, 32, false)
+        SPRS_MICRO_SYM(2, 64, false)
+    }
 #undef SPRS_MICRO_SYM
     if (n_tiny) {
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, false, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, wstream,
@@ -2107,18 +2154,24 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     uint32_t bin_shift = 0;
     while (bin_shift < 32 && ((pl->b_cols - (pl->b_cols ? 1 : 0)) >> bin_shift) >= (uint64_t)SM_NBIN) ++bin_shift;
     const uint32_t small_flags = add_flags();
-#define SPRS_MICRO_NUM(M, GV)                                                                                                       \
+#define SPRS_MICRO_NUM(M, GV, SV)                                                                                                     \
     if (pl->n_micro[M]) {                                                                                                           \
         uint64_t mg = ((pl->n_micro[M] + (WAVE / GV) - 1) / (WAVE / GV) + 3) / 4;                                                     \
         if (mg > 256 * 8) mg = 256 * 8;                                                                                             \
-        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, true, GV>), dim3((unsigned)mg), dim3(256), 0, wstream, A, B,                 \
+        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, true, GV, SV>), dim3((unsigned)mg), dim3(256), 0, wstream, A, B,                 \
                            (const MicroRec *)pl->micro_list[M].as<MicroRec>(), pl->n_micro[M], pl->count.as<uint64_t>(),             \
                            (const uint64_t *)pl->off.as<uint64_t>(), c_indices, c_values);                                           \
         SPRS_TRY_HIP(hipGetLastError());                                                                                            \
     }
-    SPRS_MICRO_NUM(0, 16)
-    SPRS_MICRO_NUM(1, 32)
-    SPRS_MICRO_NUM(2, 64)
+    if (options().spgemm_micro != 3) {
+        SPRS_MICRO_NUM(0, 16, true)
+        SPRS_MICRO_NUM(1, 32, true)
+        SPRS_MICRO_NUM(2, 64, true)
+    } else {                                                             // the rotation exchanges of the first version (A/B)
+        SPRS_MICRO_NUM(0, 16, false)
+        SPRS_MICRO_NUM(1, 32, false)
+        SPRS_MICRO_NUM(2, 64, false)
+    }
 #undef SPRS_MICRO_NUM
     if (n_tiny)
         hipLaunchKernelGGL((small_rows_kernel<IDX, PTR, true, TINY_TAB>), small_grid(n_tiny), dim3(SM_BLOCK), 0, wstream, A,

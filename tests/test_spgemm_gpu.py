@@ -344,9 +344,23 @@ def test_micro_rows_lane_groups(hip, idx, ptr):
         a = gen.uniform_csr((n, n), per / n, seed=seed, value_seed=seed + 50)
         b = gen.uniform_csr((n, n), per / n, seed=seed + 100, value_seed=seed + 150)
         cases.append(tuple(((n, n), m[0].numpy().astype(ptr), m[1].numpy().astype(idx), m[2].numpy()) for m in (a, b)))
+    # long runs of one column: 60 k's whose rows of B all hold column 7 (and one or no other column) — a run as long as the group
+    # is wide, added in k order from 0.0 (smmp.rs:166-181); and rows of B made of the same 3 columns
+    nb2 = 64
+    b2_rows = [[7] if k % 3 else [7, 100 + k] for k in range(60)] + [[1, 2, 3]] * 4
+    b2_ip = np.zeros(nb2 + 1, dtype=np.int64)
+    b2_ip[1:] = np.cumsum([len(r) for r in b2_rows])
+    b2_ix = np.array([c for r in b2_rows for c in r], dtype=np.int64)
+    b2_dt = rng.standard_normal(b2_ix.size) * 10.0 ** rng.integers(-12, 13, size=b2_ix.size)
+    a2_rows = [list(range(60)), list(range(0, 40)), list(range(5, 21)), [60, 61, 62, 63], list(range(50, 64)), list(range(0, 60, 3))]
+    a2_ip = np.zeros(len(a2_rows) + 1, dtype=np.int64)
+    a2_ip[1:] = np.cumsum([len(r) for r in a2_rows])
+    a2_ix = np.array([k for r in a2_rows for k in r], dtype=np.int64)
+    a2_dt = rng.standard_normal(a2_ix.size) * 10.0 ** rng.integers(-12, 13, size=a2_ix.size)
+    cases.append((((len(a2_rows), nb2), a2_ip.astype(ptr), a2_ix.astype(idx), a2_dt), ((nb2, 200), b2_ip.astype(ptr), b2_ix.astype(idx), b2_dt)))
     for a, b in cases:
         ref = oracle.mul_csr_csr(*a, *b, threads=1)
-        for micro in (0, 2):
+        for micro in (0, 2, 3):                                           # sorted groups, the hash kernel, all-pairs rotations
             hip.set_option("spgemm_micro", micro)
             try:
                 _, ip, ix, dt = gpu_mul(a, b)
