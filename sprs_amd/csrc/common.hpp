@@ -76,7 +76,7 @@ constexpr bool DEVTOOLS = false;
     X(spmv_band_split_permute, 0, 0, 2, 0) /* with the overlap: hot labels of x gathered first, the rest scattered on the second stream: 0/1 on, 2 off */ \
     X(spmm_long_row, -1, -1, INT64_MAX, 0) /* SpMM: -1 / 0 default (the entry-stream kernel); L > 0: rows of <= L entries summed in entry order by lane groups, longer ones by 512-entry chunks (reference bits for the short rows, several times slower) */ \
     X(spmm_stream, 1, 0, 1, 0)          /* SpMM: 1 tiles of 256 consecutive entries per wave (default); 0 one wave per row chunk (the kernel of rounds 1-3; also what a matrix with 2^32 or more columns runs) */ \
-    X(spgemm_micro, 0, 0, 3, 0)         /* rows of at most 64 products and k's by lane groups, 4 / 2 / 1 rows per wave, no LDS (micro_rows_kernel): 0/1 on (the group sorts its products), 2 off (the hash kernel, A/B), 3 on with all-pairs rotations instead of the sort (A/B) */ \
+    X(spgemm_micro, 0, 0, 2, 0)         /* rows of at most 64 products and k's by lane groups, 4 / 2 / 1 rows per wave, no LDS (micro_rows_kernel): 0/1 on, 2 off (the hash kernel, A/B) */ \
     X(spgemm_task_order, 0, 0, 2, 0)    /* large-row tasks: 0/1 costliest first (stable sort by cost class), 2 row order (A/B) */  \
     X(spgemm_xcd_chunk, 0, -1, 0, 0)    /* large-row task list -> XCDs: 0 round-robin, -1 one contiguous run per XCD */            \
     X(spgemm_bucket, 1, 0, 1, 0)        /* column-bucket table of B instead of binary searches (A/B) */                           \

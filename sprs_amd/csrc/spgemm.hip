@@ -32,6 +32,7 @@
 // Developer builds (make DEVTOOLS=1): option spgemm_prof prints per-class / per-phase timings of the numeric kernels; the
 // release library compiles the timers and the printout out.
 #include "common.hpp"
+#include "lanes.hpp"
 #include "scan.hpp"
 
 #include <algorithm>
@@ -191,6 +192,10 @@ __device__ __forceinline__ int ceil_log2_u32(uint32_t v) { return v <= 1 ? 0 : 3
 // windows), 4 large (a workgroup); 5 / 6 / 7 MICRO rows — at most 16 / 32 / 64 products AND k's: 4 / 2 / 1 rows per wave, no LDS
 // (micro_rows_kernel) — every row of the reference's own benchmark matrices (uniform density, 4 entries per row) is one
 constexpr uint8_t CLS_MICRO16 = 5, CLS_MICRO32 = 6, CLS_MICRO64 = 7;
+// extent word of an entry of A (micro rows): start of B's row k (40 bits) | its length (24 bits, saturated)
+constexpr uint32_t EXT_SHIFT = 40;
+constexpr uint64_t MICRO_KEY32_COLS = (1ull << 26) - 2;     // columns of B up to which (column << 6 | position) stays below 2^32 - 1
+constexpr uint64_t EXT_START = (1ull << EXT_SHIFT) - 1ull, EXT_LEN_MAX = (1ull << (64 - EXT_SHIFT)) - 1ull;
 
 // 16 lanes per row, four rows per wave (round 6: one wave per row left 60 lanes idle on the 4-entry rows of the reference's
 // benchmark matrices and made this pass 0.5 ms of their 4.6 ms product; long rows just take more strides)
@@ -198,7 +203,8 @@ template <typename IDX, typename PTR>
 __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, uint64_t rows,
                                                        uint64_t b_cols, uint64_t heavy_products, uint32_t wl, uint32_t min_wl, uint64_t mid_max,
                                                        uint64_t *__restrict__ ub, uint64_t *__restrict__ ntasks,
-                                                       uint8_t *__restrict__ cls, uint8_t *__restrict__ wlog, uint32_t micro) {
+                                                       uint8_t *__restrict__ cls, uint8_t *__restrict__ wlog, uint32_t micro,
+                                                       uint64_t *__restrict__ ext) {
     const uint32_t lane = threadIdx.x & (WAVE - 1), sub = lane >> 4, sl = lane & 15u;
     const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
@@ -213,7 +219,13 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
             for (int u = 0; u < 4; ++u) k[u] = p + 16 * u < e ? (uint64_t)A.indices[p + 16 * u] : ~0ull;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (k[u] != ~0ull) acc += (uint64_t)B.indptr[k[u] + 1] - (uint64_t)B.indptr[k[u]];
+                if (k[u] != ~0ull) {
+                    const uint64_t bs = (uint64_t)B.indptr[k[u]], len = (uint64_t)B.indptr[k[u] + 1] - bs;
+                    acc += len;
+                    // the extent of B's row behind this entry, for the micro rows' kernels (start | saturated length: a micro
+                    // row's k's have at most 64 entries each)
+                    if (ext) ext[p + 16 * u] = bs | ((len < EXT_LEN_MAX ? len : EXT_LEN_MAX) << EXT_SHIFT);
+                }
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);   // the 16 lanes of the row
@@ -519,61 +531,77 @@ __global__ __launch_bounds__(SM_BLOCK) void small_rows_kernel(CsrView<IDX, PTR> 
 // The reference's own benchmark (sprs-benches/src/main.rs:148-163: uniform density, 4 entries per row, up to 2.5 M rows) is
 // made of rows of ~16 products.  One wave per such row (small_rows_kernel) idles 48 lanes and walks a chain of nine dependent
 // round trips per row: 2.1 + 1.5 ms of the 4.6 ms product (profiles/r15a).  Here a lane group owns a row:
-//   * lane j of the group holds k_j (a micro row has at most G k's) and the bounds of B's row k_j; a group-wide prefix of the
-//     lengths places the row's expansion — k ascending, columns ascending inside a k: the reference's own order
-//     (smmp.rs:174-181) — one product per lane;
-//   * every lane meets every other lane of its group once (rotation by 1 .. G - 1): a product is the FIRST of its column when no
-//     lower lane holds the same column; the first one adds the later ones in ascending position, from 0.0 + its own — the
-//     reference's chain, bit for bit; a second rotation counts the first occurrences with a smaller column: the rank in the
-//     sorted output row (smmp.rs:124: rows come out sorted);
-//   * symbolic: the count of first occurrences.
+//   * lane j of the group holds the extent of B's row k_j — start and length in one word, left per entry of A by
+//     row_work_kernel, which had to fetch B.indptr[k], B.indptr[k + 1] anyway: a streamed load here instead of two more
+//     dependent gathers per pass; a group-wide prefix of the lengths places the row's expansion — k ascending, columns
+//     ascending inside a k: the reference's own order (smmp.rs:174-181) — one product per lane;
+//   * the group SORTS its products by (column, position) — a bitonic network over the lanes, log2(G)(log2(G)+1)/2 exchanges
+//     (the first version let every lane meet every other one: 2(G - 1) rotations, 854 against 527 us for the rows of 17 - 32
+//     products, profiles/r16m).  Equal columns then sit side by side in ascending position: the first of a run is the output
+//     entry, its rank is the number of runs before it (the row comes out sorted, smmp.rs:124), and it adds the rest of its run
+//     one by one, from 0.0 + its own — the reference's chain (smmp.rs:166-181), bit for bit;
+//   * symbolic: the number of runs.
+// A row is a chain of dependent round trips (record -> bounds of the A row -> extents -> entries of B) and a wave has nothing
+// else to do meanwhile, so the chain is a software pipeline over the wave's rows: while the entries of row i are in flight
+// the extents of row i + 1, the bounds of row i + 2 and the record of row i + 3 are requested — one round trip per row.
 // ---------------------------------------------------------------------------
-template <typename IDX, typename PTR, bool NUMERIC, int G, bool SORTED>
-__global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, const MicroRec *__restrict__ list,
-                                                         uint64_t n, uint64_t *__restrict__ count, const uint64_t *__restrict__ off,
-                                                         IDX *__restrict__ c_indices, double *__restrict__ c_data) {
-    constexpr int R = WAVE / G;
+template <typename IDX, typename PTR, bool NUMERIC, int G, typename KEY>
+__global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, CsrView<IDX, PTR> B, const uint64_t *__restrict__ ext,
+                                                         const MicroRec *__restrict__ list, uint64_t n, uint64_t *__restrict__ count,
+                                                         const uint64_t *__restrict__ off, IDX *__restrict__ c_indices,
+                                                         double *__restrict__ c_data) {
+    constexpr int R = WAVE / G, LOG2G = G == 16 ? 4 : G == 32 ? 5 : 6;
+    constexpr KEY NO_KEY = ~(KEY)0;                                      // a lane without a product: the end of the order
     const uint32_t lane = threadIdx.x & (WAVE - 1), g = lane / G, gl = lane % G;
     const uint64_t w0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
     const uint64_t nw = (uint64_t)gridDim.x * (blockDim.x / WAVE);
-    // A row is a chain of dependent round trips (record -> bounds of the A row -> k's -> bounds of the B rows -> entries) and a
-    // wave has nothing else to do meanwhile: the record of the row after next and the bounds of the next row are requested while
-    // this row is worked on — three round trips per row instead of five.
     const uint64_t stride = nw * R;
-    auto load_rec = [&](uint64_t qq0) {
+    auto load_rec = [&](uint64_t qq0) {                                  // (past the end: the last record again, dropped below)
         const uint64_t qq = qq0 + g;
         return list[qq < n ? qq : n - 1];
     };
-    MicroRec rec = load_rec(w0 * R), rec1 = load_rec(w0 * R + stride);
-    uint64_t as = (uint64_t)A.indptr[rec.r], ae = (uint64_t)A.indptr[rec.r + 1];
-    uint64_t o = NUMERIC ? off[rec.t] : 0;
-    for (uint64_t q0 = w0 * R; q0 < n; q0 += stride) {                   // wave-uniform
-        const MicroRec rec2 = load_rec(q0 + 2 * stride);
-        const uint64_t as1 = (uint64_t)A.indptr[rec1.r], ae1 = (uint64_t)A.indptr[rec1.r + 1];
-        const uint64_t o1 = NUMERIC ? off[rec1.t] : 0;
-        const uint64_t as_c = as, ae_c = ae, o_c = o;
-        const MicroRec rec_c = rec;
-        rec = rec1;                                                      // (handed on: the body below works on the _c copies)
-        rec1 = rec2;
-        as = as1;
-        ae = ae1;
-        o = o1;
-        const uint64_t q = q0 + g;
-        const bool row_ok = q < n;
-        const uint32_t nk = row_ok ? (uint32_t)(ae_c - as_c) : 0u;      // <= G by the row's class
-        const bool has = gl < nk;
-        const uint64_t k = has ? (uint64_t)A.indices[as_c + gl] : 0;
-        double av = 0.0;
-        if constexpr (NUMERIC) av = has ? A.data[as_c + gl] : 0.0;
-        const uint64_t bs = has ? (uint64_t)B.indptr[k] : 0;
-        const uint32_t len = has ? (uint32_t)((uint64_t)B.indptr[k + 1] - bs) : 0u;
-        uint32_t inc = len;                                              // inclusive prefix of the lengths over the group
-#pragma unroll
-        for (int d = 1; d < G; d <<= 1) {
-            const uint32_t v = __shfl_up(inc, d, G);
-            if (gl >= (uint32_t)d) inc += v;
-        }
-        const uint32_t total = __shfl(inc, G - 1, G);                    // products of the row (<= G)
+    // every load is unconditional — a load under a lane's condition is a branch that ends in a wait for that one load (see the
+    // window kernels): a lane without a k reads the row's first entry (a micro row has one) and drops it
+    struct Bounds { uint64_t as, ae, o, t; };
+    auto load_bounds = [&](const MicroRec &rc) {
+        Bounds bd;
+        bd.as = (uint64_t)A.indptr[rc.r];
+        bd.ae = (uint64_t)A.indptr[rc.r + 1];
+        bd.o = NUMERIC ? off[rc.t] : 0;
+        bd.t = rc.t;
+        return bd;
+    };
+    struct Ext { uint64_t e; double av; uint64_t o, t; uint32_t nk; };
+    auto load_ext = [&](const Bounds &bd, uint64_t qq0) {
+        Ext x;
+        x.nk = qq0 + g < n ? (uint32_t)(bd.ae - bd.as) : 0u;            // <= G by the row's class
+        const uint64_t at = bd.as + (gl < x.nk ? gl : 0u);
+        x.e = ext[at];
+        x.av = NUMERIC ? A.data[at] : 0.0;
+        x.o = bd.o;
+        x.t = bd.t;
+        return x;
+    };
+    const uint64_t q00 = w0 * R;
+    MicroRec rec2 = load_rec(q00 + 2 * stride);
+    Bounds bd1 = load_bounds(load_rec(q00 + stride));
+    Ext x0 = load_ext(load_bounds(load_rec(q00)), q00);
+    for (uint64_t q0 = q00; q0 < n; q0 += stride) {                      // wave-uniform
+        const MicroRec rec3 = load_rec(q0 + 3 * stride);
+        const Bounds bd2 = load_bounds(rec2);
+        const Ext x1 = load_ext(bd1, q0 + stride);
+        const Ext xc = x0;                                               // (handed on: the body below works on row q0's copy)
+        x0 = x1;
+        bd1 = bd2;
+        rec2 = rec3;
+        const bool row_ok = q0 + g < n;
+        const bool has = gl < xc.nk;
+        const uint64_t bs = xc.e & EXT_START;
+        const uint32_t len = has ? (uint32_t)(xc.e >> EXT_SHIFT) : 0u;
+        const uint32_t inc = group_incl_scan_u32<G>(len);                // inclusive prefix of the lengths over the group (DPP, lanes.hpp)
+        uint32_t total;                                                  // products of the row (<= G)
+        if constexpr (G == WAVE) total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+        else total = __shfl(inc, G - 1, G);
         const bool valid = gl < total;                                   // lane = position gl of the expansion
         uint32_t own = 0;                                                // its k: the number of group lanes whose prefix is <= gl
 #pragma unroll
@@ -582,42 +610,32 @@ __global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, Cs
             if (v <= gl) own += step;
         }
         own &= G - 1;
-        const uint32_t inc_o = __shfl(inc, (int)own, G), len_o = __shfl(len, (int)own, G);
-        const uint64_t bs_o = __shfl(bs, (int)own, G);
-        const uint64_t pos = valid ? bs_o + (uint64_t)(gl - (inc_o - len_o)) : 0ull;   // (a lane without a product loads entry 0 and drops it)
-        uint32_t c = (uint32_t)B.indices[pos];
+        // position gl of the expansion is entry (start of B's row) + gl - (products before that row): one word to fetch from the owner
+        const uint64_t base_o = __shfl(bs - (uint64_t)(inc - len), (int)own, G);
+        const uint64_t pos = valid ? base_o + gl : 0ull;                 // (a lane without a product loads entry 0 and drops it)
+        uint32_t c;
         double pr = 0.0;
         if constexpr (NUMERIC) {
-            const double av_o = __shfl(av, (int)own, G);
+            c = (uint32_t)B.indices[pos];
+            const double av_o = __shfl(xc.av, (int)own, G);
             pr = av_o * B.data[pos];
+        } else {
+            c = B.col32[pos];
         }
-        if (!valid) c = EMPTY;                                           // (no column equals it: b_cols < 2^32 - 1 on this path)
-        if constexpr (SORTED) {
-            // The group SORTS its products by (column, position) — a bitonic network over the lanes, log2(G)(log2(G)+1)/2
-            // exchanges instead of the 2(G - 1) of the rotations below (G = 64: 21 against 126).  Equal columns then sit
-            // side by side in ascending position: the first of a run is the output entry, its rank is the number of runs before
-            // it (the row comes out sorted), and it adds the rest of its run one by one, from 0.0 + its own — the reference's
-            // chain (smmp.rs:166-181).  The loop over a run's length ends for the whole wave when no run goes on.
-            uint64_t sk = ((uint64_t)c << 6) | gl;                       // (lanes without a product: EMPTY, the end of the order)
-#pragma unroll
-            for (int k2 = 2; k2 <= G; k2 <<= 1)
-#pragma unroll
-                for (int j = k2 >> 1; j > 0; j >>= 1) {
-                    const uint64_t p = __shfl_xor(sk, j, G);
-                    const bool take_min = ((gl & (uint32_t)j) == 0) == ((gl & (uint32_t)k2) == 0);
-                    sk = ((p < sk) == take_min) ? p : sk;
-                }
-            const uint32_t cs = (uint32_t)(sk >> 6), ps = (uint32_t)sk & 63u;
-            const uint32_t cprev = __shfl_up(cs, 1, G);
-            const bool head = cs != EMPTY && (gl == 0 || cprev != cs);
-            const unsigned long long hm = __ballot(head);
-            const unsigned long long mine = G == WAVE ? hm : (hm >> (g * G)) & ((1ull << (G % WAVE)) - 1ull);
-            if constexpr (!NUMERIC) {
-                if (row_ok && gl == 0) count[rec_c.t] = (uint64_t)__popcll(mine);
-            } else {
-                const double v = __shfl(pr, (int)ps, G);
-                const uint32_t rank = (uint32_t)__popcll(mine & ((1ull << gl) - 1ull));
-                double acc = 0.0 + v;                                    // tmp starts at N::zero() (smmp.rs:166-170)
+        // the group sorts (column, position) keys; a key is one 32-bit word when B has fewer than 2^26 - 1 columns
+        const KEY sk = group_sort<G, KEY>(valid ? ((KEY)c << LOG2G) | (KEY)gl : NO_KEY);
+        const uint32_t cs = (uint32_t)(sk >> LOG2G), ps = (uint32_t)sk & (uint32_t)(G - 1);
+        const uint32_t cprev = lane_below(cs);
+        const bool head = sk != NO_KEY && (gl == 0 || cprev != cs);
+        const unsigned long long hm = __ballot(head);
+        const unsigned long long mine = G == WAVE ? hm : (hm >> (g * G)) & ((1ull << (G % WAVE)) - 1ull);
+        if constexpr (!NUMERIC) {
+            if (row_ok && gl == 0) count[xc.t] = (uint64_t)__popcll(mine);
+        } else {
+            const double v = __shfl(pr, (int)ps, G);
+            const uint32_t rank = (uint32_t)__popcll(mine & ((1ull << gl) - 1ull));
+            double acc = 0.0 + v;                                        // tmp starts at N::zero() (smmp.rs:166-170)
+            if (__ballot(sk != NO_KEY && !head) != 0ull) {               // some column of the wave's rows has more than one product (wave-uniform)
                 bool alive = head;
                 for (int t = 1; t < G; ++t) {                            // (every lane takes part in every exchange; the exit is wave-uniform)
                     const uint32_t cn = __shfl_down(cs, (unsigned)t, G);
@@ -626,52 +644,10 @@ __global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, Cs
                     if (__ballot(alive) == 0ull) break;
                     if (alive) acc += vn;
                 }
-                if (head) {
-                    if (c_indices) c_indices[o_c + rank] = (IDX)cs;       // null: C already has its structure (numeric on a kept plan)
-                    if (c_data) c_data[o_c + rank] = acc;                 // null: structure only (the twin of smmp::symbolic)
-                }
             }
-            continue;
-        }
-        bool first = valid;
-        double acc = 0.0 + pr;                                           // tmp starts at N::zero() (smmp.rs:166-170)
-        // (four exchanges in flight per step: fully unrolled the compiler hoists all G of them — 256 registers at G = 64)
-#pragma clang loop unroll(disable)
-        for (int s0 = 1; s0 < G; s0 += 4)
-#pragma unroll
-        for (int s = s0; s < s0 + 4; ++s) {
-            if (s >= G) break;
-            const int src = (int)((gl + (uint32_t)s) & (uint32_t)(G - 1));
-            const uint32_t cj = __shfl(c, src, G);
-            double pj = 0.0;
-            if constexpr (NUMERIC) pj = __shfl(pr, src, G);              // (every lane takes part in every exchange: no shuffle under a lane's condition)
-            const bool same = valid && cj == c;
-            const bool lower = gl + (uint32_t)s >= (uint32_t)G;          // the partner is a LOWER position of the expansion
-            if (same && lower) first = false;                            // ... with the same column: this one is not the first
-            if constexpr (NUMERIC) {
-                if (same && !lower) acc += pj;                           // higher positions, in ascending order: the reference's chain
-            }
-        }
-        if constexpr (!NUMERIC) {
-            const unsigned long long fm = __ballot(first);
-            if (row_ok && gl == 0) {
-                const unsigned long long mine = G == WAVE ? fm : (fm >> (g * G)) & ((1ull << (G % WAVE)) - 1ull);
-                count[rec_c.t] = (uint64_t)__popcll(mine);
-            }
-        } else {
-            const uint32_t key = first ? c : EMPTY;                      // only first occurrences are output columns
-            uint32_t rank = 0;
-#pragma clang loop unroll(disable)
-            for (int s0 = 1; s0 < G; s0 += 4)
-#pragma unroll
-            for (int s = s0; s < s0 + 4; ++s) {
-                if (s >= G) break;
-                const uint32_t kj = __shfl(key, (int)((gl + (uint32_t)s) & (uint32_t)(G - 1)), G);
-                rank += kj < c ? 1u : 0u;
-            }
-            if (first) {
-                if (c_indices) c_indices[o_c + rank] = (IDX)c;             // null: C already has its structure (numeric on a kept plan)
-                if (c_data) c_data[o_c + rank] = acc;                      // null: structure only (the twin of smmp::symbolic)
+            if (head) {
+                if (c_indices) c_indices[xc.o + rank] = (IDX)cs;         // null: C already has its structure (numeric on a kept plan)
+                if (c_data) c_data[xc.o + rank] = acc;                   // null: structure only (the twin of smmp::symbolic)
             }
         }
     }
@@ -1701,7 +1677,7 @@ struct sprs_hip_spgemm_plan {
     int64_t winlog = 17, midwin = 14;
     uint32_t xcd_chunk = 0;        // how the launch deals the task list to the XCDs (task_of_block)
     uint64_t kept_words = 0;       // 64-bit words per row of the kept bitmaps (0: none kept)
-    sprs_hip::DevBuf bcol32, bpack, large_slot, kept_bm, bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, mid_list, large_list, count, off, counters;
+    sprs_hip::DevBuf bcol32, bpack, ent_ext, large_slot, kept_bm, bucket, ub, ntasks, first_task, wlog, task_row, tiny_list, small_list, mid_list, large_list, count, off, counters;
 };
 
 namespace sprs_hip {
@@ -1870,6 +1846,9 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     SPRS_TRY_HIP(pos_small.alloc((rows + 1) * 8));
     SPRS_TRY_HIP(pos_large.alloc((rows + 1) * 8));
     const dim3 rgrid((unsigned)((rows + 255) / 256)), rblock(256);
+    // micro rows (lane groups): columns of B below EMPTY, entries of B below 2^40 (the extent word of an entry of A)
+    const bool micro = options().spgemm_micro != 2 && b_cols < 0xFFFFFFFFull && (uint64_t)b->nnz <= EXT_START;
+    if (micro) SPRS_TRY_HIP(pl->ent_ext.alloc((a->nnz ? a->nnz : 1) * sizeof(uint64_t)));
     if (rows) {
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
@@ -1877,7 +1856,7 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
                            (uint64_t)options().spgemm_heavy, (uint32_t)options().spgemm_winlog, (uint32_t)options().spgemm_minwin,
                            pl->nb ? (uint64_t)options().spgemm_mid : 0ull,      /* the wave-per-row kernel takes its window edges from the bucket table */
                            pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), cls.as<uint8_t>(), pl->wlog.as<uint8_t>(),
-                           (options().spgemm_micro != 2 && b_cols < 0xFFFFFFFFull) ? 1u : 0u);
+                           micro ? 1u : 0u, micro ? pl->ent_ext.as<uint64_t>() : (uint64_t *)nullptr);
         SPRS_TRY_HIP(hipGetLastError());
         hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, (const uint8_t *)cls.as<uint8_t>(), pl->ntasks.as<uint64_t>(), rows,
                            is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), is_mid.as<uint64_t>(), n_large_r.as<uint64_t>());
@@ -1978,21 +1957,21 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         if (g > 256 * 8) g = 256 * 8;                                    // what the chip holds at once; the waves stride over the list
         return dim3((unsigned)g);
     };
-#define SPRS_MICRO_SYM(M, GV, SV)                                                                                                     \
+#define SPRS_MICRO_SYM(M, GV, KV)                                                                                                     \
     if (pl->n_micro[M]) {                                                                                                           \
-        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, false, GV, SV>), micro_grid(pl->n_micro[M], WAVE / GV), dim3(256), 0, wstream, A, B, \
+        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, false, GV, KV>), micro_grid(pl->n_micro[M], WAVE / GV), dim3(256), 0, wstream, A, B, (const uint64_t *)pl->ent_ext.as<uint64_t>(), \
                            (const MicroRec *)pl->micro_list[M].as<MicroRec>(), pl->n_micro[M], pl->count.as<uint64_t>(),             \
                            (const uint64_t *)nullptr, (IDX *)nullptr, (double *)nullptr);                                            \
         SPRS_TRY_HIP(hipGetLastError());                                                                                            \
     }
-    if (options().spgemm_micro != 3) {
-        SPRS_MICRO_SYM(0, 16, true)
-        SPRS_MICRO_SYM(1, 32, true)
-        SPRS_MICRO_SYM(2, 64, true)
-    } else {                                                             // the rotation exchanges of the first version (A/B)
-        SPRS_MICRO_SYM(0, 16, false)
-        SPRS_MICRO_SYM(1, 32, false)
-        SPRS_MICRO_SYM(2, 64, false)
+    if (b_cols <= MICRO_KEY32_COLS) {                                   // (column, position) sort keys of one word
+        SPRS_MICRO_SYM(0, 16, uint32_t)
+        SPRS_MICRO_SYM(1, 32, uint32_t)
+        SPRS_MICRO_SYM(2, 64, uint32_t)
+    } else {
+        SPRS_MICRO_SYM(0, 16, uint64_t)
+        SPRS_MICRO_SYM(1, 32, uint64_t)
+        SPRS_MICRO_SYM(2, 64, uint64_t)
     }
 #undef SPRS_MICRO_SYM
     if (n_tiny) {
@@ -2154,23 +2133,23 @@ int32_t plan_run(sprs_hip_spgemm_plan *pl, const sprs_hip_csmat *a, const sprs_h
     uint32_t bin_shift = 0;
     while (bin_shift < 32 && ((pl->b_cols - (pl->b_cols ? 1 : 0)) >> bin_shift) >= (uint64_t)SM_NBIN) ++bin_shift;
     const uint32_t small_flags = add_flags();
-#define SPRS_MICRO_NUM(M, GV, SV)                                                                                                     \
+#define SPRS_MICRO_NUM(M, GV, KV)                                                                                                     \
     if (pl->n_micro[M]) {                                                                                                           \
         uint64_t mg = ((pl->n_micro[M] + (WAVE / GV) - 1) / (WAVE / GV) + 3) / 4;                                                     \
         if (mg > 256 * 8) mg = 256 * 8;                                                                                             \
-        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, true, GV, SV>), dim3((unsigned)mg), dim3(256), 0, wstream, A, B,                 \
+        hipLaunchKernelGGL((micro_rows_kernel<IDX, PTR, true, GV, KV>), dim3((unsigned)mg), dim3(256), 0, wstream, A, B, (const uint64_t *)pl->ent_ext.as<uint64_t>(), \
                            (const MicroRec *)pl->micro_list[M].as<MicroRec>(), pl->n_micro[M], pl->count.as<uint64_t>(),             \
                            (const uint64_t *)pl->off.as<uint64_t>(), c_indices, c_values);                                           \
         SPRS_TRY_HIP(hipGetLastError());                                                                                            \
     }
-    if (options().spgemm_micro != 3) {
-        SPRS_MICRO_NUM(0, 16, true)
-        SPRS_MICRO_NUM(1, 32, true)
-        SPRS_MICRO_NUM(2, 64, true)
-    } else {                                                             // the rotation exchanges of the first version (A/B)
-        SPRS_MICRO_NUM(0, 16, false)
-        SPRS_MICRO_NUM(1, 32, false)
-        SPRS_MICRO_NUM(2, 64, false)
+    if (pl->b_cols <= MICRO_KEY32_COLS) {                                   // (column, position) sort keys of one word
+        SPRS_MICRO_NUM(0, 16, uint32_t)
+        SPRS_MICRO_NUM(1, 32, uint32_t)
+        SPRS_MICRO_NUM(2, 64, uint32_t)
+    } else {
+        SPRS_MICRO_NUM(0, 16, uint64_t)
+        SPRS_MICRO_NUM(1, 32, uint64_t)
+        SPRS_MICRO_NUM(2, 64, uint64_t)
     }
 #undef SPRS_MICRO_NUM
     if (n_tiny)

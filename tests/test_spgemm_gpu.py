@@ -358,9 +358,13 @@ def test_micro_rows_lane_groups(hip, idx, ptr):
     a2_ix = np.array([k for r in a2_rows for k in r], dtype=np.int64)
     a2_dt = rng.standard_normal(a2_ix.size) * 10.0 ** rng.integers(-12, 13, size=a2_ix.size)
     cases.append((((len(a2_rows), nb2), a2_ip.astype(ptr), a2_ix.astype(idx), a2_dt), ((nb2, 200), b2_ip.astype(ptr), b2_ix.astype(idx), b2_dt)))
+    # the same rows against a B of 2^26 + 100 columns: past the width where a (column, position) sort key fits one 32-bit word
+    wide = (1 << 26) + 100
+    scale = wide // cols
+    cases.append((A, ((n_b, wide), bip, (bix.astype(np.int64) * scale + 3).astype(idx), bdt)))
     for a, b in cases:
         ref = oracle.mul_csr_csr(*a, *b, threads=1)
-        for micro in (0, 2, 3):                                           # sorted groups, the hash kernel, all-pairs rotations
+        for micro in (0, 2):                                              # lane groups, the hash kernel
             hip.set_option("spgemm_micro", micro)
             try:
                 _, ip, ix, dt = gpu_mul(a, b)
