@@ -19,6 +19,7 @@
 #   spgemm_traffic        FETCH_SIZE / WRITE_SIZE pass over SpGEMM config 5 -> spgemm_traffic.txt (scripts/spgemm_traffic.py)
 #   spmm[:args]           SpMM on R-MAT 10M (scripts/spmm_bench.py [n nnz_per_row k ...]) + its kernel stats
 #   spgemm_uniform[:args] bench.py --workload spgemm_uniform (sprs-benches shape) + its kernel stats (small_rows_kernel throughput)
+#   spgemm_uniform_seq    dispatch sequence (offsets, durations, gaps) of one uniform product -> spgemm_uniform_seq.txt
 #   py:<file>             python <file> (an ad-hoc measurement script kept under scripts/)
 #   pmcsq:<config>        SQ counter passes (instruction mix, busy / wait cycles) over one sweep config, per kernel means -> pmcsq.txt
 #   probe:<name>[:args]   scripts/probes/<name>.out [args] (stand-alone hardware probe, built here with hipcc; JSON lines -> <name>.jsonl)
@@ -104,6 +105,8 @@ for step in "$@"; do
     spgemm_uniform) # the reference's own bench shape (uniform 2.5M x 2.5M, 4 per row): the line, then per-kernel times of the same command
             timeout 600 python bench.py --workload spgemm_uniform $arg 2>/dev/null | tee -a $OUT/spgemm_uniform.jsonl
             ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d /tmp/st -o s -- python $ROOT/bench.py --workload spgemm_uniform --no-cpu-baseline --steps 3 $arg > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_summary.py $(prof_db /tmp/st) sprs_hip ) 2>&1 | grep -E "^kernel|^#|sprs_hip" | cut -c1-200 | head -24 | tee -a $OUT/spgemm_uniform_kernel_stats.txt ;;
+    spgemm_uniform_seq) # dispatch sequence of ONE uniform product with the gaps between its kernels
+            ( cd /tmp && rm -rf /tmp/st && timeout -s KILL 300 rocprofv3 --kernel-trace -d /tmp/st -o s -- python $ROOT/bench.py --workload spgemm_uniform --no-cpu-baseline --steps 3 $arg > /dev/null 2>&1; python3 $ROOT/scripts/rocprof_seq.py $(prof_db /tmp/st) start=pack_cols sprs_hip ) 2>&1 | cut -c1-200 | tee $OUT/spgemm_uniform_seq.txt ;;
     py)     timeout 900 python $arg 2>&1 | grep -v amdgpu.ids | tee -a $OUT/py.log ;;
     *)      echo "unknown step $name" ;;
   esac

@@ -2,7 +2,7 @@
 """Per-dispatch view of a rocprofv3 --kernel-trace result (rocpd SQLite): the kernels whose name contains one
 of the given substrings, grouped by (name, grid), with mean / min duration over the dispatches, and the
 dispatch sequence of the last repetition with the gaps between kernels.
-usage: rocprof_seq.py <results.db> substring [substring ...]"""
+usage: rocprof_seq.py <results.db> [start=<substring of the kernel that opens a repetition; default permute>] substring [substring ...]"""
 import sqlite3
 import sys
 from collections import OrderedDict
@@ -15,7 +15,13 @@ def short(name, n=84):
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    subs = sys.argv[2:] or ["sprs_hip"]
+    args = sys.argv[2:]
+    opener = "permute"
+    for a in list(args):
+        if a.startswith("start="):
+            opener = a[6:]
+            args.remove(a)
+    subs = args or ["sprs_hip"]
     rows = [r for r in db.execute("select name, grid_x, workgroup_x, start, end from kernels order by start")
             if any(s in r[0] for s in subs)]
     groups = OrderedDict()
@@ -33,7 +39,7 @@ def main():
             seq.append(r)
             if first_name is None:
                 first_name = r[0]
-            if "permute" in r[0]:
+            if opener in r[0]:
                 break
         seq.reverse()
         print("# last repetition (start-to-start offsets in us)")

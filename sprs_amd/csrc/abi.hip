@@ -109,15 +109,17 @@ hipError_t pool_alloc(void **out, uint64_t bytes, uint64_t *cap, int device) {
     return e;
 }
 
-void pool_free(void *ptr, uint64_t cap, int device) {
+void pool_free(void *ptr, uint64_t cap, int device, bool stream_ordered) {
     if (!ptr) return;
     int current = -1;
     // a block of ANOTHER device than the calling thread's current one goes straight back to the driver:
     // the synchronisation below would wait on the wrong device
     if (options().pool && cap >= POOL_MIN && hipGetDevice(&current) == hipSuccess && current == device) {
         Pool &p = pool();
-        // the block may still be read by kernels in flight: same guarantee as hipFree
-        if (hipDeviceSynchronize() == hipSuccess) {
+        // the block may still be read by kernels in flight: same guarantee as hipFree — unless the caller vouches that all of
+        // them, and every later use of a pooled block, are ordered by the null stream (the SpGEMM plan's temporaries: a product
+        // dropped ~25 blocks, each behind its own device synchronisation)
+        if (stream_ordered || hipDeviceSynchronize() == hipSuccess) {
             std::lock_guard<std::mutex> g(p.mu);
             if (p.cached + cap <= (uint64_t)options().pool_max_bytes) {
                 p.blocks.insert({{device, cap}, ptr});
@@ -182,11 +184,11 @@ int32_t alloc_csmat(sprs_hip_csmat **out, int32_t storage, uint64_t rows, uint64
     m->idx_bytes = idx_bytes;
     m->owns = true;
     hipError_t e = hipGetDevice(&m->device);
-    if (e == hipSuccess) e = hipMalloc(&m->indptr, (m->outer() + 1) * (uint64_t)iptr_bytes);
+    if (e == hipSuccess) e = pool_alloc(&m->indptr, (m->outer() + 1) * (uint64_t)iptr_bytes, &m->cap_indptr, m->device);
     if (e == hipSuccess) e = pool_alloc(&m->indices, nnz * (uint64_t)idx_bytes, &m->cap_indices, m->device);
     if (e == hipSuccess) e = pool_alloc((void **)&m->data, nnz * sizeof(double), &m->cap_data, m->device);
     if (e != hipSuccess) {
-        if (m->indptr) (void)hipFree(m->indptr);
+        pool_free(m->indptr, m->cap_indptr, m->device);
         pool_free(m->indices, m->cap_indices, m->device);
         pool_free(m->data, m->cap_data, m->device);
         delete m;
@@ -605,7 +607,7 @@ int32_t sprs_hip_csmat_free(sprs_hip_csmat *m) {
     if (m->t_view || m->as_other || m->plan.built) (void)hipDeviceSynchronize();
     invalidate_caches(m);
     if (m->owns) {
-        if (m->indptr) (void)hipFree(m->indptr);
+        pool_free(m->indptr, m->cap_indptr, m->device);
         pool_free(m->indices, m->cap_indices, m->device);
         pool_free(m->data, m->cap_data, m->device);
     }

@@ -205,7 +205,7 @@ struct sprs_hip_csmat {
     uint64_t spmv_calls = 0;   // multiplies so far: the re-laid-out plan copies (banded / XCD-sliced) are built at the SECOND one (or by sprs_hip_csmat_prepare)
     bool prepared = false;     // sprs_hip_csmat_prepare was called: the copy plans may be built at once
     bool one_shot = false;     // the handle multiplies once (sprs_hip_spmv_f64_host): plain plan, no copies of the matrix
-    uint64_t cap_indices = 0, cap_data = 0;   // bytes of the owned blocks (>= what nnz needs: blocks come from the pool)
+    uint64_t cap_indptr = 0, cap_indices = 0, cap_data = 0;   // bytes of the owned blocks (>= what nnz needs: blocks come from the pool)
     int device = 0;
     std::recursive_mutex mu;   // guards plan / mm: held from the look-up (or rebuild) of a plan until the kernels that read it are launched
     sprs_hip::SpmvPlan plan;
@@ -222,7 +222,9 @@ namespace sprs_hip {
 
 // abi.hip: result-block pool
 hipError_t pool_alloc(void **p, uint64_t bytes, uint64_t *cap, int device);
-void pool_free(void *p, uint64_t cap, int device);
+// stream_ordered = true: the block was only ever touched by work enqueued on the NULL stream (or on streams joined back to it)
+// and every later user of the pool enqueues there too, so it goes back without waiting for the device
+void pool_free(void *p, uint64_t cap, int device, bool stream_ordered = false);
 uint64_t pool_trim();
 uint64_t pool_cached_bytes();
 

@@ -263,61 +263,160 @@ struct alignas(16) MicroRec {       // a micro row in its class list: its task (
 };
 
 // Task lists, deterministic (first version: atomicAdd tickets, i.e. an arbitrary order that changed from call to call).
-// Classes of a row: tiny (<= 64 products), small (<= 512), large (one task per column window).
-__global__ void task_class_kernel(const uint8_t *__restrict__ cls, const uint64_t *__restrict__ ntasks, uint64_t rows,
-                                  uint64_t *__restrict__ is_tiny, uint64_t *__restrict__ is_small, uint64_t *__restrict__ is_mid,
-                                  uint64_t *__restrict__ n_large) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const uint8_t c = cls[r];
-    // the micro classes ride in the high halves of the same words: one scan gives both positions (rows < 2^32 per class)
-    is_tiny[r] = (uint64_t)(c == 1) | ((uint64_t)(c == CLS_MICRO16) << 32);
-    is_small[r] = (uint64_t)(c == 2) | ((uint64_t)(c == CLS_MICRO32) << 32);
-    is_mid[r] = (uint64_t)(c == 3) | ((uint64_t)(c == CLS_MICRO64) << 32);
-    n_large[r] = c == 4 ? ntasks[r] : 0;
+// Classes of a row: tiny (<= 64 products), small (<= 512), mid, large (one task per column window), three micro classes.
+// A row's place in its class list and its first task are PREFIX COUNTS over the rows: eight of them (tasks, large tasks, six
+// class flags).  Rounds 1 - 5 wrote one 8-byte flag array per count and scanned each with the general scan (five scans of
+// three launches, five 8-byte read-backs: 0.44 of the 1.72 ms of the reference's 2.5 M-row benchmark product, profiles/r16p).
+// Now the counts are taken straight from the class bytes: blocks of CLS_RB consecutive rows are summed (class_counts_kernel<false>),
+// one workgroup scans the block sums (class_sums_kernel; ONE read-back of the eight totals sizes the lists), and the second pass
+// over the same blocks (class_counts_kernel<true>) rebuilds each row's prefix — ballots for the flags, a wave scan for the
+// task counts — and writes the lists.
+constexpr int CLS_NV = 8;                           // tasks, large tasks, tiny, small, mid, micro16, micro32, micro64
+
+struct ClassLists {
+    uint64_t *task_row, *first_task, *large_slot, *tiny_list, *small_list, *mid_list, *large_list, *large_key, *mid_key;
+    MicroRec *m16, *m32, *m64;
+};
+
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint64_t o = __shfl_up(v, off, WAVE);
+        if (lane >= (uint32_t)off) v += o;
+    }
+    return v;
 }
 
-// lists in row order; for the large tasks also the sort key: the cost class (log2 of the products per task), costliest
-// first, so that the long tasks start early and the short ones fill the tail of the launch (the sort is stable: inside
-// a class the tasks stay in row order, and the list — with it every launch — is the same run to run)
-__global__ void make_tasks_kernel(const uint64_t *__restrict__ ntasks, const uint64_t *__restrict__ first_task,
-                                  const uint64_t *__restrict__ ub, uint64_t rows, const uint64_t *__restrict__ pos_tiny,
-                                  const uint64_t *__restrict__ pos_small, const uint64_t *__restrict__ pos_mid,
-                                  const uint64_t *__restrict__ pos_large, const uint8_t *__restrict__ cls,
-                                  uint64_t *__restrict__ task_row, uint64_t *__restrict__ tiny_list,
-                                  uint64_t *__restrict__ small_list, uint64_t *__restrict__ mid_list,
-                                  uint64_t *__restrict__ large_list, uint64_t *__restrict__ large_key,
-                                  uint64_t *__restrict__ mid_key, MicroRec *__restrict__ m16, MicroRec *__restrict__ m32,
-                                  MicroRec *__restrict__ m64) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    const uint64_t n = ntasks[r];
-    if (!n) return;
-    const uint64_t f = first_task[r];
-    for (uint64_t j = 0; j < n; ++j) task_row[f + j] = r;
-    const uint8_t c = cls[r];
-    constexpr uint64_t LOW = 0xFFFFFFFFull;
-    if (c == 1) {
-        tiny_list[pos_tiny[r] & LOW] = f;
-    } else if (c == 2) {
-        small_list[pos_small[r] & LOW] = f;
-    } else if (c == 3) {
-        mid_list[pos_mid[r] & LOW] = f;
-        mid_key[pos_mid[r] & LOW] = (uint64_t)__clzll((long long)(ub[r] | 1));
-    } else if (c == CLS_MICRO16) {
-        m16[pos_tiny[r] >> 32] = MicroRec{f, r};
-    } else if (c == CLS_MICRO32) {
-        m32[pos_small[r] >> 32] = MicroRec{f, r};
-    } else if (c == CLS_MICRO64) {
-        m64[pos_mid[r] >> 32] = MicroRec{f, r};
-    } else {
-        const uint64_t pos = pos_large[r];
-        const uint64_t cost = ub[r] / n;
-        const uint64_t key = (uint64_t)__clzll((long long)(cost | 1));     // 0 .. 63, small = costly
-        for (uint64_t j = 0; j < n; ++j) {
-            large_list[pos + j] = f + j;
-            large_key[pos + j] = key;
+// grid: one block of 256 threads per CLS_RB = rb consecutive rows (rb a multiple of 256).  LISTS = false: sums[v * nblocks + block]
+// = the block's eight counts.  LISTS = true: sums holds the exclusive prefix over the blocks; every row gets its positions.
+template <bool LISTS>
+__global__ __launch_bounds__(256) void class_counts_kernel(const uint8_t *__restrict__ cls, const uint64_t *__restrict__ ntasks,
+                                                           const uint64_t *__restrict__ ub, uint64_t rows, uint64_t rb,
+                                                           uint64_t *__restrict__ sums, ClassLists out) {
+    __shared__ uint64_t wtot[2][256 / WAVE][CLS_NV];
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const uint64_t nblocks = gridDim.x, row0 = (uint64_t)blockIdx.x * rb;
+    uint64_t base[CLS_NV];
+#pragma unroll
+    for (int v = 0; v < CLS_NV; ++v) base[v] = LISTS ? sums[(uint64_t)v * nblocks + blockIdx.x] : 0;
+    const uint8_t want[6] = {1, 2, 3, CLS_MICRO16, CLS_MICRO32, CLS_MICRO64};
+    if constexpr (!LISTS) {
+        // sums only: every thread counts its own rows, one LDS addition per thread and count at the end
+        __shared__ unsigned long long tot[CLS_NV];
+        if (threadIdx.x < CLS_NV) tot[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint64_t r = row0 + threadIdx.x; r < row0 + rb && r < rows; r += 256) {
+            const uint8_t c = cls[r];
+            const uint64_t nt = ntasks[r];
+            base[0] += nt;
+            base[1] += c == 4 ? nt : 0;
+#pragma unroll
+            for (int v = 0; v < 6; ++v) base[2 + v] += c == want[v] ? 1u : 0u;
         }
+#pragma unroll
+        for (int v = 0; v < CLS_NV; ++v)
+            if (base[v]) atomicAdd(&tot[v], (unsigned long long)base[v]);
+        __syncthreads();
+        if (threadIdx.x < CLS_NV) sums[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = tot[threadIdx.x];
+        return;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t it = 0;
+    for (uint64_t r0 = row0; r0 < row0 + rb && r0 < rows; r0 += 256, ++it) {       // block-uniform
+        const uint64_t r = r0 + threadIdx.x;
+        const bool ok = r < rows;
+        const uint8_t c = ok ? cls[r] : (uint8_t)0;
+        const uint64_t nt = ok ? ntasks[r] : 0;
+        uint64_t pre[CLS_NV], tot[CLS_NV];
+        {
+            const uint64_t inc = wave_incl_scan_u64(nt);
+            pre[0] = inc - nt;
+            tot[0] = __shfl(inc, WAVE - 1, WAVE);
+            const uint64_t nl = c == 4 ? nt : 0, incl = wave_incl_scan_u64(nl);
+            pre[1] = incl - nl;
+            tot[1] = __shfl(incl, WAVE - 1, WAVE);
+        }
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+            const unsigned long long m = __ballot(c == want[v]);
+            pre[2 + v] = (uint64_t)__popcll(m & below);
+            tot[2 + v] = (uint64_t)__popcll(m);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int v = 0; v < CLS_NV; ++v) wtot[it & 1][wave][v] = tot[v];
+        }
+        __syncthreads();                                                           // (two buffers: one barrier per 256 rows)
+#pragma unroll
+        for (int v = 0; v < CLS_NV; ++v) {
+            uint64_t before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < 256 / WAVE; ++w) {
+                const uint64_t t = wtot[it & 1][w][v];
+                if ((uint32_t)w < wave) before += t;
+                all += t;
+            }
+            pre[v] += base[v] + before;
+            base[v] += all;
+        }
+        if constexpr (LISTS) {
+            if (ok) {
+                const uint64_t f = pre[0];
+                out.first_task[r] = f;
+                out.large_slot[r] = pre[1];
+                for (uint64_t j = 0; j < nt; ++j) out.task_row[f + j] = r;
+                if (nt) {
+                    if (c == 1) {
+                        out.tiny_list[pre[2]] = f;
+                    } else if (c == 2) {
+                        out.small_list[pre[3]] = f;
+                    } else if (c == 3) {
+                        out.mid_list[pre[4]] = f;
+                        out.mid_key[pre[4]] = (uint64_t)__clzll((long long)(ub[r] | 1));
+                    } else if (c == CLS_MICRO16) {
+                        out.m16[pre[5]] = MicroRec{f, r};
+                    } else if (c == CLS_MICRO32) {
+                        out.m32[pre[6]] = MicroRec{f, r};
+                    } else if (c == CLS_MICRO64) {
+                        out.m64[pre[7]] = MicroRec{f, r};
+                    } else {
+                        // lists in row order; for the large tasks also the sort key: the cost class (log2 of the products per task),
+                        // costliest first, so that the long tasks start early and the short ones fill the tail of the launch (the
+                        // sort is stable: inside a class the tasks stay in row order, and the list is the same run to run)
+                        const uint64_t pos = pre[1];
+                        const uint64_t cost = ub[r] / nt;
+                        const uint64_t key = (uint64_t)__clzll((long long)(cost | 1));     // 0 .. 63, small = costly
+                        for (uint64_t j = 0; j < nt; ++j) {
+                            out.large_list[pos + j] = f + j;
+                            out.large_key[pos + j] = key;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// one workgroup of CLS_NV waves: wave v turns sums[v * nblocks ..] into its exclusive prefix and leaves the total in totals[v];
+// the total of the tasks also closes first_task (first_task[rows] = number of tasks)
+__global__ __launch_bounds__(CLS_NV *WAVE) void class_sums_kernel(uint64_t *__restrict__ sums, uint64_t nblocks, uint64_t *__restrict__ totals,
+                                                                  uint64_t *__restrict__ first_task, uint64_t rows) {
+    const uint32_t lane = threadIdx.x & (WAVE - 1), v = threadIdx.x / WAVE;
+    uint64_t *s = sums + (uint64_t)v * nblocks;
+    uint64_t carry = 0;
+    uint64_t xn = lane < nblocks ? s[lane] : 0;                                     // (the next chunk is requested while this one is scanned)
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += WAVE) {                               // wave-uniform
+        const uint64_t b = b0 + lane;
+        const uint64_t x = xn;
+        xn = b + WAVE < nblocks ? s[b + WAVE] : 0;
+        const uint64_t inc = wave_incl_scan_u64(x);
+        if (b < nblocks) s[b] = carry + inc - x;
+        carry += __shfl(inc, WAVE - 1, WAVE);
+    }
+    if (lane == 0) {
+        totals[v] = carry;
+        if (v == 0) first_task[rows] = carry;
     }
 }
 
@@ -616,8 +715,10 @@ __global__ __launch_bounds__(256) void micro_rows_kernel(CsrView<IDX, PTR> A, Cs
         uint32_t c;
         double pr = 0.0;
         if constexpr (NUMERIC) {
-            c = (uint32_t)B.indices[pos];
             const double av_o = __shfl(xc.av, (int)own, G);
+            // ({column, value} records of B — one 64-byte gather per k instead of 16 + 32 — take 35 us off the three value kernels
+            // of the 2.5 M-row benchmark product and cost 57 us to build: profiles/r16r)
+            c = B.col32[pos];
             pr = av_o * B.data[pos];
         } else {
             c = B.col32[pos];
@@ -1645,7 +1746,7 @@ struct DevBuf {
     int dev = 0;
     ~DevBuf() { release(); }
     void release() {
-        if (p) pool_free(p, cap, dev);
+        if (p) pool_free(p, cap, dev, true);      // (every kernel of this file runs on the null stream or on the aux stream joined back to it)
         p = nullptr;
     }
     hipError_t alloc(uint64_t bytes) {
@@ -1830,25 +1931,23 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
         B.col32 = pl->bcol32.as<uint32_t>();
     }
 
-    DevBuf is_tiny, is_small, is_mid, n_large_r, pos_tiny, pos_small, pos_mid, large_key, mid_key, cls;
+    DevBuf large_key, mid_key, cls, class_sums, class_totals;
     DevBuf &pos_large = pl->large_slot;      // slot of a large row's bitmap = position of its first task in the (unsorted) large list
     SPRS_TRY_HIP(pl->ub.alloc(rows * 8));
     SPRS_TRY_HIP(pl->wlog.alloc(rows));
     SPRS_TRY_HIP(pl->ntasks.alloc(rows * 8));
     SPRS_TRY_HIP(pl->first_task.alloc((rows + 1) * 8));
-    SPRS_TRY_HIP(is_tiny.alloc(rows * 8));
-    SPRS_TRY_HIP(is_small.alloc(rows * 8));
-    SPRS_TRY_HIP(is_mid.alloc(rows * 8));
-    SPRS_TRY_HIP(pos_mid.alloc((rows + 1) * 8));
     SPRS_TRY_HIP(cls.alloc(rows));
-    SPRS_TRY_HIP(n_large_r.alloc(rows * 8));
-    SPRS_TRY_HIP(pos_tiny.alloc((rows + 1) * 8));
-    SPRS_TRY_HIP(pos_small.alloc((rows + 1) * 8));
     SPRS_TRY_HIP(pos_large.alloc((rows + 1) * 8));
-    const dim3 rgrid((unsigned)((rows + 255) / 256)), rblock(256);
     // micro rows (lane groups): columns of B below EMPTY, entries of B below 2^40 (the extent word of an entry of A)
     const bool micro = options().spgemm_micro != 2 && b_cols < 0xFFFFFFFFull && (uint64_t)b->nnz <= EXT_START;
     if (micro) SPRS_TRY_HIP(pl->ent_ext.alloc((a->nnz ? a->nnz : 1) * sizeof(uint64_t)));
+    // blocks of the class counts (see class_counts_kernel): 2048 rows each, more when that would be more than 65 536 blocks
+    uint64_t cls_rb = 2048;
+    while ((rows + cls_rb - 1) / cls_rb > 65536) cls_rb *= 2;
+    const uint64_t cls_blocks = rows ? (rows + cls_rb - 1) / cls_rb : 1;
+    SPRS_TRY_HIP(class_sums.alloc(cls_blocks * CLS_NV * 8));
+    SPRS_TRY_HIP(class_totals.alloc(CLS_NV * 8));
     if (rows) {
         uint64_t blocks = (rows + 3) / 4;
         if (blocks > 256 * 64) blocks = 256 * 64;
@@ -1858,27 +1957,24 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
                            pl->ub.as<uint64_t>(), pl->ntasks.as<uint64_t>(), cls.as<uint8_t>(), pl->wlog.as<uint8_t>(),
                            micro ? 1u : 0u, micro ? pl->ent_ext.as<uint64_t>() : (uint64_t *)nullptr);
         SPRS_TRY_HIP(hipGetLastError());
-        hipLaunchKernelGGL(task_class_kernel, rgrid, rblock, 0, stream, (const uint8_t *)cls.as<uint8_t>(), pl->ntasks.as<uint64_t>(), rows,
-                           is_tiny.as<uint64_t>(), is_small.as<uint64_t>(), is_mid.as<uint64_t>(), n_large_r.as<uint64_t>());
+        hipLaunchKernelGGL((class_counts_kernel<false>), dim3((unsigned)cls_blocks), dim3(256), 0, stream, (const uint8_t *)cls.as<uint8_t>(),
+                           (const uint64_t *)pl->ntasks.as<uint64_t>(), (const uint64_t *)pl->ub.as<uint64_t>(), rows, cls_rb,
+                           class_sums.as<uint64_t>(), ClassLists{});
         SPRS_TRY_HIP(hipGetLastError());
+    } else {
+        SPRS_TRY_HIP(hipMemsetAsync(class_sums.p, 0, CLS_NV * 8, stream));
     }
-    SPRS_TRY(exclusive_scan_u64(pl->ntasks.as<uint64_t>(), pl->first_task.as<uint64_t>(), rows, stream));
-    SPRS_TRY(exclusive_scan_u64(is_tiny.as<uint64_t>(), pos_tiny.as<uint64_t>(), rows, stream));
-    SPRS_TRY(exclusive_scan_u64(is_small.as<uint64_t>(), pos_small.as<uint64_t>(), rows, stream));
-    SPRS_TRY(exclusive_scan_u64(is_mid.as<uint64_t>(), pos_mid.as<uint64_t>(), rows, stream));
-    SPRS_TRY(exclusive_scan_u64(n_large_r.as<uint64_t>(), pos_large.as<uint64_t>(), rows, stream));
-    SPRS_TRY_HIP(hipMemcpy(&pl->ntask_total, pl->first_task.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
-    SPRS_TRY_HIP(hipMemcpy(&pl->n_tiny, pos_tiny.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
-    SPRS_TRY_HIP(hipMemcpy(&pl->n_small, pos_small.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
-    SPRS_TRY_HIP(hipMemcpy(&pl->n_mid, pos_mid.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
-    SPRS_TRY_HIP(hipMemcpy(&pl->n_large, pos_large.as<uint64_t>() + rows, 8, hipMemcpyDeviceToHost));
-    // (the micro classes' counts ride in the high halves of the tiny / small / mid scans)
-    pl->n_micro[0] = pl->n_tiny >> 32;
-    pl->n_micro[1] = pl->n_small >> 32;
-    pl->n_micro[2] = pl->n_mid >> 32;
-    pl->n_tiny &= 0xFFFFFFFFull;
-    pl->n_small &= 0xFFFFFFFFull;
-    pl->n_mid &= 0xFFFFFFFFull;
+    hipLaunchKernelGGL(class_sums_kernel, dim3(1), dim3(CLS_NV * WAVE), 0, stream, class_sums.as<uint64_t>(), cls_blocks,
+                       class_totals.as<uint64_t>(), pl->first_task.as<uint64_t>(), rows);
+    SPRS_TRY_HIP(hipGetLastError());
+    uint64_t totals[CLS_NV];
+    SPRS_TRY_HIP(hipMemcpy(totals, class_totals.p, sizeof(totals), hipMemcpyDeviceToHost));     // the one read-back that sizes the lists
+    pl->ntask_total = totals[0];
+    pl->n_large = totals[1];
+    pl->n_tiny = totals[2];
+    pl->n_small = totals[3];
+    pl->n_mid = totals[4];
+    for (int m = 0; m < 3; ++m) pl->n_micro[m] = totals[5 + m];
     const uint64_t ntask_total = pl->ntask_total, n_small = pl->n_small, n_mid = pl->n_mid, n_large = pl->n_large, n_tiny = pl->n_tiny;
     for (int m = 0; m < 3; ++m) SPRS_TRY_HIP(pl->micro_list[m].alloc((pl->n_micro[m] ? pl->n_micro[m] : 1) * sizeof(MicroRec)));
     if (n_large > 0x7fffffffull) SPRS_FAIL(SPRS_HIP_INVALID_ARG, "too many SpGEMM tasks for one launch");
@@ -1892,13 +1988,14 @@ int32_t plan_build(const sprs_hip_csmat *a, const sprs_hip_csmat *b, sprs_hip_sp
     SPRS_TRY_HIP(mid_key.alloc(n_mid * 8));
     SPRS_TRY_HIP(pl->count.alloc(ntask_total * 8));
     SPRS_TRY_HIP(pl->off.alloc((ntask_total + 1) * 8));
-    if (ntask_total) {
-        hipLaunchKernelGGL(make_tasks_kernel, rgrid, rblock, 0, stream, pl->ntasks.as<uint64_t>(), pl->first_task.as<uint64_t>(),
-                           pl->ub.as<uint64_t>(), rows, pos_tiny.as<uint64_t>(), pos_small.as<uint64_t>(), pos_mid.as<uint64_t>(),
-                           pos_large.as<uint64_t>(), (const uint8_t *)cls.as<uint8_t>(), pl->task_row.as<uint64_t>(),
-                           pl->tiny_list.as<uint64_t>(), pl->small_list.as<uint64_t>(), pl->mid_list.as<uint64_t>(),
-                           pl->large_list.as<uint64_t>(), large_key.as<uint64_t>(), mid_key.as<uint64_t>(),
-                           pl->micro_list[0].as<MicroRec>(), pl->micro_list[1].as<MicroRec>(), pl->micro_list[2].as<MicroRec>());
+    if (rows) {
+        ClassLists lists{pl->task_row.as<uint64_t>(), pl->first_task.as<uint64_t>(), pos_large.as<uint64_t>(), pl->tiny_list.as<uint64_t>(),
+                         pl->small_list.as<uint64_t>(), pl->mid_list.as<uint64_t>(), pl->large_list.as<uint64_t>(), large_key.as<uint64_t>(),
+                         mid_key.as<uint64_t>(), pl->micro_list[0].as<MicroRec>(), pl->micro_list[1].as<MicroRec>(),
+                         pl->micro_list[2].as<MicroRec>()};
+        hipLaunchKernelGGL((class_counts_kernel<true>), dim3((unsigned)cls_blocks), dim3(256), 0, stream, (const uint8_t *)cls.as<uint8_t>(),
+                           (const uint64_t *)pl->ntasks.as<uint64_t>(), (const uint64_t *)pl->ub.as<uint64_t>(), rows, cls_rb,
+                           class_sums.as<uint64_t>(), lists);
         SPRS_TRY_HIP(hipGetLastError());
     }
     // costliest tasks first (stable sort by cost class); option spgemm_task_order = 2 keeps the row order (A/B)
