@@ -67,7 +67,8 @@ Pool &pool() {
     static Pool p;
     return p;
 }
-constexpr uint64_t POOL_MIN = 1ull << 20;
+constexpr uint64_t POOL_MIN = 1ull << 20;      // from here on: best fit with <= 25 % slack
+constexpr uint64_t POOL_SMALL = 256;            // below POOL_MIN: size classes, powers of two from this one
 }  // namespace
 
 uint64_t pool_trim() {
@@ -88,7 +89,14 @@ uint64_t pool_cached_bytes() {
 
 hipError_t pool_alloc(void **out, uint64_t bytes, uint64_t *cap, int device) {
     if (bytes == 0) bytes = 8;       // hipMalloc(0) returns nullptr; kernels never see NULL
-    if (options().pool && bytes >= POOL_MIN) {
+    // small blocks (task lists of a few entries, block sums of a scan, key arrays) are pooled in power-of-two classes from 256 B:
+    // a product made ~15 of them, each a hipMalloc and a hipFree (which waits for the device) of its own
+    if (bytes < POOL_MIN) {
+        uint64_t cls = POOL_SMALL;
+        while (cls < bytes) cls <<= 1;
+        bytes = cls;
+    }
+    if (options().pool) {
         Pool &p = pool();
         std::lock_guard<std::mutex> g(p.mu);
         auto it = p.blocks.lower_bound({device, bytes});
@@ -114,7 +122,7 @@ void pool_free(void *ptr, uint64_t cap, int device, bool stream_ordered) {
     int current = -1;
     // a block of ANOTHER device than the calling thread's current one goes straight back to the driver:
     // the synchronisation below would wait on the wrong device
-    if (options().pool && cap >= POOL_MIN && hipGetDevice(&current) == hipSuccess && current == device) {
+    if (options().pool && cap >= POOL_SMALL && hipGetDevice(&current) == hipSuccess && current == device) {
         Pool &p = pool();
         // the block may still be read by kernels in flight: same guarantee as hipFree — unless the caller vouches that all of
         // them, and every later use of a pooled block, are ordered by the null stream (the SpGEMM plan's temporaries: a product

@@ -92,17 +92,22 @@ int32_t radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t n, const std::
         for (int b = 0; b < f.second; b += 8) passes.push_back({f.first + b, (1u << (f.second - b < 8 ? f.second - b : 8)) - 1u});
     if (passes.empty()) return SPRS_HIP_OK;
     const uint64_t nchunks = (n + RS_CHUNK - 1) / RS_CHUNK;
+    // temporaries from the library's pool, handed back in null-stream order (a call on another stream waits for it first)
     uint64_t *tk = nullptr, *tv = nullptr, *hist = nullptr, *offs = nullptr;
+    uint64_t cap_tk = 0, cap_tv = 0, cap_hist = 0, cap_offs = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     auto cleanup = [&]() {
-        if (tk) (void)hipFree(tk);
-        if (tv) (void)hipFree(tv);
-        if (hist) (void)hipFree(hist);
-        if (offs) (void)hipFree(offs);
+        if (stream != nullptr) (void)hipStreamSynchronize(stream);
+        pool_free(tk, cap_tk, dev, true);
+        pool_free(tv, cap_tv, dev, true);
+        pool_free(hist, cap_hist, dev, true);
+        pool_free(offs, cap_offs, dev, true);
     };
-    hipError_t e = hipMalloc((void **)&tk, n * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&tv, n * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&hist, (RS_BINS * nchunks + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&offs, (RS_BINS * nchunks + 1) * 8);
+    if (e == hipSuccess) e = pool_alloc((void **)&tk, n * 8, &cap_tk, dev);
+    if (e == hipSuccess) e = pool_alloc((void **)&tv, n * 8, &cap_tv, dev);
+    if (e == hipSuccess) e = pool_alloc((void **)&hist, (RS_BINS * nchunks + 1) * 8, &cap_hist, dev);
+    if (e == hipSuccess) e = pool_alloc((void **)&offs, (RS_BINS * nchunks + 1) * 8, &cap_offs, dev);
     if (e != hipSuccess) {
         cleanup();
         return fail_hip(e, "radix_sort_pairs");
@@ -126,7 +131,7 @@ int32_t radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t n, const std::
     }
     if (st == SPRS_HIP_OK) {
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);   // the temporaries go away below
+        if (e == hipSuccess && stream != nullptr) e = hipStreamSynchronize(stream);   // (the temporaries go back to the pool below, in null-stream order)
         if (e != hipSuccess) st = fail_hip(e, "radix_sort_pairs");
     }
     cleanup();
