@@ -44,7 +44,7 @@ def algorithmic_bytes(rows, cols, nnz, idx_bytes, iptr_bytes, accumulate=False):
 # what a workload's launches can reach: its kernels, the headers they include, the shared scan / sort, the option table
 CSRC_OF = {
     "spmv": ("common.hpp", "scan.hpp", "scan.hip", "spmv_shared.hpp", "spmv.hip", "spmv_band.hip", "spmv_band_kernels.hpp"),
-    "spgemm": ("common.hpp", "scan.hpp", "scan.hip", "sort.hip", "spgemm.hip"),
+    "spgemm": ("common.hpp", "lanes.hpp", "scan.hpp", "scan.hip", "sort.hip", "spgemm.hip"),
 }
 
 
@@ -296,8 +296,8 @@ def spgemm_uniform(dev, n=2_500_000, nnz_over_rows=4, steps=3, with_cpu=True):
     m2 (n x n), both from the uniform generator at density nnz_over_rows / n (sprs-rand `rand_csr`, here gen.uniform_csr),
     timed at ThreadingStrategy::Fixed(1) and ::Automatic on the CPU (the C restatement of smmp::mul_csr_csr; the reference
     also times 2 and 4 threads).  Every row of the product has ~16 multiply-adds: the whole product runs through the
-    one-wave-per-row LDS-hash kernel (small_rows_kernel).  The WHOLE product is compared with the oracle's, structure and
-    value bits."""
+    lane-group kernel of the rows of at most 64 products (micro_rows_kernel).  The WHOLE product is compared
+    with the oracle's, structure and value bits."""
     from sprs_amd import gen, smmp
     from sprs_amd.device import DeviceCsMat
     dens = float(nnz_over_rows) / n
