@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <vector>
 
@@ -28,15 +29,15 @@ __global__ void exchanges(const uint64_t *in, uint64_t *out) {
     o[23] = 0;
 }
 
-int main() {
-    const int waves = 4096, n = waves * 64;
+int main(int argc, char **argv) {
+    const int waves = argc > 1 ? atoi(argv[1]) : 4096, n = waves * 64;      // (a multiple of 4: four waves per block)
     std::mt19937_64 rng(12345);
     std::vector<uint64_t> in(n), out((size_t)n * 24);
     for (auto &x : in) x = rng();
     for (int i = 0; i < 64; ++i) in[i] = (uint64_t)(i * 3 + 1) | ((uint64_t)(1000 - i) << 32);     // a readable first wave
     uint64_t *d_in, *d_out;
-    (void)hipMalloc(&d_in, n * 8);
-    (void)hipMalloc(&d_out, (size_t)n * 24 * 8);
+    (void)hipMalloc((void **)&d_in, n * 8);
+    (void)hipMalloc((void **)&d_out, (size_t)n * 24 * 8);
     (void)hipMemcpy(d_in, in.data(), n * 8, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(exchanges, dim3(waves / 4), dim3(256), 0, 0, d_in, d_out);
     if (hipDeviceSynchronize() != hipSuccess) { printf("{\"probe\": \"lane_ops\", \"error\": \"launch\"}\n"); return 1; }

@@ -1,8 +1,9 @@
 // Lane exchanges of one wavefront WITHOUT the LDS crossbar (gfx950): DPP modifiers inside a row of 16 lanes, v_permlane16_swap /
 // v_permlane32_swap between rows — VALU instructions that fold into their consumer (v_min_u32_dpp ...), where __shfl_xor is a
 // ds_bpermute_b32 plus an address and a wait per exchange.  The micro-row kernel of spgemm.hip sorts a lane group with them
-// (a bitonic network: 10 / 15 / 21 exchanges for 16 / 32 / 64 lanes).  The CPU emulator (tests/emu) takes the __shfl forms;
-// scripts/probes/lane_ops.hip checks every function here against __shfl on the hardware.
+// (a bitonic network: 10 / 15 / 21 exchanges for 16 / 32 / 64 lanes).  The CPU emulator (tests/emu) models the DPP controls and
+// the two swaps and runs these sequences as written; scripts/probes/lane_ops.hip checks every function here against __shfl on
+// the hardware.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -14,9 +15,6 @@ namespace sprs_hip {
 template <int J>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
     static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "a single bit");
-#ifdef SPRS_HIP_EMU
-    return __shfl_xor(v, J, 64);
-#else
     if constexpr (J == 1) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);       // quad_perm:[1,0,3,2]
     } else if constexpr (J == 2) {
@@ -37,7 +35,6 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
         const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
         return (threadIdx.x & 32u) ? r[0] : r[1];
     }
-#endif
 }
 
 template <int J>
@@ -47,36 +44,18 @@ __device__ __forceinline__ uint64_t lane_xor(uint64_t v) {
 
 // the value of the lane below (lane - 1); lane 0 of the wave gets 0
 __device__ __forceinline__ uint32_t lane_below(uint32_t v) {
-#ifdef SPRS_HIP_EMU
-    const uint32_t o = __shfl_up(v, 1, 64);
-    return (threadIdx.x & 63u) ? o : 0u;
-#else
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);          // wave_shr:1
-#endif
 }
 
 // the value of the lane above (lane + 1); lane 63 gets 0
 __device__ __forceinline__ uint32_t lane_above(uint32_t v) {
-#ifdef SPRS_HIP_EMU
-    const uint32_t o = __shfl_down(v, 1, 64);
-    return (threadIdx.x & 63u) != 63u ? o : 0u;
-#else
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);          // wave_shl:1
-#endif
 }
 
 // inclusive sum over the lanes of a GROUP of G = 16 / 32 / 64 consecutive lanes (groups aligned to G)
 template <int G>
 __device__ __forceinline__ uint32_t group_incl_scan_u32(uint32_t v) {
     static_assert(G == 16 || G == 32 || G == 64, "a row, two rows or the wave");
-#ifdef SPRS_HIP_EMU
-    const uint32_t gl = threadIdx.x & (uint32_t)(G - 1);
-    for (int off = 1; off < G; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, G);
-        if (gl >= (uint32_t)off) v += o;
-    }
-    return v;
-#else
     int x = (int)v;
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);     // row_shr:1 (zeros shifted in)
     x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);     // row_shr:2
@@ -85,7 +64,6 @@ __device__ __forceinline__ uint32_t group_incl_scan_u32(uint32_t v) {
     if constexpr (G >= 32) x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
     if constexpr (G >= 64) x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
     return (uint32_t)x;
-#endif
 }
 
 // ascending sort of one key per lane inside every group of G lanes (keys of a group distinct, or equal keys interchangeable):

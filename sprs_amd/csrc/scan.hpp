@@ -55,14 +55,6 @@ __device__ __forceinline__ void wave_sync_lds() {
 
 // inclusive MAX scan over the 64 lanes (same DPP ladder as the sum; identity 0, operands are small non-negative numbers)
 __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
-#ifdef SPRS_HIP_EMU
-    const uint32_t lane = threadIdx.x & (63);
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, 64);
-        if (lane >= (uint32_t)off && o > v) v = o;
-    }
-    return v;
-#else
     // UNSIGNED max (v_max_u32): a mark of 2^31 or more — a gap of that many rows inside one SpMM tile — stays the largest
     uint32_t x = v;
 #define SPRS_MAX_STEP(CTRL, MASK, BOUND)                                                                  \
@@ -78,7 +70,6 @@ __device__ __forceinline__ uint32_t wave_incl_max_u32(uint32_t v) {
     SPRS_MAX_STEP(0x143, 0xc, false)     // row_bcast:31 into rows 2 and 3
 #undef SPRS_MAX_STEP
     return x;
-#endif
 }
 
 // the same scans with LDS-only barriers

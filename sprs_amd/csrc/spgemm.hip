@@ -1024,25 +1024,7 @@ constexpr int MID_ACC = 512;                      // accumulators of one pass
 constexpr int MID_K = 64;                         // k's per row: one per lane
 
 // inclusive scan over the 64 lanes without the LDS: four row_shr steps inside the rows of 16 lanes, then row_bcast 15 and 31
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-#ifdef SPRS_HIP_EMU
-    const uint32_t lane = threadIdx.x & (WAVE - 1);
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, WAVE);
-        if (lane >= (uint32_t)off) v += o;
-    }
-    return v;
-#else
-    int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);     // row_shr:1 (zeros shifted in)
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);     // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);     // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);     // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
-    return (uint32_t)x;
-#endif
-}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) { return group_incl_scan_u32<WAVE>(v); }   // lanes.hpp
 
 // The products of one wave instruction into their accumulators.  The lanes hold 64 CONSECUTIVE positions of the expansion
 // (k ascending with the lane), so lanes that meet in one accumulator must be applied in ascending lane order.

@@ -94,13 +94,6 @@ struct PieceView {
 
 // ---- wave primitives without the LDS ---------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t band_scan_incl_u32(uint32_t v, uint32_t lane) {
-#ifdef SPRS_HIP_EMU
-    for (int off = 1; off < WAVE; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, WAVE);
-        if (lane >= (uint32_t)off) v += o;
-    }
-    return v;
-#else
     (void)lane;
     int x = (int)v;
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);     // row_shr:1 (zeros shifted in)
@@ -110,14 +103,12 @@ __device__ __forceinline__ uint32_t band_scan_incl_u32(uint32_t v, uint32_t lane
     x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3
     return (uint32_t)x;
-#endif
 }
 
 // Segmented inclusive scan over the lanes.  In: S = the sum of the run that is open at the end of the lane, F = 1 when a
 // row starts inside the lane.  Out: S = the sum of the run open at the end of the lane INCLUDING what lower lanes hold
 // of it; F = 1 when a row starts in this lane or below.  The operator (S, F) o (s, f) = (f ? s : S + s, F | f) is
 // associative: the DPP scan pattern of band_scan_incl_u32 applies (lanes that receive nothing get the identity (0, 0)).
-#ifndef SPRS_HIP_EMU
 template <int CTRL, int ROW_MASK, bool BOUND>
 __device__ __forceinline__ void band_seg_step(double &S, uint32_t &F) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(S), CTRL, ROW_MASK, 0xf, BOUND);
@@ -127,19 +118,8 @@ __device__ __forceinline__ void band_seg_step(double &S, uint32_t &F) {
     S = F ? S : vs + S;
     F |= fs;
 }
-#endif
 
 __device__ __forceinline__ void band_seg_scan(double &S, uint32_t &F, uint32_t lane) {
-#ifdef SPRS_HIP_EMU
-    for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
-        const double vs = __shfl_up(S, dlt, WAVE);
-        const uint32_t fs = __shfl_up(F, dlt, WAVE);
-        if (lane >= (uint32_t)dlt) {
-            if (!F) S = vs + S;
-            F |= fs;
-        }
-    }
-#else
     (void)lane;
     band_seg_step<0x111, 0xf, true>(S, F);
     band_seg_step<0x112, 0xf, true>(S, F);
@@ -147,20 +127,14 @@ __device__ __forceinline__ void band_seg_scan(double &S, uint32_t &F, uint32_t l
     band_seg_step<0x118, 0xf, true>(S, F);
     band_seg_step<0x142, 0xa, false>(S, F);
     band_seg_step<0x143, 0xc, false>(S, F);
-#endif
 }
 
 // value of the lane below (lane 0: 0.0, flag 0)
 __device__ __forceinline__ double band_lane_below(double S, uint32_t lane) {
-#ifdef SPRS_HIP_EMU
-    const double b = __shfl_up(S, 1, WAVE);
-    return lane ? b : 0.0;
-#else
     (void)lane;
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(S), 0x138, 0xf, 0xf, true);   // wave_shr:1
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(S), 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
-#endif
 }
 
 __device__ __forceinline__ double band_read_lane63(double v) {
@@ -752,20 +726,12 @@ constexpr int RU = 16;       // partials in flight per lane; the table rows are 
 
 // lane's bit of a wave-uniform mask as a condition, and the number of mask bits below the lane
 __device__ __forceinline__ bool band_mask_bit(uint32_t m_lo, uint32_t m_hi, uint32_t lane) {
-#ifdef SPRS_HIP_EMU
-    return (((unsigned long long)m_hi << 32 | m_lo) >> lane) & 1ull;
-#else
     (void)lane;
     return __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)m_hi << 32) | m_lo);     // the mask becomes EXEC / VCC as it is
-#endif
 }
 __device__ __forceinline__ uint32_t band_mask_rank(uint32_t m_lo, uint32_t m_hi, uint32_t lane) {
-#ifdef SPRS_HIP_EMU
-    return (uint32_t)__popcll(((unsigned long long)m_hi << 32 | m_lo) & ((1ull << lane) - 1ull));
-#else
     (void)lane;
     return __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
-#endif
 }
 
 // All pieces of every row, in ascending order.

@@ -88,11 +88,13 @@ extern Fiber *cur;
 extern Idx g_blockIdx, g_blockDim, g_gridDim;
 const Idx &tid_of_current();
 
-enum Op { OP_BALLOT, OP_SHFL, OP_SHFL_UP, OP_SHFL_DOWN, OP_SHFL_XOR, OP_BARRIER };
+enum Op { OP_BALLOT, OP_SHFL, OP_SHFL_UP, OP_SHFL_DOWN, OP_SHFL_XOR, OP_BARRIER, OP_DPP, OP_PERMLANE16_SWAP, OP_PERMLANE32_SWAP };
 // noinline: the return address identifies the call site inside the kernel
 // convergent + noduplicate: the host compiler must not clone a call into both arms of a branch (jump threading
 // would split the lanes of one logical collective over two call sites)
 uint64_t collective(Op op, uint64_t val, int arg, int width) __attribute__((noinline, convergent, noduplicate));
+// ... with a second operand per lane (the `old` value of a DPP move, the second register of a permlane swap)
+uint64_t collective2(Op op, uint64_t val, uint64_t val2, int arg, int width) __attribute__((noinline, convergent, noduplicate));
 void syncthreads() __attribute__((noinline, convergent, noduplicate));
 // a wave spinning on an LDS word written by another wave of the block (spgemm.hip, token hand-over): the fiber steps
 // aside and is resumed on the scheduler's next sweep over the block
@@ -159,6 +161,36 @@ template <typename T>
 HIPEMU_INLINE T __shfl_xor(T v, int mask, int width = 64) {
     return hipemu::from_bits<T>(hipemu::collective(hipemu::OP_SHFL_XOR, hipemu::to_bits(v), mask, width));
 }
+// The gfx9 DPP move (v_mov_b32_dpp) as the kernels use it through __builtin_amdgcn_update_dpp: the lane exchanges of the shipped
+// sources run here as written — quad_perm, row_shl / row_shr / row_ror, wave_shl:1 / wave_shr:1, row_mirror / row_half_mirror,
+// row_bcast:15 / 31, row and bank masks, bound_ctrl (hipemu.cpp: resolve_one) — and so do v_permlane16_swap / v_permlane32_swap
+// of gfx950.  scripts/probes/lane_ops.hip holds the same sequences against __shfl on the hardware.
+HIPEMU_INLINE int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    const int arg = (ctrl & 0x1ff) | ((row_mask & 0xf) << 12) | ((bank_mask & 0xf) << 16) | (bound_ctrl ? 1 << 20 : 0);
+    return (int)(uint32_t)hipemu::collective2(hipemu::OP_DPP, (uint32_t)src, (uint32_t)old, arg, 64);
+}
+struct hipemu_uint2 {
+    unsigned v[2];
+    unsigned operator[](int i) const { return v[i]; }
+};
+HIPEMU_INLINE hipemu_uint2 __builtin_amdgcn_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+    const uint64_t r = hipemu::collective2(hipemu::OP_PERMLANE16_SWAP, a, b, 0, 64);
+    return hipemu_uint2{{(unsigned)r, (unsigned)(r >> 32)}};
+}
+HIPEMU_INLINE hipemu_uint2 __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+    const uint64_t r = hipemu::collective2(hipemu::OP_PERMLANE32_SWAP, a, b, 0, 64);
+    return hipemu_uint2{{(unsigned)r, (unsigned)(r >> 32)}};
+}
+// v_mbcnt_lo / v_mbcnt_hi: mask bits below the lane (plus the addend); inverse ballot: the lane's bit of a wave-uniform mask
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned add) {
+    const unsigned lane = hipemu::tid_of_current().x & 63u;
+    return add + (unsigned)__builtin_popcount(lane >= 32 ? m : m & ((1u << lane) - 1u));
+}
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned add) {
+    const unsigned lane = hipemu::tid_of_current().x & 63u;
+    return add + (lane <= 32 ? 0u : (unsigned)__builtin_popcount(m & ((1u << (lane - 32)) - 1u)));
+}
+inline bool __builtin_amdgcn_inverse_ballot_w64(unsigned long long m) { return (m >> (hipemu::tid_of_current().x & 63u)) & 1ull; }
 HIPEMU_INLINE int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane, 64); }
 HIPEMU_INLINE int __builtin_amdgcn_readfirstlane(int v) {
     const unsigned long long m = __ballot(1);

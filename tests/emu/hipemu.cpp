@@ -20,7 +20,7 @@ struct Fiber {
     State state = DONE;
     // pending collective
     Op op;
-    uint64_t val = 0, result = 0;
+    uint64_t val = 0, val2 = 0, result = 0;
     int arg = 0, width = 64;
     const void *site = nullptr;
 };
@@ -92,6 +92,38 @@ uint64_t collective(Op op, uint64_t val, int arg, int width) {
     return me->result;
 }
 
+uint64_t collective2(Op op, uint64_t val, uint64_t val2, int arg, int width) {
+    Fiber *me = cur;
+    me->op = op;
+    me->val = val;
+    me->val2 = val2;
+    me->arg = arg;
+    me->width = width;
+    me->site = __builtin_return_address(0);
+    me->state = AT_COLLECTIVE;
+    yield_to_scheduler();
+    return me->result;
+}
+
+// source lane of a gfx9 DPP control for `lane` (-1: no valid source: outside the row / the wave)
+static int dpp_source(int ctrl, int lane) {
+    const int row = lane & ~15, i = lane & 15;
+    if (ctrl <= 0xff) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);                    // quad_perm
+    if (ctrl >= 0x101 && ctrl <= 0x10f) return i + (ctrl & 15) < 16 ? lane + (ctrl & 15) : -1;  // row_shl:n
+    if (ctrl >= 0x111 && ctrl <= 0x11f) return i - (ctrl & 15) >= 0 ? lane - (ctrl & 15) : -1;  // row_shr:n
+    if (ctrl >= 0x121 && ctrl <= 0x12f) return row + ((i - (ctrl & 15)) & 15);                  // row_ror:n
+    if (ctrl == 0x130) return lane + 1 < 64 ? lane + 1 : -1;                                    // wave_shl:1
+    if (ctrl == 0x134) return (lane + 1) & 63;                                                  // wave_rol:1
+    if (ctrl == 0x138) return lane - 1;                                                         // wave_shr:1
+    if (ctrl == 0x13c) return (lane - 1) & 63;                                                  // wave_ror:1
+    if (ctrl == 0x140) return row + 15 - i;                                                     // row_mirror
+    if (ctrl == 0x141) return (lane & ~7) | (7 - (lane & 7));                                   // row_half_mirror
+    if (ctrl == 0x142) return row >= 16 ? row - 1 : -1;                                         // row_bcast:15 (into the next row)
+    if (ctrl == 0x143) return lane >= 32 ? 31 : -1;                                             // row_bcast:31 (into rows 2 and 3)
+    fprintf(stderr, "hipemu: DPP control 0x%x is not modelled\n", ctrl);
+    abort();
+}
+
 static void trampoline() {
     g_launcher->call();
     cur->state = DONE;
@@ -114,14 +146,15 @@ static bool resolve_one(size_t w0, size_t w1) {
     }
     if (!site) return false;
     static const bool trace = getenv("HIPEMU_TRACE") != nullptr;
-    bool in[64];
-    uint64_t vals[64];
+    bool in[64] = {false};
+    uint64_t vals[64] = {0}, vals2[64] = {0};
     unsigned long long ballot = 0;
     for (size_t i = w0; i < w1; ++i) {
         Fiber &f = g_fibers[i];
         const size_t l = i - w0;
         in[l] = f.state == AT_COLLECTIVE && f.site == site;
         vals[l] = in[l] ? f.val : 0;
+        vals2[l] = in[l] ? f.val2 : 0;
         if (in[l] && f.op == OP_BALLOT && f.val) ballot |= 1ull << l;
     }
     if (trace) {
@@ -147,6 +180,35 @@ static bool resolve_one(size_t w0, size_t w1) {
             case OP_SHFL_UP: src = lane - f.arg < seg ? lane : lane - f.arg; break;
             case OP_SHFL_DOWN: src = lane + f.arg >= seg + w ? lane : lane + f.arg; break;
             case OP_SHFL_XOR: src = (lane ^ f.arg) >= seg + w || (lane ^ f.arg) < seg ? lane : (lane ^ f.arg); break;
+            case OP_DPP: {
+                // v_mov_b32_dpp: a lane outside the row / bank masks keeps `old`; one whose source lane does not exist (or is
+                // not executing) gets 0 with bound_ctrl and keeps `old` without
+                const int ctrl = f.arg & 0x1ff, row_mask = (f.arg >> 12) & 0xf, bank_mask = (f.arg >> 16) & 0xf;
+                const bool bound = (f.arg >> 20) & 1;
+                const bool written = ((row_mask >> (lane >> 4)) & 1) && ((bank_mask >> ((lane & 15) >> 2)) & 1);
+                const int s = dpp_source(ctrl, lane);
+                const bool ok = s >= 0 && (size_t)s < w1 - w0 && in[s];
+                f.result = !written ? f.val2 : ok ? vals[s] : bound ? 0 : f.val2;
+                break;
+            }
+            case OP_PERMLANE16_SWAP: {
+                // odd rows of the first operand <-> even rows of the second; result = new first | new second << 32
+                const bool odd = (lane >> 4) & 1;
+                const uint64_t a = odd ? vals2[lane - 16] : f.val, b = odd ? f.val2 : vals[lane + 16];
+                f.result = (a & 0xffffffffull) | (b << 32);
+                break;
+            }
+            case OP_PERMLANE32_SWAP: {
+                // upper half of the first operand <-> lower half of the second
+                const bool up = lane >= 32;
+                const uint64_t a = up ? vals2[lane - 32] : f.val, b = up ? f.val2 : vals[lane + 32];
+                f.result = (a & 0xffffffffull) | (b << 32);
+                break;
+            }
+        }
+        if (f.op == OP_DPP || f.op == OP_PERMLANE16_SWAP || f.op == OP_PERMLANE32_SWAP) {
+            f.state = READY;
+            continue;
         }
         if (f.op != OP_BALLOT && f.op != OP_BARRIER) {
             // a source lane that is inactive (exited, or elsewhere in a divergent branch) yields the own value

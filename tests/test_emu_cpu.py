@@ -23,6 +23,18 @@ def emu_lib():
     return os.path.join(EMU, "libsprs_hip_emu.so")
 
 
+def test_lane_exchanges_of_the_emulator(emu_lib):
+    """The shipped kernels' lane exchanges (sprs_amd/csrc/lanes.hpp and the DPP scan ladders: quad_perm, row_shr / row_shl /
+    row_ror, wave_shr / wave_shl, row_bcast 15 / 31 with row and bank masks, v_permlane16_swap / v_permlane32_swap) run in the
+    emulator AS WRITTEN — there is no __shfl alternative in the product sources — so the emulator's model of those controls is
+    itself checked here, by the probe that checks the hardware (scripts/probes/lane_ops.hip: every exchange against index
+    arithmetic, the group scans against a loop, the group sorts against std::sort)."""
+    r = subprocess.run(["make", "-C", EMU, "lane_ops_emu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([os.path.join(EMU, "lane_ops_emu"), "256"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and '"ok": true' in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
 @pytest.mark.parametrize("order", ["default", "reverse", "rotate"])
 def test_spgemm_kernels_under_wave_orders(emu_lib, order):
     env = dict(os.environ, SPRS_HIP_LIBRARY=emu_lib, HIPEMU_WAVE_ORDER=order)
