@@ -70,18 +70,23 @@ int32_t exclusive_scan_u64(const uint64_t *in, uint64_t *out, uint64_t n, hipStr
         return SPRS_HIP_OK;
     }
     const uint64_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
-    // block sums from the library's pool; the block goes back in NULL-STREAM order (pool_free, common.hpp), so a call on another
-    // stream waits for that stream first
+    // block sums: on the null stream from the library's pool, handed back in null-stream order (pool_free, common.hpp: the pool's
+    // blocks may still be in use by earlier null-stream work); on any other stream a block of its own, freed behind that stream
     uint64_t *sums = nullptr, cap = 0;
     int dev = 0;
     SPRS_TRY_HIP(hipGetDevice(&dev));
-    SPRS_TRY_HIP(pool_alloc((void **)&sums, (nblocks + 1) * sizeof(uint64_t), &cap, dev));
+    if (stream == nullptr) SPRS_TRY_HIP(pool_alloc((void **)&sums, (nblocks + 1) * sizeof(uint64_t), &cap, dev));
+    else SPRS_TRY_HIP(hipMalloc((void **)&sums, (nblocks + 1) * sizeof(uint64_t)));
     hipLaunchKernelGGL(scan_partial_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, n, sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, sums, nblocks);
     hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, in, n, sums, nblocks, out);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess && stream != nullptr) e = hipStreamSynchronize(stream);
-    pool_free(sums, cap, dev, true);
+    if (stream == nullptr) {
+        pool_free(sums, cap, dev, true);
+    } else {
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(sums);
+    }
     if (e != hipSuccess) return fail_hip(e, "exclusive_scan_u64");
     return SPRS_HIP_OK;
 }

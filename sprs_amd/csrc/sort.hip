@@ -92,22 +92,32 @@ int32_t radix_sort_pairs(uint64_t *keys, uint64_t *vals, uint64_t n, const std::
         for (int b = 0; b < f.second; b += 8) passes.push_back({f.first + b, (1u << (f.second - b < 8 ? f.second - b : 8)) - 1u});
     if (passes.empty()) return SPRS_HIP_OK;
     const uint64_t nchunks = (n + RS_CHUNK - 1) / RS_CHUNK;
-    // temporaries from the library's pool, handed back in null-stream order (a call on another stream waits for it first)
+    // temporaries: on the null stream from the library's pool, handed back in null-stream order (the pool's blocks may still be in
+    // use by earlier null-stream work); on any other stream blocks of their own, freed behind that stream
     uint64_t *tk = nullptr, *tv = nullptr, *hist = nullptr, *offs = nullptr;
     uint64_t cap_tk = 0, cap_tv = 0, cap_hist = 0, cap_offs = 0;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
-    auto cleanup = [&]() {
-        if (stream != nullptr) (void)hipStreamSynchronize(stream);
-        pool_free(tk, cap_tk, dev, true);
-        pool_free(tv, cap_tv, dev, true);
-        pool_free(hist, cap_hist, dev, true);
-        pool_free(offs, cap_offs, dev, true);
+    const bool pooled = stream == nullptr;
+    auto take = [&](uint64_t **p, uint64_t bytes, uint64_t *cap) {
+        return pooled ? pool_alloc((void **)p, bytes, cap, dev) : hipMalloc((void **)p, bytes);
     };
-    if (e == hipSuccess) e = pool_alloc((void **)&tk, n * 8, &cap_tk, dev);
-    if (e == hipSuccess) e = pool_alloc((void **)&tv, n * 8, &cap_tv, dev);
-    if (e == hipSuccess) e = pool_alloc((void **)&hist, (RS_BINS * nchunks + 1) * 8, &cap_hist, dev);
-    if (e == hipSuccess) e = pool_alloc((void **)&offs, (RS_BINS * nchunks + 1) * 8, &cap_offs, dev);
+    auto drop = [&](uint64_t *p, uint64_t cap) {
+        if (!p) return;
+        if (pooled) pool_free(p, cap, dev, true);
+        else (void)hipFree(p);
+    };
+    auto cleanup = [&]() {
+        if (!pooled) (void)hipStreamSynchronize(stream);
+        drop(tk, cap_tk);
+        drop(tv, cap_tv);
+        drop(hist, cap_hist);
+        drop(offs, cap_offs);
+    };
+    if (e == hipSuccess) e = take(&tk, n * 8, &cap_tk);
+    if (e == hipSuccess) e = take(&tv, n * 8, &cap_tv);
+    if (e == hipSuccess) e = take(&hist, (RS_BINS * nchunks + 1) * 8, &cap_hist);
+    if (e == hipSuccess) e = take(&offs, (RS_BINS * nchunks + 1) * 8, &cap_offs);
     if (e != hipSuccess) {
         cleanup();
         return fail_hip(e, "radix_sort_pairs");
