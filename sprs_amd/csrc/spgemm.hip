@@ -236,19 +236,70 @@ __global__ __launch_bounds__(256) void row_work_kernel(CsrView<IDX, PTR> A, CsrV
         const bool ok = r < rows;
         const uint64_t s = ok ? (uint64_t)A.indptr[r] : 0, e = ok ? (uint64_t)A.indptr[r + 1] : 0;
         uint64_t acc = 0;
-        for (uint64_t p = s + sl; p < e; p += 64) {                      // four strides of the 16 lanes in flight (a hub row of 2e4 k's is this pass's tail)
-            uint64_t k[4];
+        // the extent of B's row behind every entry goes to `ext` for the micro rows' kernels (start | saturated length: a micro
+        // row's k's have at most 64 entries each)
+        constexpr uint64_t HUB = 2048;                                   // k's from which the whole wave walks a row
+        const unsigned long long hubs = __ballot(sl == 0 && e - s >= HUB);
+        if (hubs) {                                                      // wave-uniform; a handful of rows per matrix
+            // a hub row (R-MAT 1M: 22 260 k's) walked by ONE 16-lane group was this pass's tail on config 5; all 64 lanes take it,
+            // four strides of 64 in flight, and the row's owner gets the sum
+            for (int g4 = 0; g4 < 4; ++g4) {
+                if (!((hubs >> (16 * g4)) & 1ull)) continue;
+                const uint64_t hs = __shfl(s, 16 * g4, WAVE), he = __shfl(e, 16 * g4, WAVE);
+                uint64_t part = 0;
+                for (uint64_t p = hs + lane; p < he; p += 256) {
+                    uint64_t k[4], bs[4], be[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) k[u] = p + 16 * u < e ? (uint64_t)A.indices[p + 16 * u] : ~0ull;
+                    for (int u = 0; u < 4; ++u) k[u] = (uint64_t)A.indices[p + 64 * u < he ? p + 64 * u : hs];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (k[u] != ~0ull) {
-                    const uint64_t bs = (uint64_t)B.indptr[k[u]], len = (uint64_t)B.indptr[k[u] + 1] - bs;
-                    acc += len;
-                    // the extent of B's row behind this entry, for the micro rows' kernels (start | saturated length: a micro
-                    // row's k's have at most 64 entries each)
-                    if (ext) ext[p + 16 * u] = bs | ((len < EXT_LEN_MAX ? len : EXT_LEN_MAX) << EXT_SHIFT);
+                    for (int u = 0; u < 4; ++u) {
+                        bs[u] = (uint64_t)B.indptr[k[u]];
+                        be[u] = (uint64_t)B.indptr[k[u] + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (p + 64 * u < he) {
+                            const uint64_t len = be[u] - bs[u];
+                            part += len;
+                            if (ext) ext[p + 64 * u] = bs[u] | ((len < EXT_LEN_MAX ? len : EXT_LEN_MAX) << EXT_SHIFT);
+                        }
                 }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, WAVE);
+                if (sub == (uint32_t)g4) acc = part;                     // (every lane of the owner group: the group sum below divides it out)
+            }
+        }
+        const bool hub_row = ok && e - s >= HUB;
+        if (hub_row) {
+            acc = sl == 0 ? acc : 0;                                     // the group's reduction below adds the 16 lanes
+        } else if (e - s <= 16) {                                        // one stride of the 16 lanes: nearly every row
+            if (s + sl < e) {
+                const uint64_t k = (uint64_t)A.indices[s + sl];
+                const uint64_t bs = (uint64_t)B.indptr[k], len = (uint64_t)B.indptr[k + 1] - bs;
+                acc = len;
+                if (ext) ext[s + sl] = bs | ((len < EXT_LEN_MAX ? len : EXT_LEN_MAX) << EXT_SHIFT);
+            }
+        } else {
+            // longer rows: four strides in flight, every load UNCONDITIONAL (a lane past the row's end reads the row's first entry
+            // and drops it) — a gather under a lane's condition is a branch that waits for that one load, and the 22 260 k's of
+            // the hub row of config 5 were 348 steps of five dependent round trips: the 1.14 ms of this pass
+            for (uint64_t p = s + sl; p < e; p += 64) {
+                uint64_t k[4], bs[4], be[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) k[u] = (uint64_t)A.indices[p + 16 * u < e ? p + 16 * u : s];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    bs[u] = (uint64_t)B.indptr[k[u]];
+                    be[u] = (uint64_t)B.indptr[k[u] + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p + 16 * u < e) {
+                        const uint64_t len = be[u] - bs[u];
+                        acc += len;
+                        if (ext) ext[p + 16 * u] = bs[u] | ((len < EXT_LEN_MAX ? len : EXT_LEN_MAX) << EXT_SHIFT);
+                    }
+            }
         }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);   // the 16 lanes of the row

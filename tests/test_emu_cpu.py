@@ -38,7 +38,7 @@ def test_lane_exchanges_of_the_emulator(emu_lib):
 @pytest.mark.parametrize("order", ["default", "reverse", "rotate"])
 def test_spgemm_kernels_under_wave_orders(emu_lib, order):
     env = dict(os.environ, SPRS_HIP_LIBRARY=emu_lib, HIPEMU_WAVE_ORDER=order)
-    sel = "golden_mul_csr_csr or zero_rows or structural_zeros or rectangular or multi_window or order_of_additions or class_boundaries or micro_rows"
+    sel = "golden_mul_csr_csr or zero_rows or structural_zeros or rectangular or multi_window or order_of_additions or class_boundaries or micro_rows or hub_rows"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_spgemm_gpu.py"), "-x", "-q", "-m", "gpu",
                         "-k", sel, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -298,6 +298,32 @@ def test_row_class_boundaries(hip, idx, ptr):
             hip.set_option("spgemm_heavy", 131072)
 
 
+def test_hub_rows_of_the_work_pass(hip):
+    """row_work_kernel walks a row of A with 16 lanes; one stride for rows of at most 16 k's, four unconditional strides beyond, and
+    the whole wave for a hub row (>= 2048 k's): rows of 0, 1, 16, 17, 64, 65, 2047, 2048, 2049 and 5000 k's next to each other (the
+    lengths on both sides of every switch, hub rows in different lane groups of one wave and alone in theirs), B with short rows —
+    products per row, classes, the extents the micro rows read and the whole product against the oracle, bits included."""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    inner, cols = 6000, 900
+    b_lens = rng.integers(0, 4, size=inner)
+    b_ip = np.zeros(inner + 1, dtype=np.int64)
+    b_ip[1:] = np.cumsum(b_lens)
+    b_ix = np.concatenate([np.sort(rng.choice(cols, size=int(l), replace=False)) for l in b_lens]).astype(np.int64)
+    b_dt = rng.standard_normal(b_ix.size)
+    a_lens = [0, 1, 16, 17, 2048, 64, 65, 2047, 2049, 3, 5000, 2, 2048, 2048, 2048, 2048, 5, 0]
+    a_ip = np.zeros(len(a_lens) + 1, dtype=np.int64)
+    a_ip[1:] = np.cumsum(a_lens)
+    a_ix = np.concatenate([np.sort(rng.choice(inner, size=l, replace=False)) for l in a_lens]).astype(np.int64)
+    a_dt = rng.standard_normal(a_ix.size)
+    a = ((len(a_lens), inner), a_ip.astype(np.uint64), a_ix.astype(np.uint64), a_dt)
+    b = ((inner, cols), b_ip.astype(np.uint64), b_ix.astype(np.uint64), b_dt)
+    ref = oracle.mul_csr_csr(*a, *b, threads=1)
+    _, ip, ix, dt = gpu_mul(a, b)
+    assert np.array_equal(ip, ref[1]) and np.array_equal(ix, ref[2])
+    assert np.array_equal(dt.view(np.uint64), ref[3].view(np.uint64))
+
+
 @pytest.mark.parametrize("idx,ptr", IDX_COMBOS)
 def test_micro_rows_lane_groups(hip, idx, ptr):
     """Rows of at most 16 / 32 / 64 products AND k's run on lane groups (micro_rows_kernel: 4 / 2 / 1 rows per wave, no LDS):
